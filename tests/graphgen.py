@@ -1,0 +1,30 @@
+"""Seeded synthetic CSR graphs / features for the tests (numpy only)."""
+import numpy as np
+
+
+def powerlaw_csr(num_node, mean_deg=8.0, alpha=0.8, dmax=None, seed=0, zero_frac=0.05):
+    """In-neighbour CSR with power-law degrees, uniform random neighbours.
+
+    Some nodes get degree 0 (zero_frac) so the len==0 / len<=fanout branches of
+    every sampler are exercised.
+    """
+    rng = np.random.RandomState(seed)
+    u = rng.random_sample(num_node)
+    deg = np.floor(u ** (-alpha)).astype(np.int64)
+    deg = np.maximum(1, (deg * (mean_deg / max(deg.mean(), 1e-9))).astype(np.int64))
+    if dmax is None:
+        dmax = max(4, num_node // 2)
+    deg = np.minimum(deg, dmax)
+    deg[rng.random_sample(num_node) < zero_frac] = 0
+    indptr = np.zeros(num_node + 1, dtype=np.uint32)
+    indptr[1:] = np.cumsum(deg)
+    indices = rng.randint(0, num_node, size=int(indptr[-1])).astype(np.uint32)
+    return indptr, indices
+
+
+def exact_features(num_node, dim, dtype=np.float32):
+    """feat[i, j] = (i * dim + j) & 0xFFFF -- exactly representable everywhere."""
+    v = (np.arange(num_node * dim, dtype=np.int64) & 0xFFFF).reshape(num_node, dim)
+    if np.dtype(dtype) == np.uint8:
+        v = v & 0xFF
+    return v.astype(dtype)
