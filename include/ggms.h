@@ -1,0 +1,217 @@
+/*
+ * ggms.h -- C ABI of the MI355X-native GGMS hot path (libggms_hip.so).
+ *
+ * Leaf operators: one entry point per reference leaf function, same argument
+ * meaning, so that a maintainer of the reference can bind them where the CUDA
+ * leaf is called today.  Citations are file:line relative to
+ * /root/reference/samgraph/common/.
+ *
+ * Conventions
+ *   - every pointer argument is DEVICE memory (or host memory mapped into the
+ *     device: hipHostMalloc / hipHostRegister) unless the name ends in _host;
+ *   - `stream` is a hipStream_t passed as void*; NULL = the null stream;
+ *   - no entry point allocates, frees or synchronises: scratch comes from the
+ *     caller (`ggms_*_workspace_bytes`), counts are written to device memory;
+ *     the reference's per-kernel StreamSync (e.g. cuda_sampling_khop3.cu:269)
+ *     is gone by design;
+ *   - ids are uint32 (IdType, constant.h:28); 0xffffffff is kEmptyKey (:75);
+ *   - return value: 0 on success, a negative ggms_status otherwise;
+ *     ggms_last_error() describes the last failure of the calling thread.
+ */
+#ifndef GGMS_H
+#define GGMS_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef uint32_t ggms_id_t;
+typedef void *ggms_stream_t;
+#define GGMS_EMPTY_KEY 0xffffffffu
+
+enum ggms_status {
+  GGMS_OK = 0,
+  GGMS_ERR_INVALID = -1, /* bad argument (null pointer, size out of range) */
+  GGMS_ERR_HIP = -2,     /* a HIP runtime call or launch failed             */
+  GGMS_ERR_NO_DEVICE = -3
+};
+
+/* DataType, common.h:38-46 (same integer codes) */
+enum ggms_dtype {
+  GGMS_F32 = 0,
+  GGMS_F64 = 1,
+  GGMS_F16 = 2,
+  GGMS_U8 = 3,
+  GGMS_I32 = 4,
+  GGMS_I8 = 5,
+  GGMS_I64 = 6
+};
+
+int ggms_abi_version(void);
+const char *ggms_last_error(void);
+size_t ggms_dtype_bytes(int dtype);
+
+/* ---------------------------------------------------------------------------
+ * Graph view.  num_part == 0: DeviceNormalGraph (cuda/dist_graph.h:160-180),
+ * indptr/indices are one CSR.  num_part > 0: DeviceDistGraph (:114-158): node
+ * v < num_cache_node lives in shard v % num_part at row v / num_part; every
+ * other node in slot num_part (the whole CSR, normally pinned host memory).
+ * part_indptr / part_indices are DEVICE arrays of num_part + 1 pointers.
+ * ------------------------------------------------------------------------- */
+typedef struct {
+  const ggms_id_t *indptr;
+  const ggms_id_t *indices;
+  const ggms_id_t *const *part_indptr;
+  const ggms_id_t *const *part_indices;
+  uint32_t num_part;
+  uint32_t num_cache_node;
+  uint32_t num_node;
+  uint32_t _pad;
+} ggms_graph_t;
+
+/* ---------------------------------------------------------------------------
+ * XORWOW state pool -- GPURandomStates, cuda/cuda_random_states.cu:36-109.
+ * One state is 6 x uint32 {d, v[5]} (24 B; cuRAND's Box-Muller fields are not
+ * kept).  states[t] = curand_init(seed + t, 0, 0).
+ * ------------------------------------------------------------------------- */
+#define GGMS_RNG_STATE_BYTES 24
+int ggms_random_states_init(void *states, size_t num_states, uint64_t seed,
+                            ggms_stream_t stream);
+/* sizing rule of cuda_random_states.cu:70-97 (host arithmetic only) */
+size_t ggms_random_states_count(int sample_type, const size_t *fanout,
+                                size_t num_fanout, size_t batch_size,
+                                size_t num_random_walk);
+
+/* ---------------------------------------------------------------------------
+ * Neighbour samplers.  Output is the compact COO the reference produces:
+ * (out_src = seed global id, out_dst = neighbour global id), seed order,
+ * *num_out_dev (device, 64-bit like the reference's size_t) = number of edges.
+ * out_src/out_dst must hold num_input * fanout entries.
+ * ------------------------------------------------------------------------- */
+/* SampleType, common/__init__.py:47-58 / common.h */
+enum ggms_sample_type {
+  GGMS_KHOP0 = 0,
+  GGMS_KHOP1 = 1,
+  GGMS_WEIGHTED_KHOP = 2,
+  GGMS_RANDOM_WALK = 3,
+  GGMS_WEIGHTED_KHOP_PREFIX = 4,
+  GGMS_KHOP2 = 5,
+  GGMS_WEIGHTED_KHOP_HASH_DEDUP = 6,
+  GGMS_KHOP3 = 7
+};
+
+size_t ggms_sample_workspace_bytes(int sample_type, size_t num_input,
+                                   size_t fanout);
+
+/* GPUSampleKHop3<G>, cuda/cuda_sampling_khop3.cu:234-318 */
+int ggms_sample_khop3(const ggms_graph_t *graph, const ggms_id_t *input,
+                      size_t num_input, size_t fanout, ggms_id_t *out_src,
+                      ggms_id_t *out_dst, uint64_t *num_out_dev, void *states,
+                      size_t num_states, void *workspace,
+                      size_t workspace_bytes, ggms_stream_t stream);
+
+/* GPUSampleKHop0<G> (NEW_ALGO), cuda/cuda_sampling_khop0.cu:243-335 */
+int ggms_sample_khop0(const ggms_graph_t *graph, const ggms_id_t *input,
+                      size_t num_input, size_t fanout, ggms_id_t *out_src,
+                      ggms_id_t *out_dst, uint64_t *num_out_dev,
+                      void *workspace, size_t workspace_bytes,
+                      ggms_stream_t stream);
+
+/* ---------------------------------------------------------------------------
+ * Ordered hash table -- OrderedHashTable, cuda/cuda_hashtable.h:103-153,
+ * cuda/cuda_hashtable.cu:699-1064.  Dedup with contiguous, prefix-stable local
+ * ids; n2o[0 .. num_items) is the unique list.  Canonical order among new
+ * keys: first occurrence in the input (DESIGN.md "canonical semantics").
+ * The caller owns the three buffers; the struct is plain data.
+ * ------------------------------------------------------------------------- */
+typedef struct {
+  void *o2n;               /* o2n_size buckets of 16 B                      */
+  ggms_id_t *n2o;          /* n2o_size ids                                   */
+  uint32_t *num_items_dev; /* device counter                                 */
+  uint64_t o2n_size;       /* power of two                                   */
+  uint64_t n2o_size;
+  uint32_t version;        /* bumped by ggms_hashtable_reset                 */
+  uint32_t _pad;
+} ggms_hashtable_t;
+
+#define GGMS_HT_BUCKET_BYTES 16
+/* TableSize(num, scale = 2), cuda_hashtable.cu:146-149 */
+size_t ggms_hashtable_num_buckets(size_t capacity);
+/* constructor body, cuda_hashtable.cu:699-729: fills buckets with 0xff */
+int ggms_hashtable_init(ggms_hashtable_t *ht, ggms_stream_t stream);
+/* Reset, cuda_hashtable.cu:739-742: O(1) version bump (+ counter clear) */
+int ggms_hashtable_reset(ggms_hashtable_t *ht, ggms_stream_t stream);
+size_t ggms_hashtable_workspace_bytes(size_t num_input);
+/* FillWithDuplicates :744-837 and FillWithDupRevised :850-912.  If
+ * unique_out != NULL the n2o prefix is also copied there (what
+ * FillWithDuplicates returns).  *ht->num_items_dev is updated on device. */
+int ggms_hashtable_fill_with_duplicates(ggms_hashtable_t *ht,
+                                        const ggms_id_t *input,
+                                        size_t num_input,
+                                        ggms_id_t *unique_out, void *workspace,
+                                        size_t workspace_bytes,
+                                        ggms_stream_t stream);
+/* GPUMapEdges, cuda/cuda_mapping.cu:68-81 */
+int ggms_map_edges(const ggms_hashtable_t *ht, const ggms_id_t *global_src,
+                   ggms_id_t *new_src, const ggms_id_t *global_dst,
+                   ggms_id_t *new_dst, size_t num_edges, ggms_stream_t stream);
+
+/* ---------------------------------------------------------------------------
+ * Feature extract -- GPUExtract, cuda/cuda_extraction.cu:74-117:
+ * dst[i, :] = src[index[i], :].  src may be device or device-mapped host
+ * memory (gpu_extract zero-copy path, dist_loops.cc:585-634).
+ * ------------------------------------------------------------------------- */
+int ggms_extract(void *dst, const void *src, const ggms_id_t *index,
+                 size_t num_index, size_t dim, int dtype,
+                 ggms_stream_t stream);
+
+/* ---------------------------------------------------------------------------
+ * Feature cache -- GPUCacheManager, cuda/cuda_cache_manager_device.cu.
+ * table[node] = cache slot or kEmptyKey.
+ * ------------------------------------------------------------------------- */
+size_t ggms_cache_index_workspace_bytes(size_t num_nodes);
+/* GetMissCacheIndex :355-441 (kernels :40-169): stable split of `nodes` into
+ * miss (src = global id, dst = output row) and hit (src = slot, dst = row). */
+int ggms_get_miss_cache_index(const ggms_id_t *table, const ggms_id_t *nodes,
+                              size_t num_nodes, ggms_id_t *miss_src_index,
+                              ggms_id_t *miss_dst_index,
+                              uint64_t *num_miss_dev,
+                              ggms_id_t *cache_src_index,
+                              ggms_id_t *cache_dst_index,
+                              uint64_t *num_cache_dev, void *workspace,
+                              size_t workspace_bytes, ggms_stream_t stream);
+/* combine_cache_data :254-275, extract_miss_data :233-252, combine_miss_data
+ * :209-231: out[dst_index[i], :] = src[src_index[i], :]; a NULL index means
+ * the identity.  num may be overridden by a device count (num_dev != NULL;
+ * `num` is then the upper bound used to size the launch). */
+int ggms_gather_scatter(void *out, const void *src, const ggms_id_t *src_index,
+                        const ggms_id_t *dst_index, size_t num,
+                        const uint64_t *num_dev, size_t dim, int dtype,
+                        ggms_stream_t stream);
+/* combine_cache_data_for_partition :277-299 with DeviceDistFeature
+ * (cuda/dist_graph.h:182-212): slot s lives in parts[s % num_part] at row
+ * s / num_part.  parts_dev: DEVICE array of num_part base pointers (local
+ * HBM, peer HBM mapped with hipIpcOpenMemHandle, or mapped host memory). */
+int ggms_gather_scatter_partition(void *out, const void *const *parts_dev,
+                                  uint32_t num_part,
+                                  const ggms_id_t *src_index,
+                                  const ggms_id_t *dst_index, size_t num,
+                                  const uint64_t *num_dev, size_t dim,
+                                  int dtype, ggms_stream_t stream);
+/* One-pass replacement of GetMissCacheIndex + GPUExtractMissData +
+ * CombineCacheData (dist_loops.cc:1209-1285): out[i,:] = table[nodes[i]] ==
+ * kEmptyKey ? host_feat[nodes[i],:] : parts[slot % P][slot / P,:].
+ * num_part == 0 -> single cache array parts_dev[0].  Also counts misses. */
+int ggms_extract_cached(void *out, const ggms_id_t *nodes, size_t num_nodes,
+                        const uint64_t *num_nodes_dev, const ggms_id_t *table,
+                        const void *const *parts_dev, uint32_t num_part,
+                        const void *host_feat, size_t dim, int dtype,
+                        uint64_t *num_miss_dev, ggms_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GGMS_H */

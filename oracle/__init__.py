@@ -19,7 +19,7 @@ _LIB = None
 _REF = None
 
 EMPTY_KEY = 0xFFFFFFFF
-KHOP0, KHOP3, CPU_KHOP0 = 0, 6, 100
+KHOP0, KHOP3, CPU_KHOP0 = 0, 7, 100
 
 u32p = C.POINTER(C.c_uint32)
 XORWOW_DTYPE = np.dtype([("d", "<u4"), ("v", "<u4", (5,))])

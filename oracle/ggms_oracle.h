@@ -145,7 +145,7 @@ void orc_ht_map_edges(const orc_hashtable_t *ht, const orc_id_t *src,
                       orc_id_t *new_dst);
 
 /* ---- multi-layer sample loop (dist_loops.cc:62-368, cpu_loops.cc:55-192) */
-enum { ORC_KHOP0 = 0, ORC_KHOP3 = 6, ORC_CPU_KHOP0 = 100 };
+enum { ORC_KHOP0 = 0, ORC_KHOP3 = 7, ORC_CPU_KHOP0 = 100 };
 typedef struct {
   size_t num_layer;
   size_t *num_src, *num_dst, *num_edge; /* per layer, index = layer id    */

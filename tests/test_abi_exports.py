@@ -1,0 +1,51 @@
+"""C-ABI library loads on a CPU-only host and exports every symbol include/*.h declares."""
+import ctypes
+import os
+import re
+
+import xgnn_amd
+from xgnn_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared(header):
+    text = open(os.path.join(ROOT, "include", header)).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b((?:ggms|samgraph)_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_ggms_header_symbols_exported_and_bound():
+    names = _declared("ggms.h")
+    assert len(names) >= 20
+    h = ctypes.CDLL(xgnn_amd.LIB_PATH)
+    for n in names:
+        assert hasattr(h, n), f"{n} declared in include/ggms.h but not exported"
+        assert n in _lib.SYMBOLS, f"{n} has no ctypes binding in xgnn_amd/_lib.py"
+    for n in _lib.SYMBOLS:
+        assert n in names, f"{n} bound but not declared in include/ggms.h"
+
+
+def test_host_only_entry_points():
+    l = xgnn_amd.lib()
+    assert l.ggms_abi_version() == 1
+    # TableSize(num, 2), cuda_hashtable.cu:146-149
+    for cap, want in [(2, 8), (3, 8), (4, 16), (1000, 2048), (2288000, 8388608), (8448000, 33554432)]:
+        assert l.ggms_hashtable_num_buckets(cap) == want, cap
+    assert [l.ggms_dtype_bytes(c) for c in range(7)] == [4, 8, 2, 1, 4, 1, 8]
+    # GPURandomStates sizing, cuda_random_states.cu:70-97 with PredictNumNodes (common.cc:488-497)
+    f = (ctypes.c_size_t * 2)(25, 10)
+    assert l.ggms_random_states_count(7, f, 2, 8000, 0) == 8000 + 8000 * 25
+    assert l.ggms_random_states_count(2, f, 2, 8000, 0) == 512 * 1024
+    f3 = (ctypes.c_size_t * 3)(5, 5, 5)
+    assert l.ggms_random_states_count(3, f3, 3, 100, 4) == ((100 * 6 * 6 + 63) // 64) * 256
+
+
+def test_no_cpu_fallback():
+    import pytest
+    import torch
+    from xgnn_amd import ops
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(Exception):
+        ops.extract(torch.zeros(4, 4), torch.zeros(2, dtype=torch.int32))

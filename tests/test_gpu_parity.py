@@ -1,0 +1,254 @@
+"""GPU parity: HIP path (through the C ABI) vs the CPU oracle, bit-exact."""
+import numpy as np
+import pytest
+
+import oracle
+from graphgen import exact_features, powerlaw_csr
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a GPU (run with -m gpu on an MI355X box)")
+    from xgnn_amd import ops as _ops
+    return _ops
+
+
+def dev(a):
+    a = np.ascontiguousarray(a)
+    if a.dtype == np.uint32:
+        a = a.view(np.int32)
+    return torch.from_numpy(a).cuda()
+
+
+def host_u32(t, n=None):
+    a = t.cpu().numpy()
+    if n is not None:
+        a = a[:n]
+    return a.view(np.uint32) if a.dtype == np.int32 else a
+
+
+def states_np(t):
+    a = t.cpu().numpy().view(np.uint32)
+    return a
+
+
+# ------------------------------------------------------------------ RNG
+def test_xorwow_state_pool(ops):
+    st = ops.random_states(1000, 0x5EED)
+    want = oracle.random_states(1000, 0x5EED)
+    got = states_np(st)
+    np.testing.assert_array_equal(got[:, 0], want["d"])
+    np.testing.assert_array_equal(got[:, 1:], want["v"])
+
+
+# -------------------------------------------------------------- extract
+@pytest.mark.parametrize("dtype,dim", [(np.float32, 100), (np.float32, 128), (np.float32, 256), (np.float32, 1),
+                                       (np.float64, 5), (np.int16, 7), (np.uint8, 3), (np.uint8, 33),
+                                       (np.int32, 32), (np.int64, 1), (np.float32, 602)])
+@pytest.mark.parametrize("n", [0, 1, 63, 64, 65, 1000, 4097])
+def test_extract(ops, dtype, dim, n):
+    rng = np.random.RandomState(dim * 31 + n)
+    N = 5000
+    table = exact_features(N, dim, dtype)
+    idx = rng.randint(0, N, n).astype(np.uint32)
+    t_table = dev(table)
+    got = ops.extract(t_table, dev(idx)) if n else ops.extract(t_table, torch.zeros(0, dtype=torch.int32, device="cuda"))
+    want = oracle.extract(table, idx)
+    assert got.cpu().numpy().tobytes() == want.tobytes()
+
+
+def test_extract_large_properties(ops):
+    """products-sized gather: checksum + idempotence (size-independent properties)."""
+    N, dim, n = 2_449_029, 100, 1_190_000
+    feat = torch.arange(N * dim, dtype=torch.int32, device="cuda").bitwise_and_(0xFFFF).to(torch.float32).view(N, dim)
+    g = torch.Generator(device="cuda").manual_seed(1)
+    idx = torch.randint(0, N, (n,), dtype=torch.int32, device="cuda", generator=g)
+    out = ops.extract(feat, idx)
+    ref = feat[idx.long()]
+    assert torch.equal(out, ref)
+    again = ops.extract(out, torch.arange(n, dtype=torch.int32, device="cuda"))
+    assert torch.equal(again, out)
+
+
+# ------------------------------------------------------------ hash table
+def _check_fill(ops, ht_gpu, ht_orc, items):
+    ht_gpu.fill_with_duplicates(dev(items))
+    ht_orc.fill_with_duplicates(items)
+    assert ht_gpu.num_items == ht_orc.num_items
+    np.testing.assert_array_equal(host_u32(ht_gpu.unique()), ht_orc.unique())
+
+
+@pytest.mark.parametrize("n", [1, 17, 512, 1024, 1025, 100_000])
+def test_hashtable_fill_and_map(ops, n):
+    """Semantics pinned by samgraph/unittest/test_hashmap.cc:84-276 (set equality, prefix
+    stability, local id == position) plus first-occurrence order vs the oracle."""
+    rng = np.random.RandomState(n)
+    universe = max(4, n // 2)
+    cap = 4 * n + 16
+    ht = ops.OrderedHashTable(cap)
+    orc = oracle.HashTable(universe + 1, cap)
+    for rnd in range(3):  # reuse with Reset (test_hashmap.cc:275-276)
+        ht.reset()
+        orc.reset()
+        a = rng.randint(0, universe, n).astype(np.uint32)
+        _check_fill(ops, ht, orc, a)
+        prefix = host_u32(ht.unique()).copy()
+        b = rng.randint(0, universe, 2 * n).astype(np.uint32)
+        _check_fill(ops, ht, orc, b)
+        uniq = host_u32(ht.unique())
+        np.testing.assert_array_equal(uniq[: prefix.size], prefix)          # prefix stability
+        assert set(uniq.tolist()) == set(a.tolist()) | set(b.tolist())      # set equality
+        assert len(set(uniq.tolist())) == uniq.size                         # no duplicates
+        ns, nd = ht.map_edges(dev(a), dev(b[:n]))
+        os_, od = orc.map_edges(a, b[:n])
+        np.testing.assert_array_equal(host_u32(ns), os_)
+        np.testing.assert_array_equal(host_u32(nd), od)
+        # SearchO2N(unique[i]).local == i  (test_hashmap.cu:24-37)
+        loc, _ = ht.map_edges(ht.unique().contiguous(), None)
+        np.testing.assert_array_equal(host_u32(loc), np.arange(uniq.size, dtype=np.uint32))
+
+
+def test_hashtable_unique_out_and_empty(ops):
+    ht = ops.OrderedHashTable(64)
+    ht.reset()
+    out = torch.full((64,), -1, dtype=torch.int32, device="cuda")
+    ht.fill_with_duplicates(dev(np.array([5, 5, 9, 5, 1], np.uint32)), unique_out=out)
+    np.testing.assert_array_equal(host_u32(out)[:3], [5, 9, 1])
+    ht.fill_with_duplicates(torch.zeros(0, dtype=torch.int32, device="cuda"), num_input=0, unique_out=out)
+    assert ht.num_items == 3
+
+
+# --------------------------------------------------------------- samplers
+GRAPHS = {
+    "small": dict(num_node=300, mean_deg=12, seed=1),
+    "mid": dict(num_node=20_000, mean_deg=30, seed=2),
+}
+
+
+@pytest.fixture(scope="module")
+def graphs(ops):
+    out = {}
+    for k, kw in GRAPHS.items():
+        ip, ix = powerlaw_csr(**kw)
+        out[k] = (ip, ix, ops.DeviceGraph(dev(ip), dev(ix)))
+    return out
+
+
+@pytest.mark.parametrize("gname,n,fanout", [("small", 1, 5), ("small", 129, 3), ("small", 300, 25), ("small", 0, 4),
+                                            ("mid", 8000, 10), ("mid", 20000, 25), ("mid", 5000, 5),
+                                            ("mid", 1000, 40), ("mid", 777, 100)])
+def test_sample_khop3(ops, graphs, gname, n, fanout):
+    ip, ix, g = graphs[gname]
+    rng = np.random.RandomState(n + fanout)
+    inp = rng.randint(0, ip.size - 1, n).astype(np.uint32)
+    nstates = max(64, (n + 127) // 128 * 8)
+    st_gpu = ops.random_states(nstates, 0xABCDEF)
+    st_orc = oracle.random_states(nstates, 0xABCDEF)
+    for rep in range(2):  # states persist across calls (khop3.cu:145)
+        src, dst, num = ops.sample_khop3(g, dev(inp) if n else torch.zeros(0, dtype=torch.int32, device="cuda"),
+                                         fanout, st_gpu)
+        wsrc, wdst = oracle.sample_khop3(ip, ix, inp, fanout, st_orc)
+        m = int(num.item())
+        assert m == wsrc.size
+        np.testing.assert_array_equal(host_u32(src, m), wsrc)
+        np.testing.assert_array_equal(host_u32(dst, m), wdst)
+        got_states = states_np(st_gpu)
+        np.testing.assert_array_equal(got_states[:, 0], st_orc["d"])
+        np.testing.assert_array_equal(got_states[:, 1:], st_orc["v"])
+
+
+@pytest.mark.parametrize("gname,n,fanout", [("small", 1, 5), ("small", 65, 3), ("small", 300, 25), ("small", 0, 4),
+                                            ("mid", 8000, 10), ("mid", 3000, 25), ("mid", 1000, 64)])
+def test_sample_khop0(ops, graphs, gname, n, fanout):
+    ip, ix, g = graphs[gname]
+    rng = np.random.RandomState(n * 7 + fanout)
+    inp = rng.randint(0, ip.size - 1, n).astype(np.uint32)
+    src, dst, num = ops.sample_khop0(g, dev(inp) if n else torch.zeros(0, dtype=torch.int32, device="cuda"), fanout)
+    wsrc, wdst = oracle.sample_khop0(ip, ix, inp, fanout)
+    m = int(num.item())
+    assert m == wsrc.size
+    np.testing.assert_array_equal(host_u32(src, m), wsrc)
+    np.testing.assert_array_equal(host_u32(dst, m), wdst)
+
+
+def test_khop3_properties_full_size(ops):
+    """BASELINE-sized layer (88k seeds x fanout 25): distinctness / membership / counts."""
+    ip, ix = powerlaw_csr(200_000, mean_deg=40, seed=5, zero_frac=0.01)
+    g = ops.DeviceGraph(dev(ip), dev(ix))
+    n, fanout = 88_000, 25
+    inp = np.random.RandomState(0).permutation(200_000)[:n].astype(np.uint32)
+    st = ops.random_states(n, 1)
+    src, dst, num = ops.sample_khop3(g, dev(inp), fanout, st)
+    m = int(num.item())
+    src, dst = host_u32(src, m), host_u32(dst, m)
+    deg = (ip[1:] - ip[:-1])[inp].astype(np.int64)
+    cnt = np.minimum(deg, fanout)
+    assert m == cnt.sum()
+    np.testing.assert_array_equal(src, np.repeat(inp, cnt))
+    off = np.concatenate([[0], np.cumsum(cnt)])
+    for i in np.random.RandomState(1).randint(0, n, 300):
+        nb = ix[ip[inp[i]]: ip[inp[i] + 1]]
+        got = dst[off[i]: off[i + 1]]
+        if deg[i] <= fanout:
+            np.testing.assert_array_equal(got, nb)
+        else:
+            # `fanout` DISTINCT positions of the list: as multisets, got is a sub-multiset of nb
+            vals, c_got = np.unique(got, return_counts=True)
+            c_nb = np.array([(nb == v).sum() for v in vals])
+            assert (c_got <= c_nb).all()
+
+
+# ------------------------------------------------------------------ cache
+@pytest.mark.parametrize("n,ratio", [(0, 0.5), (1, 0.5), (1023, 0.0), (1024, 1.0), (5000, 0.3), (100_000, 0.64)])
+def test_get_miss_cache_index(ops, n, ratio):
+    N = 50_000
+    rng = np.random.RandomState(n + 1)
+    rank = rng.permutation(N).astype(np.uint32)
+    _, table = oracle.cache_build(rank, int(N * ratio), False)
+    nodes = rng.randint(0, N, n).astype(np.uint32)
+    t_nodes = dev(nodes) if n else torch.zeros(0, dtype=torch.int32, device="cuda")
+    ms, md, nm, hs, hd, nh = ops.get_miss_cache_index(dev(table), t_nodes)
+    wms, wmd, whs, whd = oracle.get_miss_cache_index(table, nodes)
+    assert int(nm.item()) == wms.size and int(nh.item()) == whs.size
+    np.testing.assert_array_equal(host_u32(ms, wms.size), wms)
+    np.testing.assert_array_equal(host_u32(md, wms.size), wmd)
+    np.testing.assert_array_equal(host_u32(hs, whs.size), whs)
+    np.testing.assert_array_equal(host_u32(hd, whs.size), whd)
+
+
+@pytest.mark.parametrize("P", [1, 2, 3, 8])
+@pytest.mark.parametrize("dim", [100, 128])
+def test_partition_cache_paths(ops, P, dim):
+    """combine_cache_data_for_partition + miss path vs oracle, and the fused one-pass extract."""
+    N, n, ratio = 20_000, 7000, 0.4
+    rng = np.random.RandomState(P * 100 + dim)
+    feat = exact_features(N, dim, np.float32)
+    rank = rng.permutation(N).astype(np.uint32)
+    num_cached = int(N * ratio)
+    rank_s, table = oracle.cache_build(rank, num_cached, True)
+    parts = [oracle.partition_feature(feat, rank_s, num_cached, p, P) for p in range(P)]
+    nodes = rng.randint(0, N, n).astype(np.uint32)
+    wms, wmd, whs, whd = oracle.get_miss_cache_index(table, nodes)
+    want = np.zeros((n, dim), np.float32)
+    oracle.gather_scatter(want, feat, wms, wmd)
+    oracle.gather_scatter_partition(want, parts, whs, whd)
+    np.testing.assert_array_equal(want, feat[nodes])  # oracle self-consistency
+
+    t_parts = [dev(p) for p in parts]
+    ptab = ops.part_pointer_table(t_parts, "cuda")
+    t_feat = dev(feat)  # stands in for the pinned-host tier in this test
+    ms, md, nm, hs, hd, nh = ops.get_miss_cache_index(dev(table), dev(nodes))
+    out = torch.zeros((n, dim), dtype=torch.float32, device="cuda")
+    ops.gather_scatter(out, t_feat, ms, md, num=n, num_dev=nm)
+    ops.gather_scatter_partition(out, ptab, P, hs, hd, num=n, num_dev=nh)
+    assert out.cpu().numpy().tobytes() == want.tobytes()
+
+    out2 = torch.zeros((n, dim), dtype=torch.float32, device="cuda")
+    nmiss = torch.zeros(1, dtype=torch.int64, device="cuda")
+    ops.extract_cached(out2, dev(nodes), dev(table), ptab, P, t_feat, num_miss=nmiss)
+    assert out2.cpu().numpy().tobytes() == want.tobytes()
+    assert int(nmiss.item()) == wms.size

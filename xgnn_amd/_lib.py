@@ -1,0 +1,75 @@
+"""ctypes binding of include/ggms.h.  Fails loudly when the library is absent."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libggms_hip.so")
+_LIB = None
+
+
+class GgmsError(RuntimeError):
+    pass
+
+
+class Graph(C.Structure):
+    """ggms_graph_t"""
+    _fields_ = [("indptr", C.c_void_p), ("indices", C.c_void_p),
+                ("part_indptr", C.c_void_p), ("part_indices", C.c_void_p),
+                ("num_part", C.c_uint32), ("num_cache_node", C.c_uint32),
+                ("num_node", C.c_uint32), ("_pad", C.c_uint32)]
+
+
+class HashTable(C.Structure):
+    """ggms_hashtable_t"""
+    _fields_ = [("o2n", C.c_void_p), ("n2o", C.c_void_p), ("num_items_dev", C.c_void_p),
+                ("o2n_size", C.c_uint64), ("n2o_size", C.c_uint64),
+                ("version", C.c_uint32), ("_pad", C.c_uint32)]
+
+
+# name -> (restype, argtypes); every symbol declared in include/ggms.h
+_vp, _sz, _u64, _u32, _i = C.c_void_p, C.c_size_t, C.c_uint64, C.c_uint32, C.c_int
+SYMBOLS = {
+    "ggms_abi_version": (_i, []),
+    "ggms_last_error": (C.c_char_p, []),
+    "ggms_dtype_bytes": (_sz, [_i]),
+    "ggms_random_states_init": (_i, [_vp, _sz, _u64, _vp]),
+    "ggms_random_states_count": (_sz, [_i, C.POINTER(_sz), _sz, _sz, _sz]),
+    "ggms_sample_workspace_bytes": (_sz, [_i, _sz, _sz]),
+    "ggms_sample_khop3": (_i, [C.POINTER(Graph), _vp, _sz, _sz, _vp, _vp, _vp, _vp, _sz, _vp, _sz, _vp]),
+    "ggms_sample_khop0": (_i, [C.POINTER(Graph), _vp, _sz, _sz, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "ggms_hashtable_num_buckets": (_sz, [_sz]),
+    "ggms_hashtable_init": (_i, [C.POINTER(HashTable), _vp]),
+    "ggms_hashtable_reset": (_i, [C.POINTER(HashTable), _vp]),
+    "ggms_hashtable_workspace_bytes": (_sz, [_sz]),
+    "ggms_hashtable_fill_with_duplicates": (_i, [C.POINTER(HashTable), _vp, _sz, _vp, _vp, _sz, _vp]),
+    "ggms_map_edges": (_i, [C.POINTER(HashTable), _vp, _vp, _vp, _vp, _sz, _vp]),
+    "ggms_extract": (_i, [_vp, _vp, _vp, _sz, _sz, _i, _vp]),
+    "ggms_cache_index_workspace_bytes": (_sz, [_sz]),
+    "ggms_get_miss_cache_index": (_i, [_vp, _vp, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "ggms_gather_scatter": (_i, [_vp, _vp, _vp, _vp, _sz, _vp, _sz, _i, _vp]),
+    "ggms_gather_scatter_partition": (_i, [_vp, _vp, _u32, _vp, _vp, _sz, _vp, _sz, _i, _vp]),
+    "ggms_extract_cached": (_i, [_vp, _vp, _sz, _vp, _vp, _vp, _u32, _vp, _sz, _i, _vp, _vp]),
+}
+
+
+def lib():
+    """Load libggms_hip.so (once).  Raises GgmsError if it has not been built."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise GgmsError(
+                f"{LIB_PATH} is missing: build it with `make -C xgnn_amd/csrc` "
+                "(or `python -c 'import __graft_entry__ as g; g.build()'`). There is no CPU fallback.")
+        h = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(h, name)  # AttributeError if the symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        _LIB = h
+    return _LIB
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = lib().ggms_last_error().decode(errors="replace")
+        raise GgmsError(f"{what} failed (status {rc}): {msg}")

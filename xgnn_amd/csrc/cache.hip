@@ -1,0 +1,73 @@
+// cache.hip -- feature-cache hit/miss split.
+//
+// Reference: GetMissCacheIndex (cuda/cuda_cache_manager_device.cu:355-441) =
+// count_miss_cache :40-75 + 2 x cub::DeviceScan + get_miss_index :77-117 +
+// get_cache_index :119-169, with two D2H copies of the totals.
+// Here: ONE stable scan of the miss flags.  A hit's position in the hit list is
+// i - (number of misses before i), so both lists come out of the same pass, in
+// input order, and both totals stay on the device.
+#include "tile_scan.h"
+
+namespace ggms {
+
+struct MissFlag {
+  const uint32_t *table;
+  const uint32_t *nodes;
+  __device__ __forceinline__ uint32_t operator()(uint64_t i) const {
+    return table[nodes[i]] == kEmptyKey ? 1u : 0u;
+  }
+};
+
+struct SplitEmit {
+  const uint32_t *table;
+  const uint32_t *nodes;
+  uint32_t *miss_src, *miss_dst, *hit_src, *hit_dst;
+  uint64_t *num_miss, *num_hit;
+  Count n;
+  __device__ __forceinline__ void operator()(uint64_t i, uint32_t miss, uint32_t misses_before) const {
+    const uint32_t node = nodes[i];
+    if (miss) {
+      miss_dst[misses_before] = (uint32_t)i; // row in the batch output
+      miss_src[misses_before] = node;        // row in the full (host) table
+    } else {
+      const uint32_t h = (uint32_t)i - misses_before;
+      hit_dst[h] = (uint32_t)i;
+      hit_src[h] = table[node];              // cache slot
+    }
+    if (i + 1 == n.get()) {
+      *num_miss = misses_before + miss;
+      *num_hit = (i + 1) - (misses_before + miss);
+    }
+  }
+};
+
+} // namespace ggms
+
+using namespace ggms;
+
+extern "C" {
+
+size_t ggms_cache_index_workspace_bytes(size_t num_nodes) {
+  return (tile_scan_words(num_nodes) + 16) * sizeof(uint32_t);
+}
+
+int ggms_get_miss_cache_index(const ggms_id_t *table, const ggms_id_t *nodes, size_t num_nodes,
+                              ggms_id_t *miss_src_index, ggms_id_t *miss_dst_index, uint64_t *num_miss_dev,
+                              ggms_id_t *cache_src_index, ggms_id_t *cache_dst_index, uint64_t *num_cache_dev,
+                              void *workspace, size_t workspace_bytes, ggms_stream_t stream) {
+  GGMS_CHECK_ARG(num_miss_dev && num_cache_dev);
+  hipStream_t s = to_stream(stream);
+  GGMS_HIP(hipMemsetAsync(num_miss_dev, 0, sizeof(uint64_t), s));
+  GGMS_HIP(hipMemsetAsync(num_cache_dev, 0, sizeof(uint64_t), s));
+  if (num_nodes == 0) return GGMS_OK;
+  GGMS_CHECK_ARG(table && nodes && miss_src_index && miss_dst_index && cache_src_index && cache_dst_index);
+  GGMS_CHECK_ARG(workspace && workspace_bytes >= ggms_cache_index_workspace_bytes(num_nodes));
+  GGMS_CHECK_ARG(num_nodes < (1ull << 32));
+  const Count n = count_of(num_nodes);
+  return tile_scan(MissFlag{table, nodes},
+                   SplitEmit{table, nodes, miss_src_index, miss_dst_index, cache_src_index, cache_dst_index,
+                             num_miss_dev, num_cache_dev, n},
+                   num_nodes, n, (uint32_t *)workspace, nullptr, nullptr, nullptr, s);
+}
+
+} // extern "C"

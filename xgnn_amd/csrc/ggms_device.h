@@ -1,0 +1,173 @@
+// ggms_device.h -- shared device-side building blocks (gfx950, wave64).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/ggms.h"
+
+namespace ggms {
+
+constexpr uint32_t kEmptyKey = GGMS_EMPTY_KEY;
+constexpr int kWave = 64;
+constexpr int kBlock = 256;          // 4 waves, one per SIMD of a CU
+constexpr int kMaxGridBlocks = 2048; // 256 CUs x 8 resident blocks: grid-stride above
+
+// ---- error plumbing (host) -------------------------------------------------
+void set_error(const char *fmt, ...);
+#define GGMS_CHECK_ARG(cond)                                              \
+  do {                                                                    \
+    if (!(cond)) {                                                        \
+      ::ggms::set_error("%s:%d: invalid argument: %s", __FILE__, __LINE__, #cond); \
+      return GGMS_ERR_INVALID;                                            \
+    }                                                                     \
+  } while (0)
+#define GGMS_HIP(call)                                                    \
+  do {                                                                    \
+    hipError_t e_ = (call);                                               \
+    if (e_ != hipSuccess) {                                               \
+      ::ggms::set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(e_)); \
+      return GGMS_ERR_HIP;                                                \
+    }                                                                     \
+  } while (0)
+#define GGMS_LAUNCH_CHECK() GGMS_HIP(hipGetLastError())
+
+inline hipStream_t to_stream(ggms_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+inline int grid_for(size_t n, size_t per_block) {
+  size_t g = (n + per_block - 1) / per_block;
+  if (g < 1) g = 1;
+  if (g > (size_t)kMaxGridBlocks) g = kMaxGridBlocks;
+  return (int)g;
+}
+
+// ---- a count that lives either in an argument or in device memory ---------
+// Lets a whole mini-batch be enqueued without a host round trip: the size of
+// layer l's frontier is only known on the device when layer l+1 is enqueued.
+struct Count {
+  const uint64_t *dev64; // if non-null, the value is read on the device (64-bit counter)
+  const uint32_t *dev32; // same for a 32-bit counter
+  uint64_t imm;
+  __device__ __forceinline__ uint64_t get() const {
+    return dev64 ? *dev64 : (dev32 ? (uint64_t)*dev32 : imm);
+  }
+};
+inline Count count_of(size_t n, const uint64_t *dev = nullptr) { return Count{dev, nullptr, (uint64_t)n}; }
+inline Count count_of32(size_t n, const uint32_t *dev) { return Count{nullptr, dev, (uint64_t)n}; }
+
+// ---- graph views (DeviceNormalGraph / DeviceDistGraph) ---------------------
+struct GraphView {
+  const uint32_t *indptr;
+  const uint32_t *indices;
+  const uint32_t *const *part_indptr;
+  const uint32_t *const *part_indices;
+  uint32_t num_part;
+  uint32_t num_cache_node;
+
+  // neighbour list of v: pointer + length
+  __device__ __forceinline__ const uint32_t *neighbours(uint32_t v, uint32_t &len) const {
+    if (num_part == 0) {
+      const uint32_t b = indptr[v], e = indptr[v + 1];
+      len = e - b;
+      return indices + b;
+    }
+    uint32_t part, real;
+    if (v < num_cache_node) {
+      part = v % num_part;
+      real = v / num_part;
+    } else {
+      part = num_part; // whole CSR (host tier) in the last slot
+      real = v;
+    }
+    const uint32_t *ip = part_indptr[part];
+    const uint32_t b = ip[real], e = ip[real + 1];
+    len = e - b;
+    return part_indices[part] + b;
+  }
+};
+
+inline GraphView view_of(const ggms_graph_t *g) {
+  return GraphView{g->indptr, g->indices, g->part_indptr, g->part_indices, g->num_part,
+                   g->num_cache_node};
+}
+
+// ---- XORWOW, bit-compatible with cuRAND's curand_init(seed,0,0)/curand() ---
+struct Xorwow {
+  uint32_t d, v0, v1, v2, v3, v4;
+  __host__ __device__ __forceinline__ void init(uint64_t seed) {
+    const uint32_t s0 = ((uint32_t)seed) ^ 0xaad26b49u;
+    const uint32_t s1 = ((uint32_t)(seed >> 32)) ^ 0xf7dcefddu;
+    const uint32_t t0 = 1099087573u * s0;
+    const uint32_t t1 = 2591861531u * s1;
+    d = 6615241u + t1 + t0;
+    v0 = 123456789u + t0;
+    v1 = 362436069u ^ t0;
+    v2 = 521288629u + t1;
+    v3 = 88675123u ^ t1;
+    v4 = 5783321u + t0;
+  }
+  __host__ __device__ __forceinline__ uint32_t next() {
+    const uint32_t t = v0 ^ (v0 >> 2);
+    v0 = v1; v1 = v2; v2 = v3; v3 = v4;
+    v4 = (v4 ^ (v4 << 4)) ^ (t ^ (t << 1));
+    d += 362437u;
+    return v4 + d;
+  }
+  // curand_uniform: x * 2^-32 + 2^-33 in f32
+  __device__ __forceinline__ float uniform() {
+    const uint32_t x = next();
+    return __fmaf_rn(__uint2float_rn(x), 2.3283064e-10f, 2.3283064e-10f / 2.0f);
+  }
+  // curand_uniform_double (XORWOW): two draws, 53-bit mantissa
+  __device__ __forceinline__ double uniform_double() {
+    const uint32_t x = next();
+    const uint32_t y = next();
+    const uint64_t z = (uint64_t)x ^ ((uint64_t)y << 21);
+    return __fma_rn(__ull2double_rn(z), 1.1102230246251565e-16, 1.1102230246251565e-16 / 2.0);
+  }
+  __device__ __forceinline__ void load(const uint32_t *p) {
+    d = p[0]; v0 = p[1]; v1 = p[2]; v2 = p[3]; v3 = p[4]; v4 = p[5];
+  }
+  __device__ __forceinline__ void store(uint32_t *p) const {
+    p[0] = d; p[1] = v0; p[2] = v1; p[3] = v2; p[4] = v3; p[5] = v4;
+  }
+};
+
+// ---- wave / block prefix sums (wave64) -------------------------------------
+__device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
+
+__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t x) {
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t y = __shfl_up(x, off, 64);
+    if ((int)lane_id() >= off) x += y;
+  }
+  return x;
+}
+
+__device__ __forceinline__ uint32_t wave_reduce_sum(uint32_t x) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off, 64);
+  return x;
+}
+
+// Exclusive prefix sum over the 256 threads of a block; `total` gets the block sum.
+// smem: at least 4 uint32.  Ends with a barrier so smem can be reused.
+__device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t x, uint32_t *smem, uint32_t &total) {
+  const uint32_t incl = wave_inclusive_scan(x);
+  const uint32_t w = threadIdx.x >> 6;
+  if (lane_id() == 63) smem[w] = incl;
+  __syncthreads();
+  uint32_t base = 0, t = 0;
+#pragma unroll
+  for (uint32_t i = 0; i < kBlock / kWave; ++i) {
+    const uint32_t s = smem[i];
+    if (i < w) base += s;
+    t += s;
+  }
+  total = t;
+  __syncthreads();
+  return base + incl - x;
+}
+
+} // namespace ggms

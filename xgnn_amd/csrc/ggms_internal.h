@@ -1,0 +1,27 @@
+// ggms_internal.h -- cross-file C++ entry points (count-on-device variants of the leaf ops).
+#pragma once
+#include "ggms_device.h"
+
+namespace ggms {
+
+// sample_khop.hip
+size_t sample_ws_words(size_t num_input);
+int sample_khop3_impl(GraphView g, const uint32_t *input, size_t n_max, Count n, uint32_t fanout, uint32_t *out_src,
+                      uint32_t *out_dst, uint64_t *num_out_dev, uint32_t *states, uint32_t *workspace,
+                      const uint32_t *seed_local, int src_local, hipStream_t s);
+int sample_khop0_impl(GraphView g, const uint32_t *input, size_t n_max, Count n, uint32_t fanout, uint32_t *out_src,
+                      uint32_t *out_dst, uint64_t *num_out_dev, uint32_t *workspace, const uint32_t *seed_local,
+                      int src_local, hipStream_t s);
+
+// hashtable.hip
+size_t ht_ws_words(size_t num_input);
+// insert + ordered local-id assignment; item_pos[i] = bucket of input[i] (kept for ht_map_by_pos)
+int ht_fill_impl(const ggms_hashtable_t *ht, const uint32_t *input, size_t n_max, Count n, uint32_t *item_pos,
+                 uint32_t *scratch, hipStream_t s);
+// out[i] = local id stored in bucket item_pos[i]
+int ht_map_by_pos(const ggms_hashtable_t *ht, const uint32_t *item_pos, size_t n_max, Count n, uint32_t *out,
+                  hipStream_t s);
+// out[i] = local id of keys[i] (probing lookup)
+int ht_lookup(const ggms_hashtable_t *ht, const uint32_t *keys, size_t n_max, Count n, uint32_t *out, hipStream_t s);
+
+} // namespace ggms

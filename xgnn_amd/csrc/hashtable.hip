@@ -1,0 +1,256 @@
+// hashtable.hip -- ordered hash table: dedup + global -> local id remap.
+//
+// Reference: OrderedHashTable (cuda/cuda_hashtable.h:103-153, .cu:699-1064),
+// DeviceOrderedHashTable::SearchO2N (.h:56-98), GPUMapEdges (cuda_mapping.cu:31-81).
+//
+// Same contract -- contiguous local ids, prefix-stable across fills, n2o = the
+// unique list, O(1) Reset through a version stamp -- with one deliberate
+// strengthening: the reference lets whichever duplicate's CAS lands first own a
+// key (cuda_hashtable.cu:54-90), so the order among new ids is a race.  Here the
+// FIRST occurrence in the input owns the key, always (canonical semantics, see
+// DESIGN.md): ownership is decided by a 64-bit atomicMin, not by CAS arrival.
+//
+// Bucket (16 B, two 64-bit words):
+//   w0 = { version : 32 | key : 32 }                        claimed by 64-bit CAS
+//   w1 = { (0x7fffffff - version) : 31 | pending : 1 | value : 32 }
+//        pending = 1: value = smallest input index seen for the key (atomicMin)
+//        pending = 0: value = local id (assigned)
+//   Ordering of w1 under unsigned 64-bit min does all the work:
+//     newer version  <  older version   (stale buckets lose to anything current)
+//     assigned       <  pending         (a key that already has a local id keeps it)
+//     smaller index  <  larger index    (first occurrence wins)
+//   so insertion is {CAS on w0 if needed, one atomicMin on w1}; there is no
+//   per-bucket initialisation that could race with a concurrent duplicate.
+// Probing is the reference's: pos = key mod size, then pos = (pos + delta++) mod size.
+#include "ggms_internal.h"
+#include "tile_scan.h"
+
+namespace ggms {
+
+struct Bucket {
+  unsigned long long w0;
+  unsigned long long w1;
+};
+
+__device__ __forceinline__ unsigned long long make_w0(uint32_t version, uint32_t key) {
+  return ((unsigned long long)key << 32) | version;
+}
+__device__ __forceinline__ uint32_t w0_version(unsigned long long w) { return (uint32_t)w; }
+__device__ __forceinline__ uint32_t w0_key(unsigned long long w) { return (uint32_t)(w >> 32); }
+__device__ __forceinline__ unsigned long long make_w1(uint32_t version, uint32_t pending, uint32_t value) {
+  const unsigned long long hi = ((unsigned long long)(0x7fffffffu - version) << 1) | pending;
+  return (hi << 32) | value;
+}
+
+struct Table {
+  Bucket *o2n;
+  uint32_t *n2o;
+  uint32_t mask; // o2n_size - 1
+  uint32_t version;
+
+  // returns the bucket position of `key`, inserting it if absent
+  __device__ __forceinline__ uint32_t find_or_claim(uint32_t key) const {
+    uint32_t pos = key & mask;
+    uint32_t delta = 1;
+    const unsigned long long want = make_w0(version, key);
+    for (;;) {
+      unsigned long long cur = o2n[pos].w0;
+      if (w0_version(cur) != version) {
+        const unsigned long long prev = atomicCAS(&o2n[pos].w0, cur, want);
+        if (prev == cur) return pos; // claimed
+        cur = prev;                  // somebody else wrote this bucket meanwhile
+      }
+      if (cur == want) return pos;
+      if (w0_version(cur) != version) continue; // stale again (cannot happen twice, but stay safe)
+      pos = (pos + delta) & mask;
+      ++delta;
+    }
+  }
+
+  // SearchO2N: the key is known to be present
+  __device__ __forceinline__ uint32_t find(uint32_t key) const {
+    uint32_t pos = key & mask;
+    uint32_t delta = 1;
+    const unsigned long long want = make_w0(version, key);
+    // bounded: a missing key must not hang the GPU
+    for (uint32_t probes = 0; probes <= mask; ++probes) {
+      if (o2n[pos].w0 == want) return pos;
+      pos = (pos + delta) & mask;
+      ++delta;
+    }
+    return 0xffffffffu;
+  }
+};
+
+// generate_hashmap_duplicates (cuda_hashtable.cu:151-168) + ownership by atomicMin
+__global__ __launch_bounds__(kBlock) void k_ht_insert(Table t, const uint32_t *__restrict__ items, Count n_arg,
+                                                      uint32_t *__restrict__ item_pos) {
+  const uint64_t n = n_arg.get();
+  for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (uint64_t)gridDim.x * kBlock) {
+    const uint32_t key = items[i];
+    const uint32_t pos = t.find_or_claim(key);
+    atomicMin(&t.o2n[pos].w1, make_w1(t.version, 1u, (uint32_t)i));
+    item_pos[i] = pos;
+  }
+}
+
+// count_hashmap / compact_hashmap (cuda_hashtable.cu:197-232, 406-458):
+// instance i owns its key iff the bucket still says {pending, i}
+struct OwnerFlag {
+  Table t;
+  const uint32_t *item_pos;
+  __device__ __forceinline__ uint32_t operator()(uint64_t i) const {
+    return t.o2n[item_pos[i]].w1 == make_w1(t.version, 1u, (uint32_t)i) ? 1u : 0u;
+  }
+};
+struct AssignLocal {
+  Table t;
+  const uint32_t *items;
+  const uint32_t *item_pos;
+  __device__ __forceinline__ void operator()(uint64_t i, uint32_t flag, uint32_t local) const {
+    if (flag) {
+      t.o2n[item_pos[i]].w1 = make_w1(t.version, 0u, local);
+      t.n2o[local] = items[i];
+    }
+  }
+};
+
+// map_edge_ids, cuda_mapping.cu:49-66
+__global__ __launch_bounds__(kBlock) void k_map_edges(Table t, const uint32_t *__restrict__ gsrc,
+                                                      uint32_t *__restrict__ nsrc,
+                                                      const uint32_t *__restrict__ gdst,
+                                                      uint32_t *__restrict__ ndst, Count n_arg) {
+  const uint64_t n = n_arg.get();
+  for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (uint64_t)gridDim.x * kBlock) {
+    if (gsrc) {
+      const uint32_t p = t.find(gsrc[i]);
+      nsrc[i] = (p == 0xffffffffu) ? kEmptyKey : (uint32_t)t.o2n[p].w1;
+    }
+    if (gdst) {
+      const uint32_t p = t.find(gdst[i]);
+      ndst[i] = (p == 0xffffffffu) ? kEmptyKey : (uint32_t)t.o2n[p].w1;
+    }
+  }
+}
+
+__global__ void k_copy_prefix(const uint32_t *__restrict__ src, uint32_t *__restrict__ dst,
+                              const uint32_t *__restrict__ count) {
+  const uint64_t n = *count;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
+    dst[i] = src[i];
+}
+
+static inline Table table_of(const ggms_hashtable_t *ht) {
+  return Table{(Bucket *)ht->o2n, ht->n2o, (uint32_t)(ht->o2n_size - 1), ht->version};
+}
+
+__global__ __launch_bounds__(kBlock) void k_map_by_pos(Table t, const uint32_t *__restrict__ item_pos, Count n_arg,
+                                                       uint32_t *__restrict__ out) {
+  const uint64_t n = n_arg.get();
+  for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (uint64_t)gridDim.x * kBlock)
+    out[i] = (uint32_t)t.o2n[item_pos[i]].w1;
+}
+
+size_t ht_ws_words(size_t num_input) { return num_input + tile_scan_words(num_input) + 16; }
+
+int ht_fill_impl(const ggms_hashtable_t *ht, const uint32_t *input, size_t n_max, Count n, uint32_t *item_pos,
+                 uint32_t *scratch, hipStream_t s) {
+  if (n_max == 0) return GGMS_OK;
+  Table t = table_of(ht);
+  hipLaunchKernelGGL(k_ht_insert, dim3(grid_for(n_max, kBlock)), dim3(kBlock), 0, s, t, input, n, item_pos);
+  GGMS_LAUNCH_CHECK();
+  return tile_scan(OwnerFlag{t, item_pos}, AssignLocal{t, input, item_pos}, n_max, n, scratch, ht->num_items_dev,
+                   ht->num_items_dev, nullptr, s);
+}
+
+int ht_map_by_pos(const ggms_hashtable_t *ht, const uint32_t *item_pos, size_t n_max, Count n, uint32_t *out,
+                  hipStream_t s) {
+  if (n_max == 0) return GGMS_OK;
+  hipLaunchKernelGGL(k_map_by_pos, dim3(grid_for(n_max, kBlock)), dim3(kBlock), 0, s, table_of(ht), item_pos, n, out);
+  GGMS_LAUNCH_CHECK();
+  return GGMS_OK;
+}
+
+int ht_lookup(const ggms_hashtable_t *ht, const uint32_t *keys, size_t n_max, Count n, uint32_t *out, hipStream_t s) {
+  if (n_max == 0) return GGMS_OK;
+  hipLaunchKernelGGL(k_map_edges, dim3(grid_for(n_max, kBlock)), dim3(kBlock), 0, s, table_of(ht), keys, out,
+                     (const uint32_t *)nullptr, (uint32_t *)nullptr, n);
+  GGMS_LAUNCH_CHECK();
+  return GGMS_OK;
+}
+
+} // namespace ggms
+
+using namespace ggms;
+
+extern "C" {
+
+// TableSize(num, scale = kDefaultScale = 2): cuda_hashtable.cu:146-149, cuda_hashtable.h:105
+size_t ggms_hashtable_num_buckets(size_t capacity) {
+  size_t half = capacity >> 1;
+  size_t lg = 0; // floor(log2(half)); the reference's std::log2(0) = -inf case maps to 1 bucket << scale
+  while ((half >> (lg + 1)) != 0) ++lg;
+  const size_t next_pow2 = half == 0 ? 1 : ((size_t)1 << (1 + lg));
+  return next_pow2 << 2;
+}
+
+int ggms_hashtable_init(ggms_hashtable_t *ht, ggms_stream_t stream) {
+  GGMS_CHECK_ARG(ht && ht->o2n && ht->n2o && ht->num_items_dev);
+  GGMS_CHECK_ARG(ht->o2n_size != 0 && (ht->o2n_size & (ht->o2n_size - 1)) == 0 && ht->o2n_size <= (1ull << 32));
+  GGMS_HIP(hipMemsetAsync(ht->o2n, 0xff, ht->o2n_size * sizeof(Bucket), to_stream(stream)));
+  GGMS_HIP(hipMemsetAsync(ht->n2o, 0xff, ht->n2o_size * sizeof(uint32_t), to_stream(stream)));
+  GGMS_HIP(hipMemsetAsync(ht->num_items_dev, 0, sizeof(uint32_t), to_stream(stream)));
+  ht->version = 0;
+  return GGMS_OK;
+}
+
+int ggms_hashtable_reset(ggms_hashtable_t *ht, ggms_stream_t stream) {
+  GGMS_CHECK_ARG(ht && ht->num_items_dev);
+  if (ht->version >= 0x7ffffff0u) {
+    // version space exhausted (2^31 batches): start over with clean buckets
+    int rc = ggms_hashtable_init(ht, stream);
+    if (rc != GGMS_OK) return rc;
+  }
+  ht->version += 1;
+  GGMS_HIP(hipMemsetAsync(ht->num_items_dev, 0, sizeof(uint32_t), to_stream(stream)));
+  return GGMS_OK;
+}
+
+size_t ggms_hashtable_workspace_bytes(size_t num_input) {
+  // item_pos[num_input] + tile scan scratch
+  return ht_ws_words(num_input) * sizeof(uint32_t);
+}
+
+int ggms_hashtable_fill_with_duplicates(ggms_hashtable_t *ht, const ggms_id_t *input, size_t num_input,
+                                        ggms_id_t *unique_out, void *workspace, size_t workspace_bytes,
+                                        ggms_stream_t stream) {
+  GGMS_CHECK_ARG(ht && ht->o2n && ht->version != 0);
+  hipStream_t s = to_stream(stream);
+  if (num_input != 0) {
+    GGMS_CHECK_ARG(input && workspace);
+    GGMS_CHECK_ARG(workspace_bytes >= ggms_hashtable_workspace_bytes(num_input));
+    GGMS_CHECK_ARG(num_input < (1ull << 32));
+    uint32_t *item_pos = (uint32_t *)workspace;
+    int rc = ht_fill_impl(ht, input, num_input, count_of(num_input), item_pos, item_pos + num_input, s);
+    if (rc != GGMS_OK) return rc;
+  }
+  if (unique_out) {
+    hipLaunchKernelGGL(k_copy_prefix, dim3(256), dim3(kBlock), 0, s, ht->n2o, unique_out, ht->num_items_dev);
+    GGMS_LAUNCH_CHECK();
+  }
+  return GGMS_OK;
+}
+
+int ggms_map_edges(const ggms_hashtable_t *ht, const ggms_id_t *global_src, ggms_id_t *new_src,
+                   const ggms_id_t *global_dst, ggms_id_t *new_dst, size_t num_edges, ggms_stream_t stream) {
+  GGMS_CHECK_ARG(ht && ht->o2n && ht->version != 0);
+  if (num_edges == 0) return GGMS_OK;
+  GGMS_CHECK_ARG((global_src == nullptr) == (new_src == nullptr));
+  GGMS_CHECK_ARG((global_dst == nullptr) == (new_dst == nullptr));
+  hipLaunchKernelGGL(k_map_edges, dim3(grid_for(num_edges, kBlock)), dim3(kBlock), 0, to_stream(stream),
+                     table_of(ht), global_src, new_src, global_dst, new_dst, count_of(num_edges));
+  GGMS_LAUNCH_CHECK();
+  return GGMS_OK;
+}
+
+} // extern "C"

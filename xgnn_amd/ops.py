@@ -1,0 +1,224 @@
+"""Tensor-level wrappers over the C ABI (include/ggms.h).
+
+PyTorch-ROCm is used for device memory and streams only; every operator below
+is one or more calls into libggms_hip.so with raw device pointers.  Ids are
+stored in int32 tensors (the reference hands int32 to PyTorch too,
+samgraph/torch/adapter.cc:103,117) and are bit-identical to uint32.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import Graph as _CGraph, HashTable as _CHashTable, check, lib
+
+EMPTY_KEY = 0xFFFFFFFF
+
+# DataType codes, samgraph/common/common.h:38-46
+DTYPE_CODE = {
+    torch.float32: 0, torch.float64: 1, torch.float16: 2, torch.uint8: 3,
+    torch.int32: 4, torch.int8: 5, torch.int64: 6, torch.int16: 2, torch.bfloat16: 2,
+}
+
+KHOP0, KHOP1, WEIGHTED_KHOP, RANDOM_WALK, WEIGHTED_KHOP_PREFIX, KHOP2, WEIGHTED_KHOP_HASH_DEDUP, KHOP3 = range(8)
+
+
+def _require_gpu(t):
+    if not t.is_cuda:
+        raise _lib.GgmsError("xgnn_amd operators need device tensors (no CPU fallback)")
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _i32(t):
+    assert t.dtype == torch.int32 and t.is_contiguous(), "ids must be contiguous int32 tensors"
+    return t
+
+
+class DeviceGraph:
+    """ggms_graph_t over device tensors: DeviceNormalGraph or DeviceDistGraph (dist_graph.h:114-180)."""
+
+    def __init__(self, indptr, indices, part_indptr=None, part_indices=None, num_cache_node=0):
+        self.indptr, self.indices = indptr, indices
+        self._keep = [indptr, indices]
+        num_node = (indptr.numel() - 1) if indptr is not None else 0
+        self.c = _CGraph()
+        self.c.indptr = indptr.data_ptr() if indptr is not None else None
+        self.c.indices = indices.data_ptr() if indices is not None else None
+        self.c.num_node = num_node
+        self.c.num_part = 0
+        self.c.num_cache_node = 0
+        if part_indptr is not None:
+            # part_* : lists of P+1 tensors (slot P = whole CSR); pointer tables live on the device
+            dev = part_indptr[0].device
+            self._pip = torch.tensor([t.data_ptr() for t in part_indptr], dtype=torch.int64, device=dev)
+            self._pix = torch.tensor([t.data_ptr() for t in part_indices], dtype=torch.int64, device=dev)
+            self._keep += list(part_indptr) + list(part_indices)
+            self.c.part_indptr = self._pip.data_ptr()
+            self.c.part_indices = self._pix.data_ptr()
+            self.c.num_part = len(part_indptr) - 1
+            self.c.num_cache_node = num_cache_node
+            self.c.num_node = part_indptr[-1].numel() - 1
+
+
+def random_states(num_states, seed, device="cuda"):
+    """GPURandomStates (cuda_random_states.cu:64-109) with an explicit seed."""
+    st = torch.empty((num_states, 6), dtype=torch.int32, device=device)
+    _require_gpu(st)
+    check(lib().ggms_random_states_init(_ptr(st), num_states, seed, _stream()), "ggms_random_states_init")
+    return st
+
+
+def _workspace(nbytes, device):
+    return torch.empty(max(16, (nbytes + 3) // 4), dtype=torch.int32, device=device)
+
+
+def _sample(fn_name, sample_type, graph, inp, fanout, states):
+    _require_gpu(inp)
+    _i32(inp)
+    n = inp.numel()
+    dev = inp.device
+    out_src = torch.empty(max(1, n * fanout), dtype=torch.int32, device=dev)
+    out_dst = torch.empty(max(1, n * fanout), dtype=torch.int32, device=dev)
+    num_out = torch.zeros(1, dtype=torch.int64, device=dev)
+    wsb = lib().ggms_sample_workspace_bytes(sample_type, n, fanout)
+    ws = _workspace(wsb, dev)
+    if fn_name == "ggms_sample_khop3":
+        rc = lib().ggms_sample_khop3(C.byref(graph.c), _ptr(inp), n, fanout, _ptr(out_src), _ptr(out_dst),
+                                     _ptr(num_out), _ptr(states), states.shape[0], _ptr(ws), ws.numel() * 4,
+                                     _stream())
+    else:
+        rc = lib().ggms_sample_khop0(C.byref(graph.c), _ptr(inp), n, fanout, _ptr(out_src), _ptr(out_dst),
+                                     _ptr(num_out), _ptr(ws), ws.numel() * 4, _stream())
+    check(rc, fn_name)
+    return out_src, out_dst, num_out
+
+
+def sample_khop3(graph, inp, fanout, states):
+    """GPUSampleKHop3 (cuda_sampling_khop3.cu:234-318).  Returns (out_src, out_dst, num_out[1] on device)."""
+    return _sample("ggms_sample_khop3", KHOP3, graph, inp, fanout, states)
+
+
+def sample_khop0(graph, inp, fanout):
+    """GPUSampleKHop0 (cuda_sampling_khop0.cu:243-335)."""
+    return _sample("ggms_sample_khop0", KHOP0, graph, inp, fanout, None)
+
+
+class OrderedHashTable:
+    """OrderedHashTable (cuda_hashtable.h:103-153) over caller-owned device buffers."""
+
+    def __init__(self, capacity, device="cuda"):
+        nb = lib().ggms_hashtable_num_buckets(capacity)
+        self.o2n = torch.empty((nb, 4), dtype=torch.int32, device=device)
+        _require_gpu(self.o2n)
+        self.n2o = torch.empty(max(1, capacity), dtype=torch.int32, device=device)
+        self.num_items_dev = torch.zeros(1, dtype=torch.int32, device=device)
+        self.c = _CHashTable()
+        self.c.o2n = self.o2n.data_ptr()
+        self.c.n2o = self.n2o.data_ptr()
+        self.c.num_items_dev = self.num_items_dev.data_ptr()
+        self.c.o2n_size = nb
+        self.c.n2o_size = self.n2o.numel()
+        check(lib().ggms_hashtable_init(C.byref(self.c), _stream()), "ggms_hashtable_init")
+
+    def reset(self):
+        check(lib().ggms_hashtable_reset(C.byref(self.c), _stream()), "ggms_hashtable_reset")
+
+    def fill_with_duplicates(self, inp, num_input=None, unique_out=None):
+        _i32(inp)
+        n = inp.numel() if num_input is None else int(num_input)
+        ws = _workspace(lib().ggms_hashtable_workspace_bytes(n), inp.device)
+        check(lib().ggms_hashtable_fill_with_duplicates(C.byref(self.c), _ptr(inp), n, _ptr(unique_out), _ptr(ws),
+                                                        ws.numel() * 4, _stream()),
+              "ggms_hashtable_fill_with_duplicates")
+
+    @property
+    def num_items(self):
+        return int(self.num_items_dev.item())
+
+    def unique(self):
+        return self.n2o[: self.num_items]
+
+    def map_edges(self, src, dst, num_edges=None):
+        n = (src if src is not None else dst).numel() if num_edges is None else int(num_edges)
+        dev = (src if src is not None else dst).device
+        ns = torch.empty(max(1, n), dtype=torch.int32, device=dev) if src is not None else None
+        nd = torch.empty(max(1, n), dtype=torch.int32, device=dev) if dst is not None else None
+        check(lib().ggms_map_edges(C.byref(self.c), _ptr(src), _ptr(ns), _ptr(dst), _ptr(nd), n, _stream()),
+              "ggms_map_edges")
+        return (ns[:n] if ns is not None else None), (nd[:n] if nd is not None else None)
+
+
+def _dim_of(t):
+    return t.shape[1] if t.dim() > 1 else 1
+
+
+def extract(src, index, out=None):
+    """GPUExtract (cuda_extraction.cu:74-117): out[i, :] = src[index[i], :]."""
+    _require_gpu(index)
+    _i32(index)
+    assert src.is_contiguous()
+    n = index.numel()
+    if out is None:
+        out = torch.empty((n,) + tuple(src.shape[1:]), dtype=src.dtype, device=index.device)
+    check(lib().ggms_extract(_ptr(out), _ptr(src), _ptr(index), n, _dim_of(src), DTYPE_CODE[src.dtype], _stream()),
+          "ggms_extract")
+    return out
+
+
+def get_miss_cache_index(table, nodes):
+    """GetMissCacheIndex (cuda_cache_manager_device.cu:355-441).  Counts stay on the device."""
+    _require_gpu(nodes)
+    n = nodes.numel()
+    dev = nodes.device
+    outs = [torch.empty(max(1, n), dtype=torch.int32, device=dev) for _ in range(4)]
+    num_miss = torch.zeros(1, dtype=torch.int64, device=dev)
+    num_hit = torch.zeros(1, dtype=torch.int64, device=dev)
+    ws = _workspace(lib().ggms_cache_index_workspace_bytes(n), dev)
+    check(lib().ggms_get_miss_cache_index(_ptr(table), _ptr(nodes), n, _ptr(outs[0]), _ptr(outs[1]), _ptr(num_miss),
+                                          _ptr(outs[2]), _ptr(outs[3]), _ptr(num_hit), _ptr(ws), ws.numel() * 4,
+                                          _stream()), "ggms_get_miss_cache_index")
+    return outs[0], outs[1], num_miss, outs[2], outs[3], num_hit
+
+
+def gather_scatter(out, src, src_index, dst_index, num=None, num_dev=None):
+    """combine_cache_data / extract_miss_data / combine_miss_data (cuda_cache_manager_device.cu:209-275)."""
+    _require_gpu(out)
+    if num is None:
+        num = (src_index if src_index is not None else dst_index).numel()
+    check(lib().ggms_gather_scatter(_ptr(out), _ptr(src), _ptr(src_index), _ptr(dst_index), num, _ptr(num_dev),
+                                    _dim_of(out), DTYPE_CODE[out.dtype], _stream()), "ggms_gather_scatter")
+    return out
+
+
+def part_pointer_table(parts, device):
+    """Device array of shard base pointers (DeviceDistFeature, dist_graph.h:182-212)."""
+    return torch.tensor([p.data_ptr() for p in parts], dtype=torch.int64, device=device)
+
+
+def gather_scatter_partition(out, parts_table, num_part, src_index, dst_index, num=None, num_dev=None):
+    """combine_cache_data_for_partition (cuda_cache_manager_device.cu:277-299)."""
+    _require_gpu(out)
+    if num is None:
+        num = src_index.numel()
+    check(lib().ggms_gather_scatter_partition(_ptr(out), _ptr(parts_table), num_part, _ptr(src_index),
+                                              _ptr(dst_index), num, _ptr(num_dev), _dim_of(out),
+                                              DTYPE_CODE[out.dtype], _stream()), "ggms_gather_scatter_partition")
+    return out
+
+
+def extract_cached(out, nodes, table, parts_table, num_part, host_feat, num=None, num_dev=None, num_miss=None):
+    """Fused GetMissCacheIndex + GPUExtractMissData + CombineCacheData (dist_loops.cc:1209-1285)."""
+    _require_gpu(out)
+    if num is None:
+        num = nodes.numel()
+    check(lib().ggms_extract_cached(_ptr(out), _ptr(nodes), num, _ptr(num_dev), _ptr(table), _ptr(parts_table),
+                                    num_part, _ptr(host_feat), _dim_of(out), DTYPE_CODE[out.dtype], _ptr(num_miss),
+                                    _stream()), "ggms_extract_cached")
+    return out
