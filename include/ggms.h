@@ -160,6 +160,34 @@ int ggms_map_edges(const ggms_hashtable_t *ht, const ggms_id_t *global_src,
                    ggms_id_t *new_dst, size_t num_edges, ggms_stream_t stream);
 
 /* ---------------------------------------------------------------------------
+ * One mini-batch of k-layer sampling -- DoGPUSample, dist/dist_loops.cc:62-368
+ * (cuda/cuda_loops.cc:54-292): Reset + FillWithDupRevised(seeds), then for
+ * layer i = L-1 .. 0 {sample, FillWithDuplicates, GPUMapEdges}.  Enqueued on
+ * `stream` without any host round trip; all sizes are left on the device:
+ *   counts_dev[3*i + 0] = num_edge(i)   row[i]/col[i] hold that many entries
+ *   counts_dev[3*i + 1] = num_src(i)    (= unique nodes after layer i)
+ *   counts_dev[3*i + 2] = num_dst(i)    (= size of layer i's frontier)
+ *   counts_dev[3*L]     = number of input nodes; the list is ht->n2o
+ * row[i] = local id of the sampled neighbour, col[i] = local id of the seed
+ * (TrainGraph, dist_loops.cc:303-322).  row/col are HOST arrays of L device
+ * pointers with the capacities ggms_sample_batch_capacity reports; fanouts is
+ * a host array indexed by layer id.
+ * ------------------------------------------------------------------------- */
+int ggms_sample_batch_capacity(size_t num_seeds, const size_t *fanouts,
+                               uint32_t num_layer, size_t *max_input,
+                               size_t *max_edges, size_t *max_unique);
+size_t ggms_sample_batch_workspace_bytes(size_t num_seeds,
+                                         const size_t *fanouts,
+                                         uint32_t num_layer);
+int ggms_sample_batch(int sample_type, const ggms_graph_t *graph,
+                      const ggms_id_t *seeds, size_t num_seeds,
+                      const size_t *fanouts, uint32_t num_layer,
+                      ggms_hashtable_t *ht, void *states, size_t num_states,
+                      ggms_id_t *const *row, ggms_id_t *const *col,
+                      uint64_t *counts_dev, void *workspace,
+                      size_t workspace_bytes, ggms_stream_t stream);
+
+/* ---------------------------------------------------------------------------
  * Feature extract -- GPUExtract, cuda/cuda_extraction.cu:74-117:
  * dst[i, :] = src[index[i], :].  src may be device or device-mapped host
  * memory (gpu_extract zero-copy path, dist_loops.cc:585-634).

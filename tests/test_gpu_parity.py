@@ -252,3 +252,30 @@ def test_partition_cache_paths(ops, P, dim):
     ops.extract_cached(out2, dev(nodes), dev(table), ptab, P, t_feat, num_miss=nmiss)
     assert out2.cpu().numpy().tobytes() == want.tobytes()
     assert int(nmiss.item()) == wms.size
+
+
+# ------------------------------------------------------- multi-layer batch
+@pytest.mark.parametrize("stype", ["khop3", "khop0"])
+@pytest.mark.parametrize("fanouts,nseed", [([25, 10], 1000), ([5, 10, 15], 300), ([3], 129), ([25, 10], 0)])
+def test_sample_batch_vs_oracle(ops, stype, fanouts, nseed):
+    """DoGPUSample (dist_loops.cc:62-368): row/col/num_src/num_dst per layer + input nodes."""
+    ip, ix = powerlaw_csr(20_000, mean_deg=30, seed=2)
+    g = ops.DeviceGraph(dev(ip), dev(ix))
+    rng = np.random.RandomState(len(fanouts) * 1000 + nseed)
+    code = ops.KHOP3 if stype == "khop3" else ops.KHOP0
+    bs = ops.BatchSampler(g, fanouts, max(nseed, 1), sample_type=code, seed=77)
+    orc_states = oracle.random_states(bs.states.shape[0], 77) if stype == "khop3" else None
+    for rep in range(3):
+        seeds = rng.permutation(20_000)[:nseed].astype(np.uint32)
+        if rep == 2 and nseed > 10:
+            seeds[5] = seeds[0]  # duplicated seed: local ids of raw seeds go through the table
+        t_seeds = dev(seeds) if nseed else torch.zeros(0, dtype=torch.int32, device="cuda")
+        bs.sample(t_seeds)
+        got = bs.result()
+        want = oracle.do_sample(oracle.KHOP3 if stype == "khop3" else oracle.KHOP0, ip, ix, seeds, fanouts, orc_states)
+        np.testing.assert_array_equal(host_u32(got["input_nodes"]), want["input_nodes"])
+        for i in range(len(fanouts)):
+            gl, wl = got["layers"][i], want["layers"][i]
+            assert (gl["num_src"], gl["num_dst"]) == (wl["num_src"], wl["num_dst"]), (rep, i)
+            np.testing.assert_array_equal(host_u32(gl["row"]), wl["row"], err_msg=f"row layer {i} rep {rep}")
+            np.testing.assert_array_equal(host_u32(gl["col"]), wl["col"], err_msg=f"col layer {i} rep {rep}")

@@ -18,13 +18,17 @@
 //     identity-destination gather is one contiguous 1 KiB segment;
 //   * U independent 16-B loads per lane are issued before the first store.
 // Algorithmic bytes per row: 4 (index) + 2 * row_bytes.
+#include <cstdlib>
+
 #include "ggms_device.h"
 
 namespace ggms {
 
 template <int BYTES> struct ChunkT;
-template <> struct ChunkT<16> { using type = uint4; };
-template <> struct ChunkT<8> { using type = uint2; };
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+template <> struct ChunkT<16> { using type = u32x4_t; };
+template <> struct ChunkT<8> { using type = u32x2_t; };
 template <> struct ChunkT<4> { using type = uint32_t; };
 template <> struct ChunkT<2> { using type = uint16_t; };
 template <> struct ChunkT<1> { using type = uint8_t; };
@@ -81,55 +85,90 @@ __device__ __forceinline__ uint64_t shfl_u64(uint64_t v, int src) {
   return ((uint64_t)hi << 32) | lo;
 }
 
-template <int CB, typename Rows>
+// chunk loads: plain or non-temporal (rows of a batch are read once)
+// The pointers travel through ds_bpermute as integers; tell the compiler they are GLOBAL so it emits
+// global_load/global_store (vmcnt only) instead of flat_* (vmcnt + lgkmcnt, aperture check).
+template <typename V, bool NT>
+__device__ __forceinline__ V load_chunk(uint64_t addr) {
+  typedef const V __attribute__((address_space(1))) *gp_t;
+  gp_t p = (gp_t)addr;
+  if constexpr (NT) return __builtin_nontemporal_load(p);
+  else return *p;
+}
+template <typename V>
+__device__ __forceinline__ void store_chunk(uint64_t addr, V v) {
+  typedef V __attribute__((address_space(1))) *gp_t;
+  *(gp_t)addr = v;
+}
+
+template <int CB, typename Rows, bool IDENT_DST, bool NT>
 __global__ __launch_bounds__(kBlock) void k_gather_rows(char *__restrict__ out, Rows rows,
                                                         const uint32_t *__restrict__ dst_index, Count n_arg,
-                                                        uint32_t rc, uint64_t magic, uint64_t *miss_count) {
+                                                        uint32_t rc, uint32_t magic, uint64_t *miss_count) {
   using V = typename ChunkT<CB>::type;
-  constexpr int U = (CB >= 8) ? 4 : 8;
+  constexpr int U = 8;
   const uint64_t n = n_arg.get();
   const uint32_t lane = lane_id();
   const uint64_t wave = ((uint64_t)blockIdx.x * kBlock + threadIdx.x) >> 6;
   const uint64_t num_waves = (uint64_t)gridDim.x * (kBlock / kWave);
   const uint64_t row_bytes = (uint64_t)rc * CB;
+  const uint64_t num_tiles = (n + kWave - 1) / kWave;
 
-  for (uint64_t tile = wave; tile * kWave < n; tile += num_waves) {
-    const uint64_t row0 = tile * kWave;
-    const uint64_t my_row = row0 + lane;
-    uint64_t sp = 0, dp = 0;
-    bool miss = false;
-    if (my_row < n) {
+  // resolve one row per lane for tile `t`: source pointer (+ destination pointer)
+  auto resolve = [&](uint64_t t, uint64_t &sp, uint64_t &dp, bool &miss) {
+    const uint64_t my_row = t * kWave + lane;
+    sp = 0; dp = 0; miss = false;
+    if (t < num_tiles && my_row < n) {
       sp = (uint64_t)rows.row(my_row, miss);
-      const uint64_t drow = dst_index ? (uint64_t)dst_index[my_row] : my_row;
-      dp = (uint64_t)(out + drow * row_bytes);
+      if constexpr (!IDENT_DST) dp = (uint64_t)(out + (uint64_t)dst_index[my_row] * row_bytes);
     }
+  };
+
+  uint64_t sp, dp;
+  bool miss;
+  resolve(wave, sp, dp, miss);
+  for (uint64_t tile = wave; tile < num_tiles; tile += num_waves) {
+    // software pipeline: the next tile's index -> table -> pointer chain is in flight while this
+    // tile's rows stream
+    uint64_t sp_n, dp_n;
+    bool miss_n;
+    resolve(tile + num_waves, sp_n, dp_n, miss_n);
+
     if (miss_count) {
       const uint64_t m = __ballot(miss);
       if (lane == 0 && m) atomicAdd((unsigned long long *)miss_count, (unsigned long long)__popcll(m));
     }
+    const uint64_t row0 = tile * kWave;
     const uint32_t rows_here = (n - row0 < (uint64_t)kWave) ? (uint32_t)(n - row0) : (uint32_t)kWave;
-    const uint32_t total = rows_here * rc;
+    const uint32_t total = rows_here * rc; // 16-byte chunks in this tile
+    const uint64_t out_tile = (uint64_t)(out + row0 * row_bytes);
     for (uint32_t c0 = 0; c0 < total; c0 += kWave * U) {
       V tmp[U];
-      uint32_t col[U];
-      uint32_t own[U];
+      uint32_t cc[U];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const uint32_t c = c0 + u * kWave + lane;
-        uint32_t r = (uint32_t)(((uint64_t)c * magic) >> 32); // c / rc, exact for c * rc < 2^32
-        r = r < (uint32_t)kWave ? r : (uint32_t)(kWave - 1);
-        own[u] = r;
-        col[u] = c - r * rc;
+        cc[u] = c < total ? c : total - 1; // clamp: the load is unconditional, the store is not
+        // cc / rc, exact for cc * rc < 2^32; rc == 1 has magic = 0 and takes cc itself
+        const uint32_t r = __umulhi(cc[u], magic) + (rc == 1 ? cc[u] : 0u);
+        const uint32_t col = cc[u] - r * rc;
         const uint64_t p = shfl_u64(sp, (int)r);
-        if (c < total) tmp[u] = reinterpret_cast<const V *>(p)[col[u]];
+        tmp[u] = load_chunk<V, NT>(p + (uint64_t)col * CB);
       }
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const uint32_t c = c0 + u * kWave + lane;
-        const uint64_t d = shfl_u64(dp, (int)own[u]);
-        if (c < total) reinterpret_cast<V *>(d)[col[u]] = tmp[u];
+        uint64_t q;
+        if constexpr (IDENT_DST) {
+          q = out_tile + (uint64_t)cc[u] * CB;
+        } else {
+          const uint32_t r = __umulhi(cc[u], magic) + (rc == 1 ? cc[u] : 0u);
+          q = shfl_u64(dp, (int)r) + (uint64_t)(cc[u] - r * rc) * CB;
+        }
+        if (c < total) store_chunk<V>(q, tmp[u]);
       }
     }
+    sp = sp_n; dp = dp_n; miss = miss_n;
   }
 }
 
@@ -138,6 +177,8 @@ static inline int pick_chunk(size_t row_bytes, uintptr_t align_bits) {
     if (row_bytes % cb == 0 && (align_bits % cb) == 0) return cb;
   return 1;
 }
+
+static bool g_nontemporal = false; // GGMS_EXTRACT_NT=1: non-temporal row loads (measured per build)
 
 template <typename Rows>
 static int launch_gather(char *out, Rows rows, const uint32_t *dst_index, size_t n_max, Count n,
@@ -148,21 +189,30 @@ static int launch_gather(char *out, Rows rows, const uint32_t *dst_index, size_t
     set_error("extract: row of %zu bytes in %d-byte chunks is outside the supported range", row_bytes, cb);
     return GGMS_ERR_INVALID;
   }
-  const uint64_t magic = ((1ull << 32) + rc - 1) / rc;
+  static const bool env_nt = [] { const char *e = getenv("GGMS_EXTRACT_NT"); return e && e[0] == '1'; }();
+  const bool nt = env_nt || g_nontemporal;
+  const uint32_t magic = rc == 1 ? 0u : (uint32_t)(((1ull << 32) + rc - 1) / rc);
   const int grid = grid_for(n_max, kBlock); // one wave per 64 rows
-  switch (cb) {
-#define GGMS_CASE(CB)                                                                              \
-  case CB:                                                                                         \
-    hipLaunchKernelGGL((k_gather_rows<CB, Rows>), dim3(grid), dim3(kBlock), 0, stream, out, rows,  \
-                       dst_index, n, (uint32_t)rc, magic, miss_count);                             \
+#define GGMS_LAUNCH(CB, ID, NT)                                                                         \
+  hipLaunchKernelGGL((k_gather_rows<CB, Rows, ID, NT>), dim3(grid), dim3(kBlock), 0, stream, out, rows, \
+                     dst_index, n, (uint32_t)rc, magic, miss_count)
+#define GGMS_CASE(CB)                                                \
+  case CB:                                                           \
+    if (dst_index == nullptr) {                                      \
+      if (nt) GGMS_LAUNCH(CB, true, true); else GGMS_LAUNCH(CB, true, false);   \
+    } else {                                                         \
+      if (nt) GGMS_LAUNCH(CB, false, true); else GGMS_LAUNCH(CB, false, false); \
+    }                                                                \
     break;
+  switch (cb) {
     GGMS_CASE(16)
     GGMS_CASE(8)
     GGMS_CASE(4)
     GGMS_CASE(2)
     GGMS_CASE(1)
-#undef GGMS_CASE
   }
+#undef GGMS_CASE
+#undef GGMS_LAUNCH
   GGMS_LAUNCH_CHECK();
   return GGMS_OK;
 }

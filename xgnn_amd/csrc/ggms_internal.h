@@ -8,7 +8,7 @@ namespace ggms {
 size_t sample_ws_words(size_t num_input);
 int sample_khop3_impl(GraphView g, const uint32_t *input, size_t n_max, Count n, uint32_t fanout, uint32_t *out_src,
                       uint32_t *out_dst, uint64_t *num_out_dev, uint32_t *states, uint32_t *workspace,
-                      const uint32_t *seed_local, int src_local, hipStream_t s);
+                      const uint32_t *seed_local, int src_local, const uint32_t *local_to_global, hipStream_t s);
 int sample_khop0_impl(GraphView g, const uint32_t *input, size_t n_max, Count n, uint32_t fanout, uint32_t *out_src,
                       uint32_t *out_dst, uint64_t *num_out_dev, uint32_t *workspace, const uint32_t *seed_local,
                       int src_local, hipStream_t s);

@@ -1,0 +1,148 @@
+// sample_batch.hip -- one mini-batch of k-layer sampling, enqueued in one go.
+//
+// Reference: DoGPUSample (dist/dist_loops.cc:62-368; single-process twin
+// cuda/cuda_loops.cc:54-292): per layer {sample -> D2H nnz -> FillWithDuplicates ->
+// D2H num_unique -> GPUMapEdges}, i.e. two host round trips per layer plus one
+// StreamSync after every kernel.
+//
+// Here the whole loop is a straight sequence of launches on one stream.  Every
+// size that the next launch depends on (frontier size, edge count) stays in
+// device memory and is read by the kernels themselves (ggms::Count); grids are
+// sized from the closed-form upper bounds of PredictNumNodes (common.cc:488-497)
+// and grid-stride, so a launch never needs the exact value.  The caller syncs
+// once, after the feature extract that follows.
+//
+// Other savings against the reference, all result-preserving:
+//   * the frontier of layer i-1 is the hash table's n2o prefix: no `unique`
+//     buffer is allocated or copied (dist_loops.cc:271-280,350-353);
+//   * `col` (local id of the edge's seed) is written by the sampler: a seed's
+//     local id is its position in the frontier (n2o), so the E hash lookups of
+//     GPUMapEdges' src half (cuda_mapping.cu:57-60) reduce to none (n lookups
+//     for the first layer, whose input is the raw seed list);
+//   * `row` comes from the bucket position remembered at insert time
+//     (item_pos), so the dst half needs no probing either.
+#include "ggms_internal.h"
+#include "tile_scan.h"
+
+namespace ggms {
+
+__global__ void k_record(uint64_t *slot, Count c) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) *slot = c.get();
+}
+
+struct BatchCaps {
+  size_t max_input[16];
+  size_t max_edges[16];
+  size_t max_in_all, max_e_all;
+};
+
+static BatchCaps caps_of(size_t num_seeds, const size_t *fanouts, uint32_t L) {
+  BatchCaps c{};
+  size_t n = num_seeds;
+  for (int i = (int)L - 1; i >= 0; --i) {
+    c.max_input[i] = n;
+    c.max_edges[i] = n * fanouts[i];
+    n += c.max_edges[i]; // unique nodes so far <= previous unique + new edges
+    if (c.max_input[i] > c.max_in_all) c.max_in_all = c.max_input[i];
+    if (c.max_edges[i] > c.max_e_all) c.max_e_all = c.max_edges[i];
+  }
+  return c;
+}
+
+} // namespace ggms
+
+using namespace ggms;
+
+extern "C" {
+
+int ggms_sample_batch_capacity(size_t num_seeds, const size_t *fanouts, uint32_t num_layer, size_t *max_input,
+                               size_t *max_edges, size_t *max_unique) {
+  GGMS_CHECK_ARG(fanouts && num_layer >= 1 && num_layer <= 16);
+  const BatchCaps c = caps_of(num_seeds, fanouts, num_layer);
+  for (uint32_t i = 0; i < num_layer; ++i) {
+    if (max_input) max_input[i] = c.max_input[i];
+    if (max_edges) max_edges[i] = c.max_edges[i];
+  }
+  if (max_unique) *max_unique = c.max_input[0] + c.max_edges[0];
+  return GGMS_OK;
+}
+
+size_t ggms_sample_batch_workspace_bytes(size_t num_seeds, const size_t *fanouts, uint32_t num_layer) {
+  if (!fanouts || num_layer < 1 || num_layer > 16) return 0;
+  const BatchCaps c = caps_of(num_seeds, fanouts, num_layer);
+  const size_t words = num_seeds + 16                      // seed_local
+                       + sample_ws_words(c.max_in_all)     // offsets + scan scratch
+                       + c.max_e_all + 16                  // global neighbour ids of the layer
+                       + ht_ws_words(c.max_e_all);         // item_pos + scan scratch
+  return words * sizeof(uint32_t);
+}
+
+int ggms_sample_batch(int sample_type, const ggms_graph_t *graph, const ggms_id_t *seeds, size_t num_seeds,
+                      const size_t *fanouts, uint32_t num_layer, ggms_hashtable_t *ht, void *states,
+                      size_t num_states, ggms_id_t *const *row, ggms_id_t *const *col, uint64_t *counts_dev,
+                      void *workspace, size_t workspace_bytes, ggms_stream_t stream) {
+  GGMS_CHECK_ARG(graph && fanouts && ht && row && col && counts_dev);
+  GGMS_CHECK_ARG(num_layer >= 1 && num_layer <= 16);
+  GGMS_CHECK_ARG(sample_type == GGMS_KHOP3 || sample_type == GGMS_KHOP0);
+  GGMS_CHECK_ARG(num_seeds == 0 || seeds);
+  GGMS_CHECK_ARG(workspace && workspace_bytes >= ggms_sample_batch_workspace_bytes(num_seeds, fanouts, num_layer));
+  hipStream_t s = to_stream(stream);
+  const BatchCaps c = caps_of(num_seeds, fanouts, num_layer);
+  GGMS_CHECK_ARG(c.max_input[0] + c.max_edges[0] <= ht->n2o_size);
+  GGMS_CHECK_ARG(c.max_input[0] + c.max_edges[0] < (1ull << 32));
+  if (sample_type == GGMS_KHOP3) {
+    GGMS_CHECK_ARG(states && (c.max_in_all + 127) / 128 * 8 <= num_states);
+    for (uint32_t i = 0; i < num_layer; ++i) GGMS_CHECK_ARG(fanouts[i] > 0 && fanouts[i] < 128);
+  }
+
+  uint32_t *w = (uint32_t *)workspace;
+  uint32_t *seed_local = w;            w += num_seeds + 16;
+  uint32_t *samp_ws = w;               w += sample_ws_words(c.max_in_all);
+  uint32_t *tmp_dst = w;               w += c.max_e_all + 16;
+  uint32_t *item_pos = w;              w += c.max_e_all;
+  uint32_t *ht_scratch = w;
+
+  const GraphView g = view_of(graph);
+  int rc = ggms_hashtable_reset(ht, stream); // hash_table->Reset, dist_loops.cc:105
+  if (rc != GGMS_OK) return rc;
+  // FillWithDupRevised(seeds), dist_loops.cc:110-111 (item_pos doubles as scratch here)
+  rc = ht_fill_impl(ht, seeds, num_seeds, count_of(num_seeds), item_pos, ht_scratch, s);
+  if (rc != GGMS_OK) return rc;
+  // local ids of the raw seeds (they may repeat): first-layer `col`
+  rc = ht_map_by_pos(ht, item_pos, num_seeds, count_of(num_seeds), seed_local, s);
+  if (rc != GGMS_OK) return rc;
+
+  for (int i = (int)num_layer - 1; i >= 0; --i) {
+    const bool first = (i == (int)num_layer - 1);
+    const uint32_t *input = first ? seeds : ht->n2o;
+    const size_t n_max = c.max_input[i], e_max = c.max_edges[i];
+    const Count n = first ? count_of(num_seeds) : count_of32(n_max, ht->num_items_dev);
+    uint64_t *num_edge = counts_dev + 3 * i + 0;
+    uint64_t *num_src = counts_dev + 3 * i + 1;
+    uint64_t *num_dst = counts_dev + 3 * i + 2;
+    hipLaunchKernelGGL(k_record, dim3(1), dim3(64), 0, s, num_dst, n); // num_dst = |frontier| (dist_loops.cc:305)
+    GGMS_LAUNCH_CHECK();
+    if (n_max == 0) {
+      GGMS_HIP(hipMemsetAsync(num_edge, 0, sizeof(uint64_t), s));
+    } else if (sample_type == GGMS_KHOP3) {
+      rc = sample_khop3_impl(g, input, n_max, n, (uint32_t)fanouts[i], col[i], tmp_dst, num_edge, (uint32_t *)states,
+                             samp_ws, first ? seed_local : nullptr, 1, ht->n2o, s);
+    } else {
+      rc = sample_khop0_impl(g, input, n_max, n, (uint32_t)fanouts[i], col[i], tmp_dst, num_edge, samp_ws,
+                             first ? seed_local : nullptr, 1, s);
+    }
+    if (rc != GGMS_OK) return rc;
+    const Count ne = count_of(e_max, num_edge);
+    rc = ht_fill_impl(ht, tmp_dst, e_max, ne, item_pos, ht_scratch, s); // FillWithDuplicates, :279
+    if (rc != GGMS_OK) return rc;
+    rc = ht_map_by_pos(ht, item_pos, e_max, ne, row[i], s);             // GPUMapEdges dst half, :296
+    if (rc != GGMS_OK) return rc;
+    hipLaunchKernelGGL(k_record, dim3(1), dim3(64), 0, s, num_src, count_of32(0, ht->num_items_dev)); // :304
+    GGMS_LAUNCH_CHECK();
+  }
+  hipLaunchKernelGGL(k_record, dim3(1), dim3(64), 0, s, counts_dev + 3 * num_layer, count_of32(0, ht->num_items_dev));
+  GGMS_LAUNCH_CHECK();
+  return GGMS_OK;
+}
+
+} // extern "C"

@@ -53,18 +53,30 @@ struct SrcMode {
 // ---- khop3 -------------------------------------------------------------------
 // Group (b, y) of the reference grid == stream id i = 8 b + y; it serves seeds
 // 128 b + y + 8 k, k = 0..15, in that order (khop3.cu:86-89,106).
+//
+// Two launches:
+//   k_khop3_positions  one lane per stream: the serial part (RNG + rejection),
+//                      no neighbour loads; writes the chosen POSITION r_j into
+//                      out_dst[o + j].  The 16 seeds' (id, degree, offset) chains
+//                      are fetched up front into LDS so their latency is paid once.
+//   k_gather_neighbours  flat over edges: out_dst[e] = neighbours(seed)[out_dst[e]].
+// Keeping the random 4-byte neighbour reads out of the serial loop is what
+// matters: in one fused loop each lane waited ~1 us per neighbour.
 template <int SET_BITS>
-__global__ __launch_bounds__(kWave) void k_sample_khop3(GraphView g, const uint32_t *__restrict__ input,
-                                                        Count n_arg, uint32_t fanout,
-                                                        const uint32_t *__restrict__ offset,
-                                                        uint32_t *__restrict__ out_src,
-                                                        uint32_t *__restrict__ out_dst,
-                                                        uint32_t *__restrict__ states, SrcMode sm) {
+__global__ __launch_bounds__(kWave) void k_khop3_positions(GraphView g, const uint32_t *__restrict__ input,
+                                                           Count n_arg, uint32_t fanout,
+                                                           const uint32_t *__restrict__ offset,
+                                                           uint32_t *__restrict__ out_src,
+                                                           uint32_t *__restrict__ out_dst,
+                                                           uint32_t *__restrict__ states, SrcMode sm) {
   constexpr uint32_t SLOTS = 1u << SET_BITS;
   constexpr uint32_t SMASK = SLOTS - 1;
   constexpr uint32_t HASH_EMPTY = 0xffffffffu;
   __shared__ uint32_t set_tab[SLOTS * kWave]; // [slot][lane]
   __shared__ uint8_t set_used[128 * kWave];   // slot of the j-th insert of the current seed, [j][lane]
+  __shared__ uint32_t seed_len[16 * kWave];   // [k][lane]
+  __shared__ uint32_t seed_off[16 * kWave];
+  __shared__ uint32_t seed_src[16 * kWave];
   const uint64_t n = n_arg.get();
   const uint32_t lane = threadIdx.x;
   const uint64_t num_groups = ((n + 127) / 128) * 8;
@@ -75,18 +87,35 @@ __global__ __launch_bounds__(kWave) void k_sample_khop3(GraphView g, const uint3
     const uint64_t b = grp >> 3, y = grp & 7;
     Xorwow st;
     st.load(states + 6 * grp);
+    uint32_t rid[16];
+#pragma unroll
+    for (uint32_t k = 0; k < 16; ++k) {
+      const uint64_t index = 128 * b + y + 8 * k;
+      rid[k] = index < n ? input[index] : kEmptyKey;
+    }
+#pragma unroll
+    for (uint32_t k = 0; k < 16; ++k) {
+      const uint64_t index = 128 * b + y + 8 * k;
+      uint32_t len = 0, off = 0, sv = 0;
+      if (index < n) {
+        g.neighbours(rid[k], len);
+        off = offset[index];
+        sv = sm.value(rid[k], index);
+      }
+      seed_len[k * kWave + lane] = len;
+      seed_off[k * kWave + lane] = off;
+      seed_src[k * kWave + lane] = sv;
+    }
     for (uint32_t k = 0; k < 16; ++k) {
       const uint64_t index = 128 * b + y + 8 * k;
       if (index >= n) break;
-      const uint32_t rid = input[index];
-      uint32_t len;
-      const uint32_t *edges = g.neighbours(rid, len);
-      const uint32_t o = offset[index];
-      const uint32_t sv = sm.value(rid, index);
+      const uint32_t len = seed_len[k * kWave + lane];
+      const uint32_t o = seed_off[k * kWave + lane];
+      const uint32_t sv = seed_src[k * kWave + lane];
       if (len <= fanout) {
         for (uint32_t j = 0; j < len; ++j) {
           out_src[o + j] = sv;
-          out_dst[o + j] = edges[j];
+          out_dst[o + j] = j;
         }
       } else {
         uint32_t count = 0;
@@ -97,7 +126,9 @@ __global__ __launch_bounds__(kWave) void k_sample_khop3(GraphView g, const uint3
             const uint32_t cur = set_tab[pos * kWave + lane];
             if (cur == HASH_EMPTY) {
               set_tab[pos * kWave + lane] = r;
-              set_used[count * kWave + lane] = (uint8_t)pos; // insertion order (items[] of khop3.cu:64)
+              set_used[count * kWave + lane] = (uint8_t)pos;
+              out_src[o + count] = sv;
+              out_dst[o + count] = r; // insertion order == output order (items[] of khop3.cu:64)
               ++count;
               break;
             }
@@ -106,16 +137,27 @@ __global__ __launch_bounds__(kWave) void k_sample_khop3(GraphView g, const uint3
             ++delta;
           }
         }
-        for (uint32_t j = 0; j < fanout; ++j) {
-          const uint32_t slot = set_used[j * kWave + lane];
-          const uint32_t r = set_tab[slot * kWave + lane];
-          set_tab[slot * kWave + lane] = HASH_EMPTY; // leave the set empty for the next seed
-          out_src[o + j] = sv;
-          out_dst[o + j] = edges[r];
-        }
+        for (uint32_t j = 0; j < fanout; ++j) // leave the set empty for the next seed
+          set_tab[(uint32_t)set_used[j * kWave + lane] * kWave + lane] = HASH_EMPTY;
       }
     }
     st.store(states + 6 * grp);
+  }
+}
+
+// out_dst[e] holds a position inside the seed's neighbour list; replace it by the neighbour id.
+// The seed comes from out_src[e]: its global id (leaf API) or, in local mode, n2o[out_src[e]].
+__global__ __launch_bounds__(kBlock) void k_gather_neighbours(GraphView g, const uint32_t *__restrict__ out_src,
+                                                              uint32_t *__restrict__ out_dst,
+                                                              const uint64_t *__restrict__ num_out,
+                                                              const uint32_t *__restrict__ local_to_global) {
+  const uint64_t n = *num_out;
+  for (uint64_t e = (uint64_t)blockIdx.x * kBlock + threadIdx.x; e < n; e += (uint64_t)gridDim.x * kBlock) {
+    const uint32_t sv = out_src[e];
+    const uint32_t rid = local_to_global ? local_to_global[sv] : sv;
+    uint32_t len;
+    const uint32_t *edges = g.neighbours(rid, len);
+    out_dst[e] = edges[out_dst[e]];
   }
 }
 
@@ -173,7 +215,7 @@ size_t sample_ws_words(size_t num_input) { return num_input + tile_scan_words(nu
 // offsets by exclusive scan of min(deg, fanout), then the sampler proper
 int sample_khop3_impl(GraphView g, const uint32_t *input, size_t n_max, Count n, uint32_t fanout, uint32_t *out_src,
                       uint32_t *out_dst, uint64_t *num_out_dev, uint32_t *states, uint32_t *workspace,
-                      const uint32_t *seed_local, int src_local, hipStream_t s) {
+                      const uint32_t *seed_local, int src_local, const uint32_t *local_to_global, hipStream_t s) {
   uint32_t *offset = workspace;
   uint32_t *scratch = offset + n_max;
   int rc = tile_scan(SeedCount{g, input, fanout}, StoreOffset{offset}, n_max, n, scratch, nullptr, nullptr,
@@ -183,13 +225,16 @@ int sample_khop3_impl(GraphView g, const uint32_t *input, size_t n_max, Count n,
   const int grid = grid_for(num_groups, kWave);
   const SrcMode sm{seed_local, src_local};
   if (fanout < 32) {
-    hipLaunchKernelGGL((k_sample_khop3<6>), dim3(grid), dim3(kWave), 0, s, g, input, n, fanout, offset, out_src,
+    hipLaunchKernelGGL((k_khop3_positions<6>), dim3(grid), dim3(kWave), 0, s, g, input, n, fanout, offset, out_src,
                        out_dst, states, sm);
   } else {
     // 128 slots, the reference's HASHTABLE_SIZE (khop3.cu:43): load factor < 0.5 up to fanout 63
-    hipLaunchKernelGGL((k_sample_khop3<7>), dim3(grid), dim3(kWave), 0, s, g, input, n, fanout, offset, out_src,
+    hipLaunchKernelGGL((k_khop3_positions<7>), dim3(grid), dim3(kWave), 0, s, g, input, n, fanout, offset, out_src,
                        out_dst, states, sm);
   }
+  GGMS_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_gather_neighbours, dim3(grid_for(n_max * fanout, kBlock)), dim3(kBlock), 0, s, g, out_src,
+                     out_dst, num_out_dev, src_local ? local_to_global : nullptr);
   GGMS_LAUNCH_CHECK();
   return GGMS_OK;
 }
@@ -236,7 +281,7 @@ int ggms_sample_khop3(const ggms_graph_t *graph, const ggms_id_t *input, size_t 
   GGMS_CHECK_ARG((uint64_t)num_input * fanout < (1ull << 32));
   GGMS_CHECK_ARG((num_input + 127) / 128 * 8 <= num_states); // assert(i < num_random_states), khop3.cu:89
   return sample_khop3_impl(view_of(graph), input, num_input, count_of(num_input), (uint32_t)fanout, out_src, out_dst,
-                           num_out_dev, (uint32_t *)states, (uint32_t *)workspace, nullptr, 0, s);
+                           num_out_dev, (uint32_t *)states, (uint32_t *)workspace, nullptr, 0, nullptr, s);
 }
 
 int ggms_sample_khop0(const ggms_graph_t *graph, const ggms_id_t *input, size_t num_input, size_t fanout,

@@ -1,0 +1,58 @@
+"""Seeded synthetic datasets shaped like the reference's.
+
+There is no network, so ogbn-products / papers100M cannot be downloaded; these
+generators produce power-law in-neighbour CSRs with the same node count, mean
+degree, feature width and train-set size, plus exactly representable features
+so gathers can be checked bit for bit.  numpy only (host side).
+"""
+import numpy as np
+
+PRESETS = {
+    # name: num_node, mean_deg, alpha, dmax, feat_dim, num_class, num_train
+    "products": dict(num_node=2_449_029, mean_deg=50.5, alpha=0.75, dmax=17_000, feat_dim=100, num_class=47,
+                     num_train=196_615),
+    "papers100M": dict(num_node=111_059_956, mean_deg=14.55, alpha=0.7, dmax=300_000, feat_dim=128, num_class=172,
+                       num_train=1_207_179),
+    "tiny": dict(num_node=20_000, mean_deg=30.0, alpha=0.75, dmax=2_000, feat_dim=100, num_class=47,
+                 num_train=4_000),
+}
+
+
+def powerlaw_degrees(num_node, mean_deg, alpha, dmax, rng):
+    """d_v = min(dmax, floor(c * u^-alpha)), c tuned so that the mean is mean_deg."""
+    u = rng.random_sample(num_node)
+    base = u ** (-alpha)
+    lo, hi = 1e-3, 1e6
+    for _ in range(60):  # bisection on c
+        c = 0.5 * (lo + hi)
+        m = np.minimum(dmax, np.floor(c * base)).mean()
+        if m < mean_deg:
+            lo = c
+        else:
+            hi = c
+    return np.minimum(dmax, np.floor(hi * base)).astype(np.int64)
+
+
+def make_graph(preset="products", seed=42, chunk=1 << 24):
+    """Returns dict(indptr uint32[N+1], indices uint32[E], train_set uint32[T], meta)."""
+    p = dict(PRESETS[preset]) if isinstance(preset, str) else dict(preset)
+    rng = np.random.RandomState(seed)
+    n = p["num_node"]
+    deg = powerlaw_degrees(n, p["mean_deg"], p["alpha"], p["dmax"], rng)
+    indptr = np.zeros(n + 1, dtype=np.int64)
+    np.cumsum(deg, out=indptr[1:])
+    num_edge = int(indptr[-1])
+    assert num_edge < 2 ** 32, "IdType is uint32 (constant.h:28): num_edge must stay below 2^32"
+    indices = np.empty(num_edge, dtype=np.uint32)
+    for s in range(0, num_edge, chunk):  # chunked: bounded temporaries
+        e = min(num_edge, s + chunk)
+        indices[s:e] = np.random.RandomState(1234 + s // chunk).randint(0, n, size=e - s, dtype=np.int64)
+    train = np.random.RandomState(seed + 1).permutation(n)[: p["num_train"]].astype(np.uint32)
+    p["num_edge"] = num_edge
+    return dict(indptr=indptr.astype(np.uint32), indices=indices, train_set=train, meta=p)
+
+
+def degree_rank(indptr):
+    """cache_by_degree.bin equivalent: node ids by descending in-degree (stable)."""
+    deg = (indptr[1:].astype(np.int64) - indptr[:-1].astype(np.int64))
+    return np.argsort(-deg, kind="stable").astype(np.uint32)

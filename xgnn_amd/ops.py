@@ -222,3 +222,48 @@ def extract_cached(out, nodes, table, parts_table, num_part, host_feat, num=None
                                     num_part, _ptr(host_feat), _dim_of(out), DTYPE_CODE[out.dtype], _ptr(num_miss),
                                     _stream()), "ggms_extract_cached")
     return out
+
+
+class BatchSampler:
+    """DoGPUSample (dist_loops.cc:62-368) as one enqueue: buffers sized once, reused every batch."""
+
+    def __init__(self, graph, fanouts, batch_size, sample_type=KHOP3, seed=0, device="cuda"):
+        self.graph, self.fanouts, self.sample_type = graph, [int(f) for f in fanouts], sample_type
+        L = len(self.fanouts)
+        self.L = L
+        self._f = (C.c_size_t * L)(*self.fanouts)
+        mi, me, mu = (C.c_size_t * L)(), (C.c_size_t * L)(), C.c_size_t(0)
+        # first batch of an epoch may be 1.25x (dist_shuffler_aligned.cc:137-140): size for it
+        self.max_seeds = int(batch_size * 1.25) + 1
+        check(lib().ggms_sample_batch_capacity(self.max_seeds, self._f, L, mi, me, C.byref(mu)), "capacity")
+        self.max_input, self.max_edges, self.max_unique = list(mi), list(me), mu.value
+        self.ht = OrderedHashTable(self.max_unique, device)
+        nstates = lib().ggms_random_states_count(sample_type, self._f, L, self.max_seeds, 0)
+        nstates = max(nstates, (max(self.max_input) + 127) // 128 * 8)
+        self.states = random_states(nstates, seed, device) if sample_type == KHOP3 else None
+        self.row = [torch.empty(max(1, e), dtype=torch.int32, device=device) for e in self.max_edges]
+        self.col = [torch.empty(max(1, e), dtype=torch.int32, device=device) for e in self.max_edges]
+        self._row = (C.c_void_p * L)(*[t.data_ptr() for t in self.row])
+        self._col = (C.c_void_p * L)(*[t.data_ptr() for t in self.col])
+        self.counts = torch.zeros(3 * L + 1, dtype=torch.int64, device=device)
+        self.ws = _workspace(lib().ggms_sample_batch_workspace_bytes(self.max_seeds, self._f, L), device)
+
+    def sample(self, seeds):
+        """Enqueue one batch; returns nothing -- read self.counts / row / col / ht.n2o after a sync."""
+        _i32(seeds)
+        n = seeds.numel()
+        assert n <= self.max_seeds
+        check(lib().ggms_sample_batch(self.sample_type, C.byref(self.graph.c), _ptr(seeds), n, self._f, self.L,
+                                      C.byref(self.ht.c), _ptr(self.states),
+                                      self.states.shape[0] if self.states is not None else 0, self._row, self._col,
+                                      _ptr(self.counts), _ptr(self.ws), self.ws.numel() * 4, _stream()),
+              "ggms_sample_batch")
+
+    def result(self):
+        """Sync and slice the outputs (host round trip: for tests and hand-off, not for the hot loop)."""
+        c = self.counts.cpu().tolist()
+        layers = []
+        for i in range(self.L):
+            ne = c[3 * i]
+            layers.append(dict(row=self.row[i][:ne], col=self.col[i][:ne], num_src=c[3 * i + 1], num_dst=c[3 * i + 2]))
+        return dict(layers=layers, input_nodes=self.ht.n2o[: c[3 * self.L]])
