@@ -55,93 +55,160 @@ struct SrcMode {
 // 128 b + y + 8 k, k = 0..15, in that order (khop3.cu:86-89,106).
 //
 // Two launches:
-//   k_khop3_positions  one lane per stream: the serial part (RNG + rejection),
-//                      no neighbour loads; writes the chosen POSITION r_j into
-//                      out_dst[o + j].  The 16 seeds' (id, degree, offset) chains
-//                      are fetched up front into LDS so their latency is paid once.
-//   k_gather_neighbours  flat over edges: out_dst[e] = neighbours(seed)[out_dst[e]].
-// Keeping the random 4-byte neighbour reads out of the serial loop is what
-// matters: in one fused loop each lane waited ~1 us per neighbour.
-template <int SET_BITS>
-__global__ __launch_bounds__(kWave) void k_khop3_positions(GraphView g, const uint32_t *__restrict__ input,
-                                                           Count n_arg, uint32_t fanout,
-                                                           const uint32_t *__restrict__ offset,
-                                                           uint32_t *__restrict__ out_src,
-                                                           uint32_t *__restrict__ out_dst,
-                                                           uint32_t *__restrict__ states, SrcMode sm) {
-  constexpr uint32_t SLOTS = 1u << SET_BITS;
-  constexpr uint32_t SMASK = SLOTS - 1;
+//   k_khop3_positions   the reference's own geometry -- 16 lanes per stream, 8 streams per
+//                       128-thread block -- but the 16 lanes do useful work.  The stream is
+//                       serial only in its XORWOW recurrence (9 ALU ops per draw); everything
+//                       else is done 16 draws at a time: every lane of the group steps the
+//                       generator 16 times and keeps draw number `lig`, then the 16 candidates
+//                       are reduced mod deg, looked up in the group's LDS set, de-duplicated
+//                       against EARLIER candidates with DPP row shifts (first occurrence wins,
+//                       exactly what the one-draw-at-a-time loop of khop3.cu:125-131 yields),
+//                       ranked with a ballot, and the accepted ones written in rank order.
+//                       If the set completes at candidate t*, the generator is rewound to just
+//                       after draw t*, so the stream position is the reference's.
+//                       Writes POSITIONS (index into the neighbour list), no neighbour loads.
+//   k_gather_neighbours flat over edges: out_dst[e] = neighbours(seed)[out_dst[e]].
+template <int S>
+__device__ __forceinline__ uint32_t row_shr(uint32_t v, uint32_t fill) {
+  // lane l of a 16-lane row reads lane l - S of the same row; lanes l < S get `fill`
+  return (uint32_t)__builtin_amdgcn_update_dpp((int)fill, (int)v, 0x110 + S, 0xf, 0xf, false);
+}
+
+__global__ __launch_bounds__(128) void k_khop3_positions(GraphView g, const uint32_t *__restrict__ input,
+                                                         Count n_arg, uint32_t fanout,
+                                                         const uint32_t *__restrict__ offset,
+                                                         uint32_t *__restrict__ out_src,
+                                                         uint32_t *__restrict__ out_dst,
+                                                         uint32_t *__restrict__ states, SrcMode sm,
+                                                         uint32_t set_mask) {
   constexpr uint32_t HASH_EMPTY = 0xffffffffu;
-  __shared__ uint32_t set_tab[SLOTS * kWave]; // [slot][lane]
-  __shared__ uint8_t set_used[128 * kWave];   // slot of the j-th insert of the current seed, [j][lane]
-  __shared__ uint32_t seed_len[16 * kWave];   // [k][lane]
-  __shared__ uint32_t seed_off[16 * kWave];
-  __shared__ uint32_t seed_src[16 * kWave];
+  __shared__ uint32_t set_tab[8][128]; // one open-addressing set per group; set_mask + 1 slots in use
   const uint64_t n = n_arg.get();
-  const uint32_t lane = threadIdx.x;
-  const uint64_t num_groups = ((n + 127) / 128) * 8;
+  const uint32_t y = threadIdx.x >> 4, lig = threadIdx.x & 15;
+  const uint32_t grp_shift = (threadIdx.x & 63u) & ~15u; // first lane of my group inside the wave
+  uint32_t *const tab = set_tab[y];
+  const uint64_t num_blocks = (n + 127) / 128;
 
-  for (uint32_t s = 0; s < SLOTS; ++s) set_tab[s * kWave + lane] = HASH_EMPTY;
+  for (uint32_t s = lig; s <= set_mask; s += 16) tab[s] = HASH_EMPTY;
 
-  for (uint64_t grp = (uint64_t)blockIdx.x * kWave + lane; grp < num_groups; grp += (uint64_t)gridDim.x * kWave) {
-    const uint64_t b = grp >> 3, y = grp & 7;
+  for (uint64_t b = blockIdx.x; b < num_blocks; b += gridDim.x) {
+    const uint64_t stream = 8 * b + y;
     Xorwow st;
-    st.load(states + 6 * grp);
-    uint32_t rid[16];
-#pragma unroll
-    for (uint32_t k = 0; k < 16; ++k) {
-      const uint64_t index = 128 * b + y + 8 * k;
-      rid[k] = index < n ? input[index] : kEmptyKey;
+    st.load(states + 6 * stream);
+    // lane lig fetches seed k = lig of the group: id -> (degree, output offset, src value, 2^32/deg)
+    const uint64_t my_index = 128 * b + y + 8 * (uint64_t)lig;
+    const bool my_valid = my_index < n;
+    uint32_t my_len = 0, my_off = 0, my_sv = 0, my_magic = 0;
+    if (my_valid) {
+      const uint32_t rid = input[my_index];
+      g.neighbours(rid, my_len);
+      my_off = offset[my_index];
+      my_sv = sm.value(rid, my_index);
+      if (my_len > 1) my_magic = (uint32_t)(4294967296.0 / (double)my_len); // floor(2^32 / len), exact
     }
-#pragma unroll
-    for (uint32_t k = 0; k < 16; ++k) {
-      const uint64_t index = 128 * b + y + 8 * k;
-      uint32_t len = 0, off = 0, sv = 0;
-      if (index < n) {
-        g.neighbours(rid[k], len);
-        off = offset[index];
-        sv = sm.value(rid[k], index);
-      }
-      seed_len[k * kWave + lane] = len;
-      seed_off[k * kWave + lane] = off;
-      seed_src[k * kWave + lane] = sv;
-    }
-    for (uint32_t k = 0; k < 16; ++k) {
-      const uint64_t index = 128 * b + y + 8 * k;
-      if (index >= n) break;
-      const uint32_t len = seed_len[k * kWave + lane];
-      const uint32_t o = seed_off[k * kWave + lane];
-      const uint32_t sv = seed_src[k * kWave + lane];
-      if (len <= fanout) {
-        for (uint32_t j = 0; j < len; ++j) {
-          out_src[o + j] = sv;
-          out_dst[o + j] = j;
+
+    int k = -1;
+    bool seed_done = true, alive = true;
+    uint32_t len = 0, o = 0, sv = 0, magic = 0, count = 0;
+    while (__any(alive)) {
+      if (alive) {
+        if (seed_done) {
+          ++k;
+          const int src_lane = (int)grp_shift + (k < 16 ? k : 15);
+          const bool valid_k = (k < 16) && (__shfl((int)my_valid, src_lane, 64) != 0);
+          len = __shfl(my_len, src_lane, 64);
+          o = __shfl(my_off, src_lane, 64);
+          sv = __shfl(my_sv, src_lane, 64);
+          magic = __shfl(my_magic, src_lane, 64);
+          count = 0;
+          seed_done = false;
+          if (!valid_k) alive = false;
         }
-      } else {
-        uint32_t count = 0;
-        while (count < fanout) {
-          const uint32_t r = st.next() % len;
-          uint32_t pos = r & SMASK, delta = 1;
-          for (;;) {
-            const uint32_t cur = set_tab[pos * kWave + lane];
-            if (cur == HASH_EMPTY) {
-              set_tab[pos * kWave + lane] = r;
-              set_used[count * kWave + lane] = (uint8_t)pos;
-              out_src[o + count] = sv;
-              out_dst[o + count] = r; // insertion order == output order (items[] of khop3.cu:64)
-              ++count;
-              break;
+        if (alive) {
+          if (len <= fanout) {
+            // every neighbour, in list order (khop3.cu:111-116)
+            for (uint32_t j = lig; j < len; j += 16) {
+              out_src[o + j] = sv;
+              out_dst[o + j] = j;
             }
-            if (cur == r) break;
-            pos = (pos + delta) & SMASK;
-            ++delta;
+            seed_done = true;
+          } else {
+            // ---- one round: 16 consecutive draws of the stream
+            const Xorwow st0 = st;
+            uint32_t x = 0;
+#pragma unroll
+            for (uint32_t i = 0; i < 16; ++i) {
+              const uint32_t xi = st.next();
+              x = (lig == i) ? xi : x;
+            }
+            // r = x mod len: q' = mulhi(x, floor(2^32/len)) is q or q - 1 (two fix-ups for safety)
+            uint32_t r = x - __umulhi(x, magic) * len;
+            r = min(r, r - len);
+            r = min(r, r - len);
+            // already chosen for this seed?
+            bool in_set = false;
+            {
+              uint32_t pos = r & set_mask;
+              for (;;) {
+                const uint32_t cur = tab[pos];
+                if (cur == HASH_EMPTY) break;
+                if (cur == r) { in_set = true; break; }
+                pos = (pos + 1) & set_mask;
+              }
+            }
+            // equal to an EARLIER candidate of this round?
+            bool dup = false;
+            dup |= row_shr<1>(r, HASH_EMPTY) == r;
+            dup |= row_shr<2>(r, HASH_EMPTY) == r;
+            dup |= row_shr<3>(r, HASH_EMPTY) == r;
+            dup |= row_shr<4>(r, HASH_EMPTY) == r;
+            dup |= row_shr<5>(r, HASH_EMPTY) == r;
+            dup |= row_shr<6>(r, HASH_EMPTY) == r;
+            dup |= row_shr<7>(r, HASH_EMPTY) == r;
+            dup |= row_shr<8>(r, HASH_EMPTY) == r;
+            dup |= row_shr<9>(r, HASH_EMPTY) == r;
+            dup |= row_shr<10>(r, HASH_EMPTY) == r;
+            dup |= row_shr<11>(r, HASH_EMPTY) == r;
+            dup |= row_shr<12>(r, HASH_EMPTY) == r;
+            dup |= row_shr<13>(r, HASH_EMPTY) == r;
+            dup |= row_shr<14>(r, HASH_EMPTY) == r;
+            dup |= row_shr<15>(r, HASH_EMPTY) == r;
+            const bool is_new = !in_set && !dup;
+            const uint32_t new_mask = (uint32_t)(__ballot(is_new) >> grp_shift) & 0xffffu;
+            const uint32_t rank = __popc(new_mask & ((1u << lig) - 1u));
+            const uint32_t total_new = __popc(new_mask);
+            const uint32_t need = fanout - count;
+            const bool completes = total_new >= need;
+            const bool accept = is_new && rank < need;
+            if (accept) {
+              // insertion order == output order (items[] of khop3.cu:64)
+              out_src[o + count + rank] = sv;
+              out_dst[o + count + rank] = r;
+            }
+            if (completes) {
+              // rewind the generator to just after the draw that completed the set
+              const uint32_t last_mask = (uint32_t)(__ballot(accept && rank == need - 1) >> grp_shift) & 0xffffu;
+              const uint32_t tstar = __ffs(last_mask) - 1;
+              st = st0;
+              for (uint32_t i = 0; i <= tstar; ++i) st.next();
+              __builtin_amdgcn_wave_barrier();
+              for (uint32_t s = lig; s <= set_mask; s += 16) tab[s] = HASH_EMPTY; // next seed starts empty
+              __builtin_amdgcn_wave_barrier();
+              seed_done = true;
+            } else {
+              __builtin_amdgcn_wave_barrier();
+              if (accept) {
+                uint32_t pos = r & set_mask;
+                while (atomicCAS(&tab[pos], HASH_EMPTY, r) != HASH_EMPTY) pos = (pos + 1) & set_mask;
+              }
+              __builtin_amdgcn_wave_barrier();
+              count += total_new;
+            }
           }
         }
-        for (uint32_t j = 0; j < fanout; ++j) // leave the set empty for the next seed
-          set_tab[(uint32_t)set_used[j * kWave + lane] * kWave + lane] = HASH_EMPTY;
       }
     }
-    st.store(states + 6 * grp);
+    if (lig == 0) st.store(states + 6 * stream);
   }
 }
 
@@ -221,17 +288,12 @@ int sample_khop3_impl(GraphView g, const uint32_t *input, size_t n_max, Count n,
   int rc = tile_scan(SeedCount{g, input, fanout}, StoreOffset{offset}, n_max, n, scratch, nullptr, nullptr,
                      num_out_dev, s);
   if (rc != GGMS_OK) return rc;
-  const size_t num_groups = (n_max + 127) / 128 * 8;
-  const int grid = grid_for(num_groups, kWave);
+  const int grid = grid_for((n_max + 127) / 128, 1);
   const SrcMode sm{seed_local, src_local};
-  if (fanout < 32) {
-    hipLaunchKernelGGL((k_khop3_positions<6>), dim3(grid), dim3(kWave), 0, s, g, input, n, fanout, offset, out_src,
-                       out_dst, states, sm);
-  } else {
-    // 128 slots, the reference's HASHTABLE_SIZE (khop3.cu:43): load factor < 0.5 up to fanout 63
-    hipLaunchKernelGGL((k_khop3_positions<7>), dim3(grid), dim3(kWave), 0, s, g, input, n, fanout, offset, out_src,
-                       out_dst, states, sm);
-  }
+  // 64 slots up to fanout 31 (load < 0.5), else the reference's 128 (HASHTABLE_SIZE, khop3.cu:43)
+  const uint32_t set_mask = fanout < 32 ? 63u : 127u;
+  hipLaunchKernelGGL(k_khop3_positions, dim3(grid), dim3(128), 0, s, g, input, n, fanout, offset, out_src, out_dst,
+                     states, sm, set_mask);
   GGMS_LAUNCH_CHECK();
   hipLaunchKernelGGL(k_gather_neighbours, dim3(grid_for(n_max * fanout, kBlock)), dim3(kBlock), 0, s, g, out_src,
                      out_dst, num_out_dev, src_local ? local_to_global : nullptr);
