@@ -128,13 +128,16 @@ int ggms_sample_khop0(const ggms_graph_t *graph, const ggms_id_t *input,
  * The caller owns the three buffers; the struct is plain data.
  * ------------------------------------------------------------------------- */
 typedef struct {
-  void *o2n;               /* o2n_size buckets of 16 B                      */
+  void *o2n;               /* hashed: o2n_size buckets of 16 B; direct: o2n_size words of 8 B */
   ggms_id_t *n2o;          /* n2o_size ids                                   */
   uint32_t *num_items_dev; /* device counter                                 */
-  uint64_t o2n_size;       /* power of two                                   */
+  uint64_t o2n_size;       /* hashed: power of two; direct: >= number of node ids */
   uint64_t n2o_size;
   uint32_t version;        /* bumped by ggms_hashtable_reset                 */
-  uint32_t _pad;
+  uint32_t direct;         /* 0: hashed layout (reference sizing, TableSize);
+                              1: direct-mapped, one 8-byte word per node id --
+                              no probing, one atomic per insert; needs
+                              8 B x num_node of HBM              */
 } ggms_hashtable_t;
 
 #define GGMS_HT_BUCKET_BYTES 16

@@ -82,14 +82,15 @@ def _check_fill(ops, ht_gpu, ht_orc, items):
     np.testing.assert_array_equal(host_u32(ht_gpu.unique()), ht_orc.unique())
 
 
+@pytest.mark.parametrize("direct", [False, True])
 @pytest.mark.parametrize("n", [1, 17, 512, 1024, 1025, 100_000])
-def test_hashtable_fill_and_map(ops, n):
+def test_hashtable_fill_and_map(ops, n, direct):
     """Semantics pinned by samgraph/unittest/test_hashmap.cc:84-276 (set equality, prefix
     stability, local id == position) plus first-occurrence order vs the oracle."""
     rng = np.random.RandomState(n)
     universe = max(4, n // 2)
     cap = 4 * n + 16
-    ht = ops.OrderedHashTable(cap)
+    ht = ops.OrderedHashTable(cap, num_node=(universe + 1) if direct else None)
     orc = oracle.HashTable(universe + 1, cap)
     for rnd in range(3):  # reuse with Reset (test_hashmap.cc:275-276)
         ht.reset()
@@ -255,15 +256,16 @@ def test_partition_cache_paths(ops, P, dim):
 
 
 # ------------------------------------------------------- multi-layer batch
+@pytest.mark.parametrize("direct", [True, False])
 @pytest.mark.parametrize("stype", ["khop3", "khop0"])
 @pytest.mark.parametrize("fanouts,nseed", [([25, 10], 1000), ([5, 10, 15], 300), ([3], 129), ([25, 10], 0)])
-def test_sample_batch_vs_oracle(ops, stype, fanouts, nseed):
+def test_sample_batch_vs_oracle(ops, stype, fanouts, nseed, direct):
     """DoGPUSample (dist_loops.cc:62-368): row/col/num_src/num_dst per layer + input nodes."""
     ip, ix = powerlaw_csr(20_000, mean_deg=30, seed=2)
     g = ops.DeviceGraph(dev(ip), dev(ix))
     rng = np.random.RandomState(len(fanouts) * 1000 + nseed)
     code = ops.KHOP3 if stype == "khop3" else ops.KHOP0
-    bs = ops.BatchSampler(g, fanouts, max(nseed, 1), sample_type=code, seed=77)
+    bs = ops.BatchSampler(g, fanouts, max(nseed, 1), sample_type=code, seed=77, direct_table=direct)
     orc_states = oracle.random_states(bs.states.shape[0], 77) if stype == "khop3" else None
     for rep in range(3):
         seeds = rng.permutation(20_000)[:nseed].astype(np.uint32)

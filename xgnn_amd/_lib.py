@@ -23,7 +23,7 @@ class HashTable(C.Structure):
     """ggms_hashtable_t"""
     _fields_ = [("o2n", C.c_void_p), ("n2o", C.c_void_p), ("num_items_dev", C.c_void_p),
                 ("o2n_size", C.c_uint64), ("n2o_size", C.c_uint64),
-                ("version", C.c_uint32), ("_pad", C.c_uint32)]
+                ("version", C.c_uint32), ("direct", C.c_uint32)]
 
 
 # name -> (restype, argtypes); every symbol declared in include/ggms.h

@@ -17,7 +17,8 @@ void set_error(const char *fmt, ...) {
 
 __global__ __launch_bounds__(kBlock) void k_tile_prefix(const uint32_t *tile_sums, Count n_arg,
                                                         uint32_t *tile_prefix, const uint32_t *base_in,
-                                                        uint32_t *total32_out, uint64_t *total64_out) {
+                                                        uint32_t *total32_out, uint64_t *total64_out,
+                                                        uint64_t *mirror_a, uint64_t *mirror_b) {
   __shared__ uint32_t smem[kBlock / kWave];
   const uint64_t n = n_arg.get();
   const uint64_t num_tiles = (n + kTile - 1) / kTile;
@@ -35,6 +36,8 @@ __global__ __launch_bounds__(kBlock) void k_tile_prefix(const uint32_t *tile_sum
     tile_prefix[num_tiles] = running;
     if (total32_out) *total32_out = running;
     if (total64_out) *total64_out = (uint64_t)(running - base);
+    if (mirror_a) *mirror_a = (uint64_t)running;
+    if (mirror_b) *mirror_b = (uint64_t)running;
   }
 }
 

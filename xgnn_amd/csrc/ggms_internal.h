@@ -15,13 +15,12 @@ int sample_khop0_impl(GraphView g, const uint32_t *input, size_t n_max, Count n,
 
 // hashtable.hip
 size_t ht_ws_words(size_t num_input);
-// insert + ordered local-id assignment; item_pos[i] = bucket of input[i] (kept for ht_map_by_pos)
+// insert + ordered local-id assignment; item_pos[i] = bucket of input[i] (hashed layout only).
+// mirror_a/b (optional): 64-bit device slots that also receive the new item count
 int ht_fill_impl(const ggms_hashtable_t *ht, const uint32_t *input, size_t n_max, Count n, uint32_t *item_pos,
-                 uint32_t *scratch, hipStream_t s);
-// out[i] = local id stored in bucket item_pos[i]
-int ht_map_by_pos(const ggms_hashtable_t *ht, const uint32_t *item_pos, size_t n_max, Count n, uint32_t *out,
-                  hipStream_t s);
-// out[i] = local id of keys[i] (probing lookup)
-int ht_lookup(const ggms_hashtable_t *ht, const uint32_t *keys, size_t n_max, Count n, uint32_t *out, hipStream_t s);
+                 uint32_t *scratch, uint64_t *mirror_a, uint64_t *mirror_b, hipStream_t s);
+// out[i] = local id of the i-th inserted item (hashed: through item_pos; direct: through keys)
+int ht_map_by_pos(const ggms_hashtable_t *ht, const uint32_t *item_pos, const uint32_t *keys, size_t n_max, Count n,
+                  uint32_t *out, hipStream_t s);
 
 } // namespace ggms

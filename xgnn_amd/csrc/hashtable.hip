@@ -10,7 +10,7 @@
 // FIRST occurrence in the input owns the key, always (canonical semantics, see
 // DESIGN.md): ownership is decided by a 64-bit atomicMin, not by CAS arrival.
 //
-// Bucket (16 B, two 64-bit words):
+// Hashed bucket (16 B, two 64-bit words); the direct layout keeps only w1, one per node id:
 //   w0 = { version : 32 | key : 32 }                        claimed by 64-bit CAS
 //   w1 = { (0x7fffffff - version) : 31 | pending : 1 | value : 32 }
 //        pending = 1: value = smallest input index seen for the key (atomicMin)
@@ -27,36 +27,43 @@
 
 namespace ggms {
 
-struct Bucket {
-  unsigned long long w0;
-  unsigned long long w1;
-};
-
 __device__ __forceinline__ unsigned long long make_w0(uint32_t version, uint32_t key) {
   return ((unsigned long long)key << 32) | version;
 }
 __device__ __forceinline__ uint32_t w0_version(unsigned long long w) { return (uint32_t)w; }
-__device__ __forceinline__ uint32_t w0_key(unsigned long long w) { return (uint32_t)(w >> 32); }
 __device__ __forceinline__ unsigned long long make_w1(uint32_t version, uint32_t pending, uint32_t value) {
   const unsigned long long hi = ((unsigned long long)(0x7fffffffu - version) << 1) | pending;
   return (hi << 32) | value;
 }
 
+// Two layouts share the w1 word and all the ordering logic:
+//   hashed : o2n = buckets {w0, w1} (16 B), open addressing, the reference's sizing;
+//   direct : o2n = one w1 word (8 B) PER NODE ID, indexed by the id itself -- no key word, no
+//            CAS, no probing: an insert is a single fire-and-forget 64-bit atomicMin.  It costs
+//            8 B x num_node of HBM (products 20 MB, papers100M 0.9 GB of 288 GB) and is what the
+//            engine uses; the hashed layout stays for callers that size by batch, as the
+//            reference does (cuda_hashtable.cu:146-149).
 struct Table {
-  Bucket *o2n;
+  unsigned long long *w;
   uint32_t *n2o;
-  uint32_t mask; // o2n_size - 1
+  uint32_t mask; // hashed: o2n_size - 1
   uint32_t version;
 
-  // returns the bucket position of `key`, inserting it if absent
+  template <bool DIRECT>
+  __device__ __forceinline__ unsigned long long *w1(uint32_t pos) const {
+    return DIRECT ? (w + pos) : (w + 2ull * pos + 1);
+  }
+
+  // hashed only: bucket position of `key`, inserting it if absent
   __device__ __forceinline__ uint32_t find_or_claim(uint32_t key) const {
     uint32_t pos = key & mask;
     uint32_t delta = 1;
     const unsigned long long want = make_w0(version, key);
     for (;;) {
-      unsigned long long cur = o2n[pos].w0;
+      unsigned long long *p0 = w + 2ull * pos;
+      unsigned long long cur = *p0;
       if (w0_version(cur) != version) {
-        const unsigned long long prev = atomicCAS(&o2n[pos].w0, cur, want);
+        const unsigned long long prev = atomicCAS(p0, cur, want);
         if (prev == cur) return pos; // claimed
         cur = prev;                  // somebody else wrote this bucket meanwhile
       }
@@ -67,14 +74,15 @@ struct Table {
     }
   }
 
-  // SearchO2N: the key is known to be present
+  // SearchO2N: position of a key that is present (hashed: bounded probing; direct: the id)
+  template <bool DIRECT>
   __device__ __forceinline__ uint32_t find(uint32_t key) const {
+    if (DIRECT) return key;
     uint32_t pos = key & mask;
     uint32_t delta = 1;
     const unsigned long long want = make_w0(version, key);
-    // bounded: a missing key must not hang the GPU
-    for (uint32_t probes = 0; probes <= mask; ++probes) {
-      if (o2n[pos].w0 == want) return pos;
+    for (uint32_t probes = 0; probes <= mask; ++probes) { // bounded: a missing key must not hang the GPU
+      if (w[2ull * pos] == want) return pos;
       pos = (pos + delta) & mask;
       ++delta;
     }
@@ -83,39 +91,46 @@ struct Table {
 };
 
 // generate_hashmap_duplicates (cuda_hashtable.cu:151-168) + ownership by atomicMin
+template <bool DIRECT>
 __global__ __launch_bounds__(kBlock) void k_ht_insert(Table t, const uint32_t *__restrict__ items, Count n_arg,
                                                       uint32_t *__restrict__ item_pos) {
   const uint64_t n = n_arg.get();
   for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (uint64_t)gridDim.x * kBlock) {
     const uint32_t key = items[i];
-    const uint32_t pos = t.find_or_claim(key);
-    atomicMin(&t.o2n[pos].w1, make_w1(t.version, 1u, (uint32_t)i));
-    item_pos[i] = pos;
+    uint32_t pos = key;
+    if (!DIRECT) {
+      pos = t.find_or_claim(key);
+      item_pos[i] = pos;
+    }
+    atomicMin(t.w1<DIRECT>(pos), make_w1(t.version, 1u, (uint32_t)i));
   }
 }
 
 // count_hashmap / compact_hashmap (cuda_hashtable.cu:197-232, 406-458):
-// instance i owns its key iff the bucket still says {pending, i}
+// instance i owns its key iff the word still says {pending, i}
+template <bool DIRECT>
 struct OwnerFlag {
   Table t;
-  const uint32_t *item_pos;
+  const uint32_t *item_pos; // hashed: bucket positions; direct: the keys themselves
   __device__ __forceinline__ uint32_t operator()(uint64_t i) const {
-    return t.o2n[item_pos[i]].w1 == make_w1(t.version, 1u, (uint32_t)i) ? 1u : 0u;
+    return *t.w1<DIRECT>(item_pos[i]) == make_w1(t.version, 1u, (uint32_t)i) ? 1u : 0u;
   }
 };
+template <bool DIRECT>
 struct AssignLocal {
   Table t;
   const uint32_t *items;
   const uint32_t *item_pos;
   __device__ __forceinline__ void operator()(uint64_t i, uint32_t flag, uint32_t local) const {
     if (flag) {
-      t.o2n[item_pos[i]].w1 = make_w1(t.version, 0u, local);
+      *t.w1<DIRECT>(item_pos[i]) = make_w1(t.version, 0u, local);
       t.n2o[local] = items[i];
     }
   }
 };
 
 // map_edge_ids, cuda_mapping.cu:49-66
+template <bool DIRECT>
 __global__ __launch_bounds__(kBlock) void k_map_edges(Table t, const uint32_t *__restrict__ gsrc,
                                                       uint32_t *__restrict__ nsrc,
                                                       const uint32_t *__restrict__ gdst,
@@ -123,12 +138,12 @@ __global__ __launch_bounds__(kBlock) void k_map_edges(Table t, const uint32_t *_
   const uint64_t n = n_arg.get();
   for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (uint64_t)gridDim.x * kBlock) {
     if (gsrc) {
-      const uint32_t p = t.find(gsrc[i]);
-      nsrc[i] = (p == 0xffffffffu) ? kEmptyKey : (uint32_t)t.o2n[p].w1;
+      const uint32_t p = t.find<DIRECT>(gsrc[i]);
+      nsrc[i] = (p == 0xffffffffu) ? kEmptyKey : (uint32_t)*t.w1<DIRECT>(p);
     }
     if (gdst) {
-      const uint32_t p = t.find(gdst[i]);
-      ndst[i] = (p == 0xffffffffu) ? kEmptyKey : (uint32_t)t.o2n[p].w1;
+      const uint32_t p = t.find<DIRECT>(gdst[i]);
+      ndst[i] = (p == 0xffffffffu) ? kEmptyKey : (uint32_t)*t.w1<DIRECT>(p);
     }
   }
 }
@@ -141,40 +156,44 @@ __global__ void k_copy_prefix(const uint32_t *__restrict__ src, uint32_t *__rest
 }
 
 static inline Table table_of(const ggms_hashtable_t *ht) {
-  return Table{(Bucket *)ht->o2n, ht->n2o, (uint32_t)(ht->o2n_size - 1), ht->version};
+  return Table{(unsigned long long *)ht->o2n, ht->n2o, (uint32_t)(ht->o2n_size - 1), ht->version};
 }
 
+template <bool DIRECT>
 __global__ __launch_bounds__(kBlock) void k_map_by_pos(Table t, const uint32_t *__restrict__ item_pos, Count n_arg,
                                                        uint32_t *__restrict__ out) {
   const uint64_t n = n_arg.get();
   for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (uint64_t)gridDim.x * kBlock)
-    out[i] = (uint32_t)t.o2n[item_pos[i]].w1;
+    out[i] = (uint32_t)*t.w1<DIRECT>(item_pos[i]);
 }
 
 size_t ht_ws_words(size_t num_input) { return num_input + tile_scan_words(num_input) + 16; }
 
 int ht_fill_impl(const ggms_hashtable_t *ht, const uint32_t *input, size_t n_max, Count n, uint32_t *item_pos,
-                 uint32_t *scratch, hipStream_t s) {
+                 uint32_t *scratch, uint64_t *mirror_a, uint64_t *mirror_b, hipStream_t s) {
   if (n_max == 0) return GGMS_OK;
   Table t = table_of(ht);
-  hipLaunchKernelGGL(k_ht_insert, dim3(grid_for(n_max, kBlock)), dim3(kBlock), 0, s, t, input, n, item_pos);
+  const int grid = grid_for(n_max, kBlock);
+  if (ht->direct) {
+    hipLaunchKernelGGL(k_ht_insert<true>, dim3(grid), dim3(kBlock), 0, s, t, input, n, item_pos);
+    GGMS_LAUNCH_CHECK();
+    return tile_scan(OwnerFlag<true>{t, input}, AssignLocal<true>{t, input, input}, n_max, n, scratch,
+                     ht->num_items_dev, ht->num_items_dev, nullptr, s, mirror_a, mirror_b);
+  }
+  hipLaunchKernelGGL(k_ht_insert<false>, dim3(grid), dim3(kBlock), 0, s, t, input, n, item_pos);
   GGMS_LAUNCH_CHECK();
-  return tile_scan(OwnerFlag{t, item_pos}, AssignLocal{t, input, item_pos}, n_max, n, scratch, ht->num_items_dev,
-                   ht->num_items_dev, nullptr, s);
+  return tile_scan(OwnerFlag<false>{t, item_pos}, AssignLocal<false>{t, input, item_pos}, n_max, n, scratch,
+                   ht->num_items_dev, ht->num_items_dev, nullptr, s, mirror_a, mirror_b);
 }
 
-int ht_map_by_pos(const ggms_hashtable_t *ht, const uint32_t *item_pos, size_t n_max, Count n, uint32_t *out,
-                  hipStream_t s) {
+int ht_map_by_pos(const ggms_hashtable_t *ht, const uint32_t *item_pos, const uint32_t *keys, size_t n_max, Count n,
+                  uint32_t *out, hipStream_t s) {
   if (n_max == 0) return GGMS_OK;
-  hipLaunchKernelGGL(k_map_by_pos, dim3(grid_for(n_max, kBlock)), dim3(kBlock), 0, s, table_of(ht), item_pos, n, out);
-  GGMS_LAUNCH_CHECK();
-  return GGMS_OK;
-}
-
-int ht_lookup(const ggms_hashtable_t *ht, const uint32_t *keys, size_t n_max, Count n, uint32_t *out, hipStream_t s) {
-  if (n_max == 0) return GGMS_OK;
-  hipLaunchKernelGGL(k_map_edges, dim3(grid_for(n_max, kBlock)), dim3(kBlock), 0, s, table_of(ht), keys, out,
-                     (const uint32_t *)nullptr, (uint32_t *)nullptr, n);
+  const int grid = grid_for(n_max, kBlock);
+  if (ht->direct)
+    hipLaunchKernelGGL(k_map_by_pos<true>, dim3(grid), dim3(kBlock), 0, s, table_of(ht), keys, n, out);
+  else
+    hipLaunchKernelGGL(k_map_by_pos<false>, dim3(grid), dim3(kBlock), 0, s, table_of(ht), item_pos, n, out);
   GGMS_LAUNCH_CHECK();
   return GGMS_OK;
 }
@@ -196,8 +215,9 @@ size_t ggms_hashtable_num_buckets(size_t capacity) {
 
 int ggms_hashtable_init(ggms_hashtable_t *ht, ggms_stream_t stream) {
   GGMS_CHECK_ARG(ht && ht->o2n && ht->n2o && ht->num_items_dev);
-  GGMS_CHECK_ARG(ht->o2n_size != 0 && (ht->o2n_size & (ht->o2n_size - 1)) == 0 && ht->o2n_size <= (1ull << 32));
-  GGMS_HIP(hipMemsetAsync(ht->o2n, 0xff, ht->o2n_size * sizeof(Bucket), to_stream(stream)));
+  GGMS_CHECK_ARG(ht->o2n_size != 0 && ht->o2n_size <= (1ull << 32));
+  GGMS_CHECK_ARG(ht->direct || (ht->o2n_size & (ht->o2n_size - 1)) == 0);
+  GGMS_HIP(hipMemsetAsync(ht->o2n, 0xff, ht->o2n_size * (ht->direct ? 8 : 16), to_stream(stream)));
   GGMS_HIP(hipMemsetAsync(ht->n2o, 0xff, ht->n2o_size * sizeof(uint32_t), to_stream(stream)));
   GGMS_HIP(hipMemsetAsync(ht->num_items_dev, 0, sizeof(uint32_t), to_stream(stream)));
   ht->version = 0;
@@ -231,7 +251,8 @@ int ggms_hashtable_fill_with_duplicates(ggms_hashtable_t *ht, const ggms_id_t *i
     GGMS_CHECK_ARG(workspace_bytes >= ggms_hashtable_workspace_bytes(num_input));
     GGMS_CHECK_ARG(num_input < (1ull << 32));
     uint32_t *item_pos = (uint32_t *)workspace;
-    int rc = ht_fill_impl(ht, input, num_input, count_of(num_input), item_pos, item_pos + num_input, s);
+    int rc = ht_fill_impl(ht, input, num_input, count_of(num_input), item_pos, item_pos + num_input, nullptr,
+                          nullptr, s);
     if (rc != GGMS_OK) return rc;
   }
   if (unique_out) {
@@ -247,8 +268,13 @@ int ggms_map_edges(const ggms_hashtable_t *ht, const ggms_id_t *global_src, ggms
   if (num_edges == 0) return GGMS_OK;
   GGMS_CHECK_ARG((global_src == nullptr) == (new_src == nullptr));
   GGMS_CHECK_ARG((global_dst == nullptr) == (new_dst == nullptr));
-  hipLaunchKernelGGL(k_map_edges, dim3(grid_for(num_edges, kBlock)), dim3(kBlock), 0, to_stream(stream),
-                     table_of(ht), global_src, new_src, global_dst, new_dst, count_of(num_edges));
+  const int grid = grid_for(num_edges, kBlock);
+  if (ht->direct)
+    hipLaunchKernelGGL(k_map_edges<true>, dim3(grid), dim3(kBlock), 0, to_stream(stream), table_of(ht), global_src,
+                       new_src, global_dst, new_dst, count_of(num_edges));
+  else
+    hipLaunchKernelGGL(k_map_edges<false>, dim3(grid), dim3(kBlock), 0, to_stream(stream), table_of(ht), global_src,
+                       new_src, global_dst, new_dst, count_of(num_edges));
   GGMS_LAUNCH_CHECK();
   return GGMS_OK;
 }

@@ -106,11 +106,14 @@ int ggms_sample_batch(int sample_type, const ggms_graph_t *graph, const ggms_id_
   int rc = ggms_hashtable_reset(ht, stream); // hash_table->Reset, dist_loops.cc:105
   if (rc != GGMS_OK) return rc;
   // FillWithDupRevised(seeds), dist_loops.cc:110-111 (item_pos doubles as scratch here)
-  rc = ht_fill_impl(ht, seeds, num_seeds, count_of(num_seeds), item_pos, ht_scratch, s);
+  rc = ht_fill_impl(ht, seeds, num_seeds, count_of(num_seeds), item_pos, ht_scratch, nullptr, nullptr, s);
   if (rc != GGMS_OK) return rc;
   // local ids of the raw seeds (they may repeat): first-layer `col`
-  rc = ht_map_by_pos(ht, item_pos, num_seeds, count_of(num_seeds), seed_local, s);
+  rc = ht_map_by_pos(ht, item_pos, seeds, num_seeds, count_of(num_seeds), seed_local, s);
   if (rc != GGMS_OK) return rc;
+  // num_dst of the first layer = |seeds| (dist_loops.cc:305); later layers get theirs from the fill
+  hipLaunchKernelGGL(k_record, dim3(1), dim3(64), 0, s, counts_dev + 3 * (num_layer - 1) + 2, count_of(num_seeds));
+  GGMS_LAUNCH_CHECK();
 
   for (int i = (int)num_layer - 1; i >= 0; --i) {
     const bool first = (i == (int)num_layer - 1);
@@ -118,10 +121,9 @@ int ggms_sample_batch(int sample_type, const ggms_graph_t *graph, const ggms_id_
     const size_t n_max = c.max_input[i], e_max = c.max_edges[i];
     const Count n = first ? count_of(num_seeds) : count_of32(n_max, ht->num_items_dev);
     uint64_t *num_edge = counts_dev + 3 * i + 0;
-    uint64_t *num_src = counts_dev + 3 * i + 1;
-    uint64_t *num_dst = counts_dev + 3 * i + 2;
-    hipLaunchKernelGGL(k_record, dim3(1), dim3(64), 0, s, num_dst, n); // num_dst = |frontier| (dist_loops.cc:305)
-    GGMS_LAUNCH_CHECK();
+    uint64_t *num_src = counts_dev + 3 * i + 1;                       // unique nodes after this layer (:304)
+    uint64_t *next_dst = i > 0 ? counts_dev + 3 * (i - 1) + 2         // = next layer's frontier size (:305)
+                               : counts_dev + 3 * num_layer;          // = number of input nodes
     if (n_max == 0) {
       GGMS_HIP(hipMemsetAsync(num_edge, 0, sizeof(uint64_t), s));
     } else if (sample_type == GGMS_KHOP3) {
@@ -133,15 +135,17 @@ int ggms_sample_batch(int sample_type, const ggms_graph_t *graph, const ggms_id_
     }
     if (rc != GGMS_OK) return rc;
     const Count ne = count_of(e_max, num_edge);
-    rc = ht_fill_impl(ht, tmp_dst, e_max, ne, item_pos, ht_scratch, s); // FillWithDuplicates, :279
+    if (e_max == 0) { // nothing can be sampled: the counts are the current table size
+      hipLaunchKernelGGL(k_record, dim3(1), dim3(64), 0, s, num_src, count_of32(0, ht->num_items_dev));
+      hipLaunchKernelGGL(k_record, dim3(1), dim3(64), 0, s, next_dst, count_of32(0, ht->num_items_dev));
+      GGMS_LAUNCH_CHECK();
+      continue;
+    }
+    rc = ht_fill_impl(ht, tmp_dst, e_max, ne, item_pos, ht_scratch, num_src, next_dst, s); // FillWithDuplicates, :279
     if (rc != GGMS_OK) return rc;
-    rc = ht_map_by_pos(ht, item_pos, e_max, ne, row[i], s);             // GPUMapEdges dst half, :296
+    rc = ht_map_by_pos(ht, item_pos, tmp_dst, e_max, ne, row[i], s);    // GPUMapEdges dst half, :296
     if (rc != GGMS_OK) return rc;
-    hipLaunchKernelGGL(k_record, dim3(1), dim3(64), 0, s, num_src, count_of32(0, ht->num_items_dev)); // :304
-    GGMS_LAUNCH_CHECK();
   }
-  hipLaunchKernelGGL(k_record, dim3(1), dim3(64), 0, s, counts_dev + 3 * num_layer, count_of32(0, ht->num_items_dev));
-  GGMS_LAUNCH_CHECK();
   return GGMS_OK;
 }
 

@@ -46,9 +46,11 @@ __global__ __launch_bounds__(kBlock) void k_tile_reduce(ValueF value, Count n_ar
 }
 
 // One block.  tile_prefix[t] = base + sum_{u<t} tile_sums[u]; totals out.
+// mirror_a / mirror_b (optional): 64-bit copies of base + total (e.g. "frontier size" slots).
 __global__ __launch_bounds__(kBlock) void k_tile_prefix(const uint32_t *tile_sums, Count n_arg,
                                                         uint32_t *tile_prefix, const uint32_t *base_in,
-                                                        uint32_t *total32_out, uint64_t *total64_out);
+                                                        uint32_t *total32_out, uint64_t *total64_out,
+                                                        uint64_t *mirror_a, uint64_t *mirror_b);
 
 template <typename ValueF, typename EmitF>
 __global__ __launch_bounds__(kBlock) void k_tile_apply(ValueF value, EmitF emit, Count n_arg,
@@ -74,7 +76,7 @@ __global__ __launch_bounds__(kBlock) void k_tile_apply(ValueF value, EmitF emit,
 template <typename ValueF, typename EmitF>
 inline int tile_scan(ValueF value, EmitF emit, size_t n_max, Count n, uint32_t *scratch,
                      const uint32_t *base_in, uint32_t *total32_out, uint64_t *total64_out,
-                     hipStream_t stream) {
+                     hipStream_t stream, uint64_t *mirror_a = nullptr, uint64_t *mirror_b = nullptr) {
   const size_t nt = num_tiles_for(n_max);
   uint32_t *tile_sums = scratch;
   uint32_t *tile_prefix = scratch + nt + 2;
@@ -82,7 +84,7 @@ inline int tile_scan(ValueF value, EmitF emit, size_t n_max, Count n, uint32_t *
   hipLaunchKernelGGL((k_tile_reduce<ValueF>), dim3(grid), dim3(kBlock), 0, stream, value, n, tile_sums);
   GGMS_LAUNCH_CHECK();
   hipLaunchKernelGGL(k_tile_prefix, dim3(1), dim3(kBlock), 0, stream, tile_sums, n, tile_prefix, base_in,
-                     total32_out, total64_out);
+                     total32_out, total64_out, mirror_a, mirror_b);
   GGMS_LAUNCH_CHECK();
   hipLaunchKernelGGL((k_tile_apply<ValueF, EmitF>), dim3(grid), dim3(kBlock), 0, stream, value, emit, n,
                      tile_prefix);

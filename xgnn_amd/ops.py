@@ -113,9 +113,12 @@ def sample_khop0(graph, inp, fanout):
 class OrderedHashTable:
     """OrderedHashTable (cuda_hashtable.h:103-153) over caller-owned device buffers."""
 
-    def __init__(self, capacity, device="cuda"):
-        nb = lib().ggms_hashtable_num_buckets(capacity)
-        self.o2n = torch.empty((nb, 4), dtype=torch.int32, device=device)
+    def __init__(self, capacity, device="cuda", num_node=None):
+        """num_node=None: hashed layout sized like the reference (TableSize); num_node=N: direct-mapped
+        layout, one 8-byte word per node id (the engine's choice on MI355X)."""
+        direct = num_node is not None
+        nb = int(num_node) if direct else lib().ggms_hashtable_num_buckets(capacity)
+        self.o2n = torch.empty((nb, 2 if direct else 4), dtype=torch.int32, device=device)
         _require_gpu(self.o2n)
         self.n2o = torch.empty(max(1, capacity), dtype=torch.int32, device=device)
         self.num_items_dev = torch.zeros(1, dtype=torch.int32, device=device)
@@ -125,6 +128,7 @@ class OrderedHashTable:
         self.c.num_items_dev = self.num_items_dev.data_ptr()
         self.c.o2n_size = nb
         self.c.n2o_size = self.n2o.numel()
+        self.c.direct = 1 if direct else 0
         check(lib().ggms_hashtable_init(C.byref(self.c), _stream()), "ggms_hashtable_init")
 
     def reset(self):
@@ -227,7 +231,7 @@ def extract_cached(out, nodes, table, parts_table, num_part, host_feat, num=None
 class BatchSampler:
     """DoGPUSample (dist_loops.cc:62-368) as one enqueue: buffers sized once, reused every batch."""
 
-    def __init__(self, graph, fanouts, batch_size, sample_type=KHOP3, seed=0, device="cuda"):
+    def __init__(self, graph, fanouts, batch_size, sample_type=KHOP3, seed=0, device="cuda", direct_table=True):
         self.graph, self.fanouts, self.sample_type = graph, [int(f) for f in fanouts], sample_type
         L = len(self.fanouts)
         self.L = L
@@ -237,7 +241,7 @@ class BatchSampler:
         self.max_seeds = int(batch_size * 1.25) + 1
         check(lib().ggms_sample_batch_capacity(self.max_seeds, self._f, L, mi, me, C.byref(mu)), "capacity")
         self.max_input, self.max_edges, self.max_unique = list(mi), list(me), mu.value
-        self.ht = OrderedHashTable(self.max_unique, device)
+        self.ht = OrderedHashTable(self.max_unique, device, num_node=graph.c.num_node if direct_table else None)
         nstates = lib().ggms_random_states_count(sample_type, self._f, L, self.max_seeds, 0)
         nstates = max(nstates, (max(self.max_input) + 127) // 128 * 8)
         self.states = random_states(nstates, seed, device) if sample_type == KHOP3 else None
