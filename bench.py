@@ -41,11 +41,35 @@ def parse():
     return ap.parse_args()
 
 
+def usable_cores():
+    """Threads this process may really use: cgroup CPU quota if set, else the affinity mask."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return n
+
+
+def measured_traffic():
+    """HBM traffic of the extract kernel from the committed PMC profile (profiles/*_extract_traffic.json):
+    collected with separate `rocprofv3 --pmc` passes of this same command, FETCH_SIZE corrected x2."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_extract_traffic.json")))
+    if not files:
+        return None
+    d = json.load(open(files[-1]))
+    d["source"] = os.path.relpath(files[-1], ROOT)
+    return d
+
+
 def cpu_baseline(graph, fanouts, batch, feat_dim, n_batches):
     """CPU leg: the oracle (port) and, when shipped, the reference's own CPU leaves (oracle/_ref).
     Bounded sample: n_batches mini-batches of the same workload on all host cores."""
     import oracle
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     ip, ix, train = graph["indptr"], graph["indices"], graph["train_set"]
     n_node = ip.size - 1
     feat = (np.arange(n_node * feat_dim, dtype=np.int64) & 0xFFFF).astype(np.float32).reshape(n_node, feat_dim)
@@ -230,6 +254,10 @@ def main():
         algo_bytes_per_launch = rows / args.steps * (4 + 2 * row_bytes)
         avg_launch_s = ext_s / args.steps
         achieved = algo_bytes_per_launch / avg_launch_s / 1e9
+        tr = measured_traffic()
+        traffic = None
+        if tr is not None:  # PMC bytes per row (profiled run) x rows of this run / this run's launch time
+            traffic = tr["hbm_bytes_per_launch"] / tr["rows_per_launch"] * (rows / args.steps) / avg_launch_s / 1e9
         res = {
             "metric": "sampled edges/s + feature-extract GB/s per epoch-step",
             "value": edges_all / elapsed,
@@ -260,10 +288,12 @@ def main():
                 "rows_per_step": rows / args.steps,
             },
             "roofline": {
-                "kernel": "k_gather_rows<16, CachedRows> (ggms_extract_cached)",
+                "kernel": "k_gather_rows<16, CachedRows, ident-dst, nt> (ggms_extract_cached)",
                 "bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
-                "frac": achieved / 8000.0, "traffic": None,
+                "frac": achieved / 8000.0, "traffic": traffic,
                 "algorithmic_bytes_per_row": 4 + 2 * row_bytes,
+                "avg_launch_us": avg_launch_s * 1e6,
+                "traffic_source": tr["source"] if tr else None,
             },
         }
         if world == 1 and not args.no_cpu_baseline:
