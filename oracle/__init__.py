@@ -106,6 +106,15 @@ def shuffle_minstd0(data, seed):
     return d
 
 
+def aligned_pad(train, num_worker):
+    """DistAlignedShuffler ctor padding (dist_shuffler_aligned.cc:46-56)."""
+    train = _u32(train)
+    n = int(lib().orc_aligned_pad(None, _sz(train.size), _sz(num_worker), None))
+    out = np.empty(n, np.uint32)
+    lib().orc_aligned_pad(_p(train), _sz(train.size), _sz(num_worker), _p(out))
+    return out
+
+
 def mt19937_shuffle(data, seed):
     g = (C.c_uint32 * 625)()
     lib().orc_mt19937_seed(g, C.c_uint32(int(seed)))

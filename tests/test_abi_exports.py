@@ -26,6 +26,35 @@ def test_ggms_header_symbols_exported_and_bound():
         assert n in names, f"{n} bound but not declared in include/ggms.h"
 
 
+def test_samgraph_header_symbols_exported_and_bound():
+    """Every samgraph_* entry of include/samgraph.h (operation.h:30-115 + adapter.cc hand-off) is exported
+    by the same shared object and has a ctypes binding in the samgraph.common mirror."""
+    from xgnn_amd import common
+    names = _declared("samgraph.h")
+    assert len(names) >= 45
+    h = ctypes.CDLL(xgnn_amd.LIB_PATH)
+    for n in names:
+        assert hasattr(h, n), f"{n} declared in include/samgraph.h but not exported"
+        assert n in common.SAMGRAPH_SYMBOLS, f"{n} has no binding in xgnn_amd/common.py"
+    for n in common.SAMGRAPH_SYMBOLS:
+        assert n in names, f"{n} bound but not declared in include/samgraph.h"
+
+
+def test_reference_python_surface_present():
+    """Names the reference's example scripts use through `import samgraph.torch as sam`
+    (samgraph/torch/adapter.py:63-218, common/__init__.py:47-276)."""
+    import samgraph.torch as sam
+    for n in ("config init data_init sample_init train_init extract_start sample_once get_next_batch get_dgl_blocks "
+              "get_graph_feat get_graph_label get_graph_row get_graph_col get_graph_num_src get_graph_num_dst "
+              "num_epoch steps_per_epoch num_local_step num_class feat_dim report_step report_epoch_average "
+              "log_step log_epoch_add get_log_epoch_value wait_one_child shutdown cpu gpu sample_types "
+              "builtin_archs cache_policies kKHop3 kArch6 kCacheByDegree kLogEpochSampleTime kLogEpochNumSample "
+              "kLogEpochCopyTime kLogEpochFeatureBytes kLogEpochMissBytes kLogL1CopyTime kL1Event_Sample").split():
+        assert hasattr(sam, n), n
+    assert (sam.kLogEpochSampleTime, sam.kLogEpochCopyTime, sam.kLogEpochNumSample) == (0, 8, 15)
+    assert (sam.kLogL1NumSample, sam.kLogL1CopyTime, sam.kLogL1MissBytes, sam.kNumLogStepItems) == (0, 6, 13, 50)
+
+
 def test_host_only_entry_points():
     l = xgnn_amd.lib()
     assert l.ggms_abi_version() == 1

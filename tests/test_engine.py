@@ -1,0 +1,162 @@
+"""Engine behind the samgraph_* ABI vs the oracle: arch1 (one GPU) and arch6 (forked workers, GGMS shards)."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import oracle
+from graphgen import exact_features, powerlaw_csr
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DRIVER = os.path.join(ROOT, "tests", "engine_driver.py")
+
+
+def make_dataset(tmp_path, num_node=3000, dim=20, num_train=500, dtype=np.float32, seed=5):
+    from xgnn_amd import datagen
+    ip, ix = powerlaw_csr(num_node, mean_deg=15, seed=seed)
+    train = np.random.RandomState(seed).permutation(num_node)[:num_train].astype(np.uint32)
+    feat = exact_features(num_node, dim, dtype)
+    label = (np.arange(num_node, dtype=np.int64) * 7) % 13
+    g = dict(indptr=ip, indices=ix, train_set=train, meta=dict(feat_dim=dim, num_class=13))
+    names = {np.dtype(np.float32): "F32", np.dtype(np.float16): "F16", np.dtype(np.uint8): "U8"}
+    datagen.write_dataset(str(tmp_path), g, feat=feat, label=label, feat_dtype=names[np.dtype(dtype)])
+    return dict(ip=ip, ix=ix, train=train, feat=feat, label=label, path=str(tmp_path))
+
+
+def test_data_init_host_only(tmp_path):
+    """config + data_init touch no GPU (they run in the parent before fork): dataset format round trip."""
+    d = make_dataset(tmp_path)
+    code = f"""
+import sys; sys.path.insert(0, {ROOT!r})
+import samgraph.torch as sam
+sam.config({{'dataset_path': {d['path']!r}, '_arch': 6, '_sample_type': 7, 'batch_size': 64, 'num_epoch': 1,
+  '_cache_policy': 0, 'cache_percentage': 0.3, 'max_sampling_jobs': 1, 'max_copying_jobs': 1, 'omp_thread_num': 1,
+  'num_layer': 2, 'num_hidden': 8, 'lr': 0.1, 'dropout': 0.5, 'num_worker': 2, 'num_fanout': 2, 'fanout': [5, 4]}})
+sam.data_init()
+f = sam.get_dataset_feat(); l = sam.get_dataset_label()
+print(sam.num_class(), sam.feat_dim(), tuple(f.shape), float(f[17, 3]), int(l[17]))
+"""
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    assert out.stdout.split()[:2] == ["13", "20"]
+    assert "(3000, 20)" in out.stdout
+    assert float(out.stdout.split()[-2]) == float(d["feat"][17, 3]) and int(out.stdout.split()[-1]) == int(d["label"][17])
+
+
+def test_bad_config_aborts(tmp_path):
+    """A failed CHECK prints and abort()s (logging.cc:69-73): no error codes at this boundary."""
+    code = f"""
+import sys; sys.path.insert(0, {ROOT!r})
+import samgraph.torch as sam
+sam.config({{'dataset_path': '/nonexistent', '_arch': 1}})
+"""
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert out.returncode < 0  # SIGABRT
+    assert "missing config key" in out.stderr
+
+
+def _oracle_batches(d, worker_id, num_worker, batch_size, num_epoch, fanouts, seed, arch6, sample_type="khop3"):
+    """Replays shuffler + sampler + extract on the CPU exactly as the engine is specified to."""
+    train = d["train"]
+    padded = oracle.aligned_pad(train, num_worker)
+    n_local = padded.size // num_worker
+    n_local_step = (n_local + batch_size - 1) // batch_size
+    n_global = n_local_step * num_worker
+    max_seeds = int(batch_size * 1.25) + 1
+    nstates = max(oracle.predict_num_nodes(max_seeds, fanouts, len(fanouts) - 1),
+                  (oracle.predict_num_nodes(max_seeds, fanouts, len(fanouts) - 1) + 127) // 128 * 8)
+    states = oracle.random_states(nstates, seed + 1000003 * worker_id)
+    data = padded.copy()
+    out = {}
+    for ep in range(num_epoch):
+        data = oracle.shuffle_minstd0(data, ep if arch6 else seed + ep)
+        local = data[worker_id * n_local:(worker_id + 1) * n_local]
+        for st in range(n_local_step):
+            off = st * batch_size
+            size = min(batch_size, n_local - off)
+            if arch6 and ep == 0 and st == 0:
+                size = min(int(size * 1.25), n_local - off)
+            seeds = local[off:off + size]
+            code = oracle.KHOP3 if sample_type == "khop3" else oracle.KHOP0
+            res = oracle.do_sample(code, d["ip"], d["ix"], seeds, fanouts, states)
+            key = ep * n_global + worker_id * n_local_step + st
+            out[key] = dict(res=res, seeds=seeds, feat=oracle.extract(d["feat"], res["input_nodes"]),
+                            label=d["label"][seeds])
+    return out
+
+
+def _check(npz, want, num_layers):
+    keys = sorted({int(k.split(":")[0]) for k in npz.files})
+    assert keys == sorted(want.keys())
+    for key in keys:
+        w = want[key]
+        np.testing.assert_array_equal(npz[f"{key}:output_nodes"].view(np.uint32), w["seeds"])
+        np.testing.assert_array_equal(npz[f"{key}:input_nodes"].view(np.uint32), w["res"]["input_nodes"])
+        for i in range(num_layers):
+            np.testing.assert_array_equal(npz[f"{key}:row{i}"].view(np.uint32), w["res"]["layers"][i]["row"])
+            np.testing.assert_array_equal(npz[f"{key}:col{i}"].view(np.uint32), w["res"]["layers"][i]["col"])
+            assert int(npz[f"{key}:num_src{i}"]) == w["res"]["layers"][i]["num_src"]
+            assert int(npz[f"{key}:num_dst{i}"]) == w["res"]["layers"][i]["num_dst"]
+        assert npz[f"{key}:feat"].tobytes() == w["feat"].astype(np.float32).tobytes()
+        np.testing.assert_array_equal(npz[f"{key}:label"], w["label"])
+        assert float(npz[f"{key}:num_sample"]) == sum(l["row"].size for l in w["res"]["layers"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("pipelined,sample_type,table", [(0, "khop3", "direct"), (1, "khop3", "hashed"), (0, "khop0", "direct")])
+def test_arch1_end_to_end(tmp_path, pipelined, sample_type, table):
+    d = make_dataset(tmp_path / "ds")
+    prefix = str(tmp_path / "out")
+    r = subprocess.run([sys.executable, DRIVER, d["path"], prefix, "arch1", "1", f"pipelined={pipelined}",
+                        f"sample_type={sample_type}", f"hash_table={table}", "seed=99", "batch_size=64", "fanout=5 4"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    want = _oracle_batches(d, 0, 1, 64, 2, [5, 4], 99, arch6=False, sample_type=sample_type)
+    _check(np.load(prefix + ".w0.npz"), want, 2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [np.float16, np.uint8])
+def test_arch1_feature_dtypes(tmp_path, dtype):
+    """get_graph_feat casts non-f32 tables to float (adapter.py:118-122)."""
+    d = make_dataset(tmp_path / "ds", dim=7, dtype=dtype)
+    prefix = str(tmp_path / "out")
+    r = subprocess.run([sys.executable, DRIVER, d["path"], prefix, "arch1", "1", "seed=5", "num_epoch=1"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    want = _oracle_batches(d, 0, 1, 64, 1, [5, 4], 5, arch6=False)
+    _check(np.load(prefix + ".w0.npz"), want, 2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("opts", [
+    dict(cache_percentage="0.4", part_cache="True", gpu_extract="True", use_dist_graph="1.0"),
+    dict(cache_percentage="0.25", gpu_extract="True", use_dist_graph="0.5"),
+    dict(cache_percentage="0", gpu_extract="True"),
+])
+def test_arch6_two_workers_one_gpu(tmp_path, opts):
+    """XGNN mode: topology shards + partitioned feature cache shared through hipIpc, two forked workers
+    (both mapped onto the single GPU of the test box by SAMGRAPH_FORCE_DEVICE)."""
+    d = make_dataset(tmp_path / "ds")
+    prefix = str(tmp_path / "out")
+    env = dict(os.environ, SAMGRAPH_FORCE_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, DRIVER, d["path"], prefix, "arch6", "2", "seed=7", "batch_size=64",
+                        "fanout=5 4"] + [f"{k}={v}" for k, v in opts.items()],
+                       capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    for w in range(2):
+        want = _oracle_batches(d, w, 2, 64, 2, [5, 4], 7, arch6=True)
+        npz = np.load(f"{prefix}.w{w}.npz")
+        _check(npz, want, 2)
+        if float(opts["cache_percentage"]) > 0:
+            # misses are exactly the input nodes outside the cached prefix of the rank list
+            from xgnn_amd import datagen
+            rank = datagen.degree_rank(d["ip"])
+            ncache = int(d["ip"].size - 1) * float(opts["cache_percentage"])
+            cached = np.zeros(d["ip"].size - 1, bool)
+            cached[rank[: int(ncache)]] = True
+            for key, wv in want.items():
+                nmiss = int((~cached[wv["res"]["input_nodes"]]).sum())
+                assert float(npz[f"{key}:miss_bytes"]) == nmiss * d["feat"].shape[1] * 4

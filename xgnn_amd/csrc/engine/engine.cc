@@ -1,0 +1,640 @@
+// engine.cc -- host orchestration (see engine.h).  Citations are relative to
+// /root/reference/samgraph/common/.
+#include "engine.h"
+
+#include <fcntl.h>
+#include <pthread.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+#include <random>
+#include <sstream>
+
+namespace sam {
+
+void fatal(const char *file, int line, const std::string &msg) {
+  std::fprintf(stderr, "[samgraph-amd FATAL] %s:%d: %s\n", file, line, msg.c_str());
+  std::fflush(stderr);
+  std::abort(); // logging.cc:69-73: failed CHECK aborts the process
+}
+
+void log_info(const std::string &msg) {
+  static const bool on = [] { const char *e = getenv("SAMGRAPH_LOG_LEVEL"); return e && (std::string(e) == "info" || std::string(e) == "debug"); }();
+  if (on) std::fprintf(stderr, "[samgraph-amd] %s\n", msg.c_str());
+}
+
+// process-shared control block for arch6 workers (dist_graph.cu:566-636: anonymous MAP_SHARED mmap +
+// PTHREAD_PROCESS_SHARED barrier, inherited through fork)
+struct Engine::Shared {
+  pthread_barrier_t barrier;
+  int num_worker;
+  static constexpr int kMaxWorker = 16;
+  hipIpcMemHandle_t graph_indptr[kMaxWorker], graph_indices[kMaxWorker], feat_part[kMaxWorker];
+  size_t indptr_words[kMaxWorker], indices_words[kMaxWorker], feat_rows[kMaxWorker];
+};
+
+Engine &Engine::Get() {
+  static Engine e;
+  return e;
+}
+
+static int parse_device(const std::string &ctx) {
+  // "cuda:3" / "cpu:0" (Context(std::string), common.cc)
+  auto p = ctx.find(':');
+  int id = p == std::string::npos ? 0 : std::atoi(ctx.c_str() + p + 1);
+  const char *force = getenv("SAMGRAPH_FORCE_DEVICE"); // test hook: all workers on one physical GPU
+  if (force) id = std::atoi(force);
+  return id;
+}
+
+// ------------------------------------------------------------------ configuration
+void Engine::Configure(const std::unordered_map<std::string, std::string> &kv_in) {
+  auto kv = kv_in;
+  SAM_CHECK(!cfg.configured, "samgraph_config called twice");
+  // required keys, operation.cc:68-81
+  for (const char *k : {"dataset_path", "_arch", "_sample_type", "batch_size", "num_epoch", "_cache_policy",
+                        "cache_percentage", "max_sampling_jobs", "max_copying_jobs", "omp_thread_num", "num_layer",
+                        "num_hidden", "lr", "dropout"})
+    SAM_CHECK(kv.count(k), std::string("missing config key ") + k);
+  cfg.raw = kv;
+  cfg.dataset_path = kv["dataset_path"];
+  cfg.arch = std::stoi(kv["_arch"]);
+  cfg.sample_type = std::stoi(kv["_sample_type"]);
+  cfg.batch_size = std::stoull(kv["batch_size"]);
+  cfg.num_epoch = std::stoull(kv["num_epoch"]);
+  cfg.cache_policy = std::stoi(kv["_cache_policy"]);
+  cfg.cache_percentage = std::stod(kv["cache_percentage"]);
+  cfg.num_layer = std::stoull(kv["num_layer"]);
+  switch (cfg.arch) { // operation.cc:101-148
+    case kArch1:
+      SAM_CHECK(kv.count("sampler_ctx") && kv.count("trainer_ctx"), "arch1 needs sampler_ctx/trainer_ctx");
+      cfg.sampler_device = parse_device(kv["sampler_ctx"]);
+      cfg.trainer_device = parse_device(kv["trainer_ctx"]);
+      cfg.num_worker = 1;
+      break;
+    case kArch6:
+      SAM_CHECK(kv.count("num_worker"), "arch6 needs num_worker");
+      cfg.num_worker = std::stoull(kv["num_worker"]);
+      break;
+    default:
+      fatal(__FILE__, __LINE__, "only arch1 (standalone) and arch6 (SGNN/XGNN) are built; see DESIGN.md");
+  }
+  if (cfg.sample_type != GGMS_RANDOM_WALK) { // operation.cc:150-163
+    SAM_CHECK(kv.count("num_fanout") && kv.count("fanout"), "khop sampling needs num_fanout/fanout");
+    size_t nf = std::stoull(kv["num_fanout"]);
+    std::stringstream ss(kv["fanout"]);
+    for (size_t i = 0; i < nf; ++i) { size_t f; ss >> f; cfg.fanout.push_back(f); }
+  } else { // :164-175
+    cfg.random_walk_length = std::stoull(kv["random_walk_length"]);
+    cfg.random_walk_restart_prob = std::stod(kv["random_walk_restart_prob"]);
+    cfg.num_random_walk = std::stoull(kv["num_random_walk"]);
+    cfg.num_neighbor = std::stoull(kv["num_neighbor"]);
+    cfg.fanout.assign(cfg.num_layer, cfg.num_neighbor);
+  }
+  if (kv.count("use_dist_graph")) { // :191-203
+    cfg.dist_graph_percentage = std::stod(kv["use_dist_graph"]);
+    cfg.use_dist_graph = cfg.dist_graph_percentage > 0.0;
+  }
+  if (kv.count("part_cache") && kv["part_cache"] == "True") { // :205-211
+    SAM_CHECK(cfg.arch == kArch6, "partition cache can only be used in arch6");
+    cfg.part_cache = true;
+  }
+  if (kv.count("gpu_extract") && kv["gpu_extract"] == "True") cfg.gpu_extract = (cfg.arch == kArch6); // :229-235
+  if (kv.count("seed")) { cfg.has_seed = true; cfg.seed = std::stoull(kv["seed"]); }
+  if (kv.count("hash_table")) cfg.direct_table = kv["hash_table"] != "hashed";
+  SAM_CHECK(cfg.sample_type == GGMS_KHOP3 || cfg.sample_type == GGMS_KHOP0,
+            "sample types built so far: khop0, khop3 (DESIGN.md)");
+  cfg.configured = true;
+}
+
+// ------------------------------------------------------------------ dataset
+HostArray Engine::MapFile(const std::string &name, size_t bytes, bool to_shared_anon) {
+  HostArray a;
+  a.bytes = bytes;
+  const std::string path = cfg.dataset_path + name;
+  int fd = open(path.c_str(), O_RDONLY);
+  SAM_CHECK(fd >= 0, "cannot open " + path);
+  struct stat st;
+  fstat(fd, &st);
+  SAM_CHECK((size_t)st.st_size >= bytes, path + " is smaller than meta.txt says");
+  void *m = bytes ? mmap(nullptr, bytes, PROT_READ, MAP_PRIVATE, fd, 0) : nullptr; // Tensor::FromMmap
+  SAM_CHECK(bytes == 0 || m != MAP_FAILED, "mmap failed for " + path);
+  close(fd);
+  if (to_shared_anon && bytes) {
+    // ConverToAnonMmap, engine.cc:91-107: workers forked later share one locked copy
+    void *s = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED | MAP_ANONYMOUS, -1, 0);
+    SAM_CHECK(s != MAP_FAILED, "anonymous shared mmap failed");
+    std::memcpy(s, m, bytes);
+    munmap(m, bytes);
+    a.ptr = s;
+    a.shared_anon = true;
+  } else {
+    a.ptr = m;
+    a.mapped_file = true;
+  }
+  return a;
+}
+
+static bool file_exists(const std::string &p) { struct stat st; return stat(p.c_str(), &st) == 0; }
+
+void Engine::LoadDataset() {
+  if (cfg.dataset_path.back() != '/') cfg.dataset_path.push_back('/');
+  // meta.txt, engine.cc:126-142; names constant.cc:23-51
+  std::ifstream meta_file(cfg.dataset_path + "meta.txt");
+  SAM_CHECK(meta_file.good(), "cannot read " + cfg.dataset_path + "meta.txt");
+  std::unordered_map<std::string, size_t> meta;
+  std::string line;
+  while (std::getline(meta_file, line)) {
+    std::istringstream iss(line);
+    std::string k, v;
+    if (!(iss >> k >> v)) break;
+    if (k == "FEAT_DATA_TYPE") {
+      static const std::map<std::string, int> names = {{"F32", GGMS_F32}, {"F64", GGMS_F64}, {"F16", GGMS_F16},
+                                                       {"U8", GGMS_U8},   {"I32", GGMS_I32}, {"I8", GGMS_I8},
+                                                       {"I64", GGMS_I64}};
+      SAM_CHECK(names.count(v), "unknown FEAT_DATA_TYPE " + v);
+      ds.feat_dtype = names.at(v);
+    } else {
+      meta[k] = std::stoull(v);
+    }
+  }
+  for (const char *k : {"NUM_NODE", "NUM_EDGE", "FEAT_DIM", "NUM_CLASS", "NUM_TRAIN_SET", "NUM_TEST_SET", "NUM_VALID_SET"})
+    SAM_CHECK(meta.count(k), std::string("meta.txt lacks ") + k);
+  ds.num_node = meta["NUM_NODE"]; ds.num_edge = meta["NUM_EDGE"]; ds.feat_dim = meta["FEAT_DIM"];
+  ds.num_class = meta["NUM_CLASS"]; ds.num_train = meta["NUM_TRAIN_SET"]; ds.num_test = meta["NUM_TEST_SET"];
+  ds.num_valid = meta["NUM_VALID_SET"];
+  const bool share = cfg.arch == kArch6; // forked workers read the same pages
+  ds.indptr = MapFile("indptr.bin", (ds.num_node + 1) * 4, share);
+  ds.indices = MapFile("indices.bin", ds.num_edge * 4, share);
+  const size_t row_bytes = ds.feat_dim * ggms_dtype_bytes(ds.feat_dtype);
+  if (file_exists(cfg.dataset_path + "feat.bin")) {
+    ds.feat = MapFile("feat.bin", ds.num_node * row_bytes, share);
+  } else { // engine.cc:199-235: datasets without feat.bin get an (uninitialised) table; ours is zero-filled
+    ds.feat.bytes = ds.num_node * row_bytes;
+    ds.feat.ptr = mmap(nullptr, ds.feat.bytes, PROT_READ | PROT_WRITE, MAP_SHARED | MAP_ANONYMOUS, -1, 0);
+    SAM_CHECK(ds.feat.ptr != MAP_FAILED, "feature mmap failed");
+    ds.feat.shared_anon = true;
+    ds.feat_is_fake = true;
+  }
+  if (file_exists(cfg.dataset_path + "label.bin")) {
+    ds.label = MapFile("label.bin", ds.num_node * 8, share);
+  } else {
+    ds.label.bytes = ds.num_node * 8;
+    ds.label.ptr = mmap(nullptr, ds.label.bytes, PROT_READ | PROT_WRITE, MAP_SHARED | MAP_ANONYMOUS, -1, 0);
+    ds.label.shared_anon = true;
+  }
+  ds.train_set = MapFile("train_set.bin", ds.num_train * 4, false);
+  ds.test_set = MapFile("test_set.bin", ds.num_test * 4, false);
+  ds.valid_set = MapFile("valid_set.bin", ds.num_valid * 4, false);
+  if (cfg.UseGPUCache()) { // engine.cc:395-440
+    static const char *rank_files[] = {"cache_by_degree.bin", "cache_by_heuristic.bin", nullptr, "cache_by_degree_hop.bin",
+                                       nullptr, "cache_by_fake_optimal.bin", nullptr, "cache_by_random.bin"};
+    SAM_CHECK(cfg.cache_policy >= 0 && cfg.cache_policy < 8 && rank_files[cfg.cache_policy],
+              "cache policy not built (presample / dynamic): see DESIGN.md");
+    ds.ranking_nodes = MapFile(rank_files[cfg.cache_policy], ds.num_node * 4, false);
+  }
+}
+
+void Engine::DataInit() {
+  SAM_CHECK(cfg.configured, "samgraph_config first");
+  if (data_ready_) return;
+  auto t0 = std::chrono::steady_clock::now();
+  LoadDataset();
+  if (cfg.arch == kArch6) {
+    shared_ = (Shared *)mmap(nullptr, sizeof(Shared), PROT_READ | PROT_WRITE, MAP_SHARED | MAP_ANONYMOUS, -1, 0);
+    SAM_CHECK(shared_ != MAP_FAILED, "control block mmap failed");
+    SAM_CHECK(cfg.num_worker <= (size_t)Shared::kMaxWorker, "too many workers");
+    pthread_barrierattr_t attr;
+    pthread_barrierattr_init(&attr);
+    pthread_barrierattr_setpshared(&attr, PTHREAD_PROCESS_SHARED);
+    pthread_barrier_init(&shared_->barrier, &attr, (unsigned)cfg.num_worker);
+    shared_->num_worker = (int)cfg.num_worker;
+  }
+  prof.LogInit(/*kLogInitL2LoadDataset*/ 6, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+  data_ready_ = true;
+}
+
+void Engine::Barrier() {
+  if (shared_ && cfg.num_worker > 1) pthread_barrier_wait(&shared_->barrier);
+}
+
+// ------------------------------------------------------------------ shuffler
+// GPUShuffler (cuda/cuda_shuffler.cc:38-160) for one worker, DistAlignedShuffler
+// (dist/dist_shuffler_aligned.cc:37-146) for arch6: same Fisher-Yates with
+// std::default_random_engine(seed) + uniform_int_distribution<size_t>(i, n-1).
+void Engine::ShufflerInit() {
+  const uint32_t *train = (const uint32_t *)ds.train_set.ptr;
+  const size_t nw = cfg.arch == kArch6 ? cfg.num_worker : 1;
+  const size_t origin = ds.num_train;
+  num_data_ = (origin + nw - 1) / nw * nw; // aligned to num_worker (:46)
+  shuf_host_.assign(train, train + origin);
+  for (size_t i = 0; i < num_data_ - origin; ++i) shuf_host_.push_back(train[i]); // :52-54
+  num_local_data_ = num_data_ / nw;
+  num_local_step_ = (num_local_data_ + cfg.batch_size - 1) / cfg.batch_size;
+  num_global_step_ = num_local_step_ * nw;
+  global_step_offset_ = num_local_step_ * worker_id_;
+  global_data_offset_ = num_local_data_ * worker_id_;
+  cur_epoch_ = 0;
+  cur_step_ = num_local_step_;
+  shuf_initialized_ = false;
+  SAM_HIP(hipMalloc((void **)&shuf_dev_, std::max<size_t>(1, num_local_data_) * 4));
+}
+
+void Engine::Reshuffle() {
+  if (!shuf_initialized_) { cur_epoch_ = 0; shuf_initialized_ = true; } else { cur_epoch_++; }
+  cur_step_ = 0;
+  if (cur_epoch_ >= cfg.num_epoch) return;
+  uint64_t seed;
+  if (cfg.arch == kArch6) seed = cur_epoch_;   // all samplers share the permutation (:92-94)
+  else if (cfg.has_seed) seed = cfg.seed + cur_epoch_;
+  else seed = std::chrono::system_clock::now().time_since_epoch().count(); // cuda_shuffler.cc:89
+  auto g = std::default_random_engine(seed);
+  uint32_t *data = shuf_host_.data();
+  for (size_t i = 0; num_data_ && i < num_data_ - 1; i++) {
+    std::uniform_int_distribution<size_t> d(i, num_data_ - 1);
+    std::swap(data[i], data[d(g)]);
+  }
+  SAM_HIP(hipMemcpyAsync(shuf_dev_, data + global_data_offset_, num_local_data_ * 4, hipMemcpyHostToDevice, stream_));
+  SAM_HIP(hipStreamSynchronize(stream_));
+}
+
+bool Engine::ShufflerNext(Batch *b) {
+  cur_step_++;
+  if (cur_step_ >= num_local_step_) Reshuffle();
+  if (cur_epoch_ >= cfg.num_epoch) return false;
+  const size_t offset = cur_step_ * cfg.batch_size;
+  SAM_CHECK(offset < num_local_data_, "shuffler offset out of range");
+  size_t size = (offset + cfg.batch_size > num_local_data_) ? (num_local_data_ - offset) : cfg.batch_size;
+  if (cfg.arch == kArch6 && cur_epoch_ == 0 && cur_step_ == 0) { // first batch x1.25, :137-140
+    size = (size_t)(size * 1.25);
+    size = (offset + size > num_local_data_) ? (num_local_data_ - offset) : size;
+  }
+  b->num_seeds = size;
+  b->key = BatchKey(cur_epoch_, global_step_offset_ + cur_step_);
+  SAM_HIP(hipMemcpyAsync(b->output_nodes, shuf_dev_ + offset, size * 4, hipMemcpyDeviceToDevice, stream_)); // Copy1D
+  return true;
+}
+
+// ------------------------------------------------------------------ device graph (GGMS topology)
+static void *dev_upload(const void *host, size_t bytes, hipStream_t s) {
+  void *d = nullptr;
+  SAM_HIP(hipMalloc(&d, std::max<size_t>(bytes, 16)));
+  if (bytes) SAM_HIP(hipMemcpyAsync(d, host, bytes, hipMemcpyHostToDevice, s));
+  return d;
+}
+
+static const void *map_host(void *host, size_t bytes) {
+  // cudaHostRegister(..., ReadOnly) + zero-copy reads (dist_engine.cc:217-241)
+  if (bytes == 0) return nullptr;
+  SAM_HIP(hipHostRegister(host, bytes, hipHostRegisterMapped));
+  void *d = nullptr;
+  SAM_HIP(hipHostGetDevicePointer(&d, host, 0));
+  return d;
+}
+
+void Engine::UploadGraph() {
+  const uint32_t *indptr = (const uint32_t *)ds.indptr.ptr, *indices = (const uint32_t *)ds.indices.ptr;
+  std::memset(&graph_, 0, sizeof(graph_));
+  graph_.num_node = (uint32_t)ds.num_node;
+  if (!cfg.use_dist_graph) { // dist_engine.cc:203-216 / cuda_engine: whole CSR on this GPU
+    d_indptr_ = (uint32_t *)dev_upload(indptr, ds.indptr.bytes, stream_);
+    d_indices_ = (uint32_t *)dev_upload(indices, ds.indices.bytes, stream_);
+    graph_.indptr = d_indptr_;
+    graph_.indices = d_indices_;
+    SAM_HIP(hipStreamSynchronize(stream_));
+    return;
+  }
+  // DistGraph::GraphLoad, cuda/dist_graph.cu:309-385
+  const uint32_t P = (uint32_t)cfg.num_worker, p = (uint32_t)worker_id_;
+  const uint32_t num_cache_edge = (uint32_t)(ds.num_edge * cfg.dist_graph_percentage); // dist_engine.cc:225
+  uint32_t num_cache_node = 0;
+  while (num_cache_node < ds.num_node && indptr[num_cache_node] < num_cache_edge) ++num_cache_node;
+  // _DatasetPartition :228-272: shard p = nodes v == p (mod P), v < num_cache_node
+  const size_t isz = num_cache_node / P + (p < num_cache_node % P ? 1 : 0) + 1;
+  std::vector<uint32_t> pip(isz);
+  size_t ecount = 0;
+  for (uint32_t v = p; v < num_cache_node; v += P) ecount += indptr[v + 1] - indptr[v];
+  std::vector<uint32_t> pix(std::max<size_t>(ecount, 1));
+  uint32_t cnt = 0;
+  for (uint32_t v = p; v < num_cache_node; v += P) {
+    const uint32_t ne = indptr[v + 1] - indptr[v];
+    pip[v / P] = cnt;
+    std::memcpy(&pix[cnt], &indices[indptr[v]], ne * 4ull);
+    cnt += ne;
+  }
+  pip[isz - 1] = cnt;
+  part_indptr_.assign(P + 1, nullptr);
+  part_indices_.assign(P + 1, nullptr);
+  part_indptr_[p] = dev_upload(pip.data(), isz * 4, stream_);
+  part_indices_[p] = dev_upload(pix.data(), ecount * 4, stream_);
+  SAM_HIP(hipStreamSynchronize(stream_));
+  // _DataIpcShare :274-307: publish, barrier, open peers, barrier
+  if (P > 1) {
+    SAM_HIP(hipIpcGetMemHandle(&shared_->graph_indptr[p], part_indptr_[p]));
+    SAM_HIP(hipIpcGetMemHandle(&shared_->graph_indices[p], part_indices_[p]));
+    Barrier();
+    for (uint32_t q = 0; q < P; ++q) {
+      if (q == p) continue;
+      SAM_HIP(hipIpcOpenMemHandle(&part_indptr_[q], shared_->graph_indptr[q], hipIpcMemLazyEnablePeerAccess));
+      SAM_HIP(hipIpcOpenMemHandle(&part_indices_[q], shared_->graph_indices[q], hipIpcMemLazyEnablePeerAccess));
+    }
+    Barrier();
+  }
+  // slot P: the whole CSR in (device-mapped) host memory, :367-381
+  part_indptr_[P] = (void *)map_host(ds.indptr.ptr, ds.indptr.bytes);
+  part_indices_[P] = (void *)map_host(ds.indices.ptr, ds.indices.bytes);
+  d_part_indptr_tab_ = dev_upload(part_indptr_.data(), (P + 1) * sizeof(void *), stream_);
+  d_part_indices_tab_ = dev_upload(part_indices_.data(), (P + 1) * sizeof(void *), stream_);
+  SAM_HIP(hipStreamSynchronize(stream_));
+  graph_.part_indptr = (const ggms_id_t *const *)d_part_indptr_tab_;
+  graph_.part_indices = (const ggms_id_t *const *)d_part_indices_tab_;
+  graph_.num_part = P;
+  graph_.num_cache_node = num_cache_node;
+}
+
+// ------------------------------------------------------------------ init
+void Engine::SampleInit(int worker_id, const std::string &ctx) {
+  SAM_CHECK(data_ready_, "samgraph_data_init first");
+  worker_id_ = worker_id;
+  device_ = parse_device(ctx);
+  SAM_HIP(hipSetDevice(device_));
+  SAM_HIP(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+  UploadGraph();
+  ShufflerInit();
+  const uint32_t L = (uint32_t)cfg.fanout.size();
+  // first batch of arch6 is x1.25 (dist_shuffler_aligned.cc:137-140): size every buffer for it
+  max_seeds_ = (size_t)(cfg.batch_size * 1.25) + 1;
+  max_input_.resize(L);
+  max_edges_.resize(L);
+  SAM_GGMS(ggms_sample_batch_capacity(max_seeds_, cfg.fanout.data(), L, max_input_.data(), max_edges_.data(), &max_unique_));
+  // OrderedHashTable(PredictNumNodes(...)) dist_engine.cc:423-424; direct layout by default
+  std::memset(&ht_, 0, sizeof(ht_));
+  ht_.direct = cfg.direct_table ? 1 : 0;
+  ht_.o2n_size = cfg.direct_table ? ds.num_node : ggms_hashtable_num_buckets(max_unique_);
+  ht_.n2o_size = max_unique_;
+  SAM_HIP(hipMalloc(&ht_.o2n, ht_.o2n_size * (cfg.direct_table ? 8 : 16)));
+  SAM_HIP(hipMalloc((void **)&ht_.n2o, max_unique_ * 4));
+  SAM_HIP(hipMalloc((void **)&ht_.num_items_dev, 16));
+  SAM_GGMS(ggms_hashtable_init(&ht_, stream_));
+  // GPURandomStates dist_engine.cc:432-433; seed = wall clock unless the "seed" key is given
+  num_states_ = ggms_random_states_count(cfg.sample_type, cfg.fanout.data(), L, max_seeds_, cfg.num_random_walk);
+  size_t max_in = 0;
+  for (auto v : max_input_) max_in = std::max(max_in, v);
+  num_states_ = std::max(num_states_, (max_in + 127) / 128 * 8);
+  SAM_HIP(hipMalloc(&states_, num_states_ * GGMS_RNG_STATE_BYTES));
+  const uint64_t seed = cfg.has_seed ? cfg.seed + 1000003ull * worker_id
+                                     : (uint64_t)std::chrono::system_clock::now().time_since_epoch().count();
+  SAM_GGMS(ggms_random_states_init(states_, num_states_, seed, stream_));
+  ws_bytes_ = ggms_sample_batch_workspace_bytes(max_seeds_, cfg.fanout.data(), L);
+  SAM_HIP(hipMalloc(&ws_, ws_bytes_));
+  SAM_HIP(hipStreamSynchronize(stream_));
+  prof.Resize(cfg.num_epoch, num_global_step_);
+  sample_ready_ = true;
+}
+
+void Engine::BuildCache() {
+  const size_t row_bytes = ds.feat_dim * ggms_dtype_bytes(ds.feat_dtype);
+  const char *feat = (const char *)ds.feat.ptr;
+  // labels are 8 B x N: always resident on the device (the reference keeps them on the host and
+  // gathers through zero-copy in gpu_extract mode, dist_loops.cc:938-974)
+  label_src_ = dev_upload(ds.label.ptr, ds.label.bytes, stream_);
+  if (!cfg.UseGPUCache()) {
+    if (cfg.arch == kArch1 || !cfg.gpu_extract) {
+      // arch1: the whole table lives in HBM and is gathered directly (cuda_loops_arch1.cc:61)
+      d_feat_ = dev_upload(feat, ds.feat.bytes, stream_);
+      feat_src_ = d_feat_;
+    } else {
+      feat_src_ = map_host(ds.feat.ptr, ds.feat.bytes); // cache 0 %: DoGPUFeatureExtract from host, dist_loops.cc:585-634
+    }
+    SAM_HIP(hipStreamSynchronize(stream_));
+    return;
+  }
+  // GPUCacheManager ctor: cuda_cache_manager_host.cc:61-130 (replicated) / :133-254 (partition)
+  const uint32_t *rank_in = (const uint32_t *)ds.ranking_nodes.ptr;
+  num_cached_nodes_ = (size_t)(ds.num_node * cfg.cache_percentage);
+  std::vector<uint32_t> rank(rank_in, rank_in + ds.num_node);
+  const uint32_t P = cfg.part_cache ? (uint32_t)cfg.num_worker : 1, p = cfg.part_cache ? (uint32_t)worker_id_ : 0;
+  if (cfg.part_cache) { // load balance across shards: :169-171
+    std::mt19937 eg((uint32_t)num_cached_nodes_);
+    std::shuffle(rank.begin(), rank.begin() + num_cached_nodes_, eg);
+  }
+  std::vector<uint32_t> table(ds.num_node, GGMS_EMPTY_KEY);
+  for (size_t i = 0; i < num_cached_nodes_; ++i) table[rank[i]] = (uint32_t)i; // :197-229
+  cache_table_ = (uint32_t *)dev_upload(table.data(), ds.num_node * 4, stream_);
+  // DistGraph::FeatureLoad / _PartitionFeature, dist_graph.cu:493-521: rows rank[i], i == p (mod P)
+  const size_t my_rows = num_cached_nodes_ / P + (p < num_cached_nodes_ % P ? 1 : 0);
+  std::vector<char> tmp(std::max<size_t>(my_rows * row_bytes, 16));
+  size_t c = 0;
+  for (size_t i = p; i < num_cached_nodes_; i += P, ++c) std::memcpy(&tmp[c * row_bytes], feat + (size_t)rank[i] * row_bytes, row_bytes);
+  cache_parts_.assign(P, nullptr);
+  cache_parts_[p] = dev_upload(tmp.data(), my_rows * row_bytes, stream_);
+  SAM_HIP(hipStreamSynchronize(stream_));
+  if (P > 1) { // _DataIpcShare
+    SAM_HIP(hipIpcGetMemHandle(&shared_->feat_part[p], cache_parts_[p]));
+    Barrier();
+    for (uint32_t q = 0; q < P; ++q)
+      if (q != p) SAM_HIP(hipIpcOpenMemHandle(&cache_parts_[q], shared_->feat_part[q], hipIpcMemLazyEnablePeerAccess));
+    Barrier();
+  }
+  d_cache_parts_tab_ = dev_upload(cache_parts_.data(), P * sizeof(void *), stream_);
+  num_cache_part_ = cfg.part_cache ? P : 0;
+  // miss tier: pinned host memory read by the gather kernel itself (GPUExtractMissData, :573-625)
+  feat_src_ = map_host(ds.feat.ptr, ds.feat.bytes);
+  SAM_HIP(hipStreamSynchronize(stream_));
+}
+
+void Engine::TrainInit(int worker_id, const std::string &ctx) {
+  SAM_CHECK(sample_ready_, "samgraph_sample_init first");
+  SAM_CHECK(parse_device(ctx) == device_, "arch6: sampler and trainer share the GPU (cuda_cache_manager_host.cc:152-155)");
+  (void)worker_id;
+  SAM_HIP(hipSetDevice(device_));
+  auto t0 = std::chrono::steady_clock::now();
+  BuildCache();
+  prof.LogInit(/*kLogInitL2BuildCache*/ 10, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+  // batch slots (GraphPool(max_copying_jobs), cuda_engine.cc:151): buffers sized once at their bounds
+  const uint32_t L = (uint32_t)cfg.fanout.size();
+  const size_t row_bytes = ds.feat_dim * ggms_dtype_bytes(ds.feat_dtype);
+  size_t nslots = 2;
+  if (cfg.raw.count("max_copying_jobs")) nslots = std::max<size_t>(2, std::min<size_t>(4, std::stoull(cfg.raw["max_copying_jobs"]) + 1));
+  for (size_t s = 0; s < nslots; ++s) {
+    auto b = std::make_unique<Batch>();
+    b->slot = (int)s;
+    b->row.resize(L); b->col.resize(L); b->data.resize(L, nullptr);
+    for (uint32_t i = 0; i < L; ++i) {
+      SAM_HIP(hipMalloc((void **)&b->row[i], std::max<size_t>(max_edges_[i], 4) * 4));
+      SAM_HIP(hipMalloc((void **)&b->col[i], std::max<size_t>(max_edges_[i], 4) * 4));
+    }
+    SAM_HIP(hipMalloc((void **)&b->input_nodes, max_unique_ * 4));
+    SAM_HIP(hipMalloc((void **)&b->output_nodes, max_seeds_ * 4));
+    SAM_HIP(hipMalloc(&b->feat, max_unique_ * row_bytes));
+    SAM_HIP(hipMalloc((void **)&b->label, max_seeds_ * 8));
+    SAM_HIP(hipMalloc((void **)&b->counts_dev, (3 * L + 4) * 8));
+    SAM_HIP(hipMemset(b->counts_dev, 0, (3 * L + 4) * 8));
+    SAM_HIP(hipHostMalloc((void **)&b->counts, (3 * L + 4) * 8));
+    std::memset(b->counts, 0, (3 * L + 4) * 8);
+    SAM_HIP(hipEventCreate(&b->ev_start));
+    SAM_HIP(hipEventCreate(&b->ev_sampled));
+    SAM_HIP(hipEventCreate(&b->ev_done));
+    slots_.push_back(std::move(b));
+  }
+  train_ready_ = true;
+}
+
+void Engine::Init() { // samgraph_init, single process
+  DataInit();
+  const std::string ctx = "cuda:" + std::to_string(cfg.sampler_device);
+  SampleInit(0, ctx);
+  TrainInit(0, "cuda:" + std::to_string(cfg.trainer_device));
+}
+
+void Engine::Start() {}
+
+void Engine::Shutdown() {
+  shutdown_ = true;
+  bg_stop_ = true;
+  pool_cv_.notify_all();
+  if (bg_.joinable()) bg_.join();
+  if (stream_) (void)hipStreamSynchronize(stream_);
+}
+
+// ------------------------------------------------------------------ hot loop
+Batch *Engine::AcquireSlot() {
+  for (;;) {
+    {
+      std::lock_guard<std::mutex> lk(pool_mu_);
+      for (auto &b : slots_)
+        if (!b->in_use && b->refs.load() == 0) { b->in_use = true; return b.get(); }
+    }
+    if (bg_stop_) return nullptr;
+    // GraphPool full (cuda_loops_arch1.cc:45-48): the foreground call returns without sampling,
+    // the background thread backs off and retries
+    if (!bg_.joinable()) return nullptr;
+    std::this_thread::sleep_for(std::chrono::microseconds(20));
+  }
+}
+
+// RunArch1LoopsOnce (cuda/cuda_loops_arch1.cc:43-86) / RunArch6LoopsOnce (dist/dist_loops_arch6.cc:236-243):
+// shuffle -> sample -> extract, all enqueued on one stream with no host round trip
+void Engine::RunSampleOnce() {
+  SAM_CHECK(train_ready_, "engine not initialised");
+  SAM_HIP(hipSetDevice(device_));
+  Batch *b = AcquireSlot();
+  if (!b) return;
+  if (!ShufflerNext(b)) { // training finished
+    std::lock_guard<std::mutex> lk(pool_mu_);
+    b->in_use = false;
+    return;
+  }
+  const uint32_t L = (uint32_t)cfg.fanout.size();
+  SAM_HIP(hipEventRecord(b->ev_start, stream_));
+  SAM_GGMS(ggms_sample_batch(cfg.sample_type, &graph_, b->output_nodes, b->num_seeds, cfg.fanout.data(), L, &ht_,
+                             states_, num_states_, b->row.data(), b->col.data(), b->counts_dev, ws_, ws_bytes_, stream_));
+  SAM_HIP(hipEventRecord(b->ev_sampled, stream_));
+  uint64_t *n_in = b->counts_dev + 3 * L, *n_miss = b->counts_dev + 3 * L + 1;
+  SAM_HIP(hipMemsetAsync(n_miss, 0, 8, stream_));
+  // input nodes = the table's unique list (task->input_nodes, dist_loops.cc:357); it is overwritten by the
+  // next batch, so the slot keeps its own copy
+  SAM_GGMS(ggms_gather_scatter(b->input_nodes, ht_.n2o, nullptr, nullptr, max_unique_, n_in, 1, GGMS_I32, stream_));
+  if (cfg.UseGPUCache()) {
+    // DoArch6GetCacheMissIndex + DoArch6GPUCacheFeatureCopy (dist_loops.cc:1015-1285) in one pass
+    SAM_GGMS(ggms_extract_cached(b->feat, ht_.n2o, max_unique_, n_in, cache_table_, (const void *const *)d_cache_parts_tab_,
+                                 num_cache_part_, feat_src_, ds.feat_dim, ds.feat_dtype, n_miss, stream_));
+  } else {
+    // DoGPUFeatureExtract (cuda/cuda_loops.cc, dist_loops.cc:585-634)
+    SAM_GGMS(ggms_gather_scatter(b->feat, feat_src_, ht_.n2o, nullptr, max_unique_, n_in, ds.feat_dim, ds.feat_dtype, stream_));
+  }
+  // DoGPULabelExtract, dist_loops.cc:938-974
+  SAM_GGMS(ggms_extract(b->label, label_src_, b->output_nodes, b->num_seeds, 1, GGMS_I64, stream_));
+  SAM_HIP(hipMemcpyAsync(b->counts, b->counts_dev, (3 * L + 4) * 8, hipMemcpyDeviceToHost, stream_));
+  SAM_HIP(hipEventRecord(b->ev_done, stream_));
+  {
+    std::lock_guard<std::mutex> lk(pool_mu_);
+    pool_.push_back(b); // graph_pool->Submit
+  }
+  pool_cv_.notify_all();
+}
+
+// block until the batch is complete, publish sizes, log the items the scripts read
+void Engine::Finish(Batch *b) {
+  SAM_HIP(hipEventSynchronize(b->ev_done));
+  const uint32_t L = (uint32_t)cfg.fanout.size();
+  b->num_input = b->counts[3 * L];
+  b->num_miss = b->counts[3 * L + 1];
+  float ms_sample = 0, ms_copy = 0;
+  (void)hipEventElapsedTime(&ms_sample, b->ev_start, b->ev_sampled);
+  (void)hipEventElapsedTime(&ms_copy, b->ev_sampled, b->ev_done);
+  uint64_t edges = 0;
+  for (uint32_t i = 0; i < L; ++i) edges += b->counts[3 * i];
+  const double row_bytes = (double)ds.feat_dim * ggms_dtype_bytes(ds.feat_dtype);
+  // item codes: profiler.h:58-140 (kLogL1NumSample = 0, kLogL1NumNode = 1, kLogL1SampleTime = 3,
+  // kLogL1CopyTime = 6, kLogL1FeatureBytes = 9, kLogL1MissBytes = 13; epoch items :119-137)
+  prof.LogStep(b->key, 0, (double)edges);
+  prof.LogStep(b->key, 1, (double)b->num_input);
+  prof.LogStep(b->key, 3, ms_sample * 1e-3);
+  prof.LogStep(b->key, 6, ms_copy * 1e-3);
+  prof.LogStep(b->key, 9, b->num_input * row_bytes);
+  prof.LogStep(b->key, 13, b->num_miss * row_bytes);
+  prof.LogEpochAdd(b->key, 0 /*kLogEpochSampleTime*/, ms_sample * 1e-3);
+  prof.LogEpochAdd(b->key, 8 /*kLogEpochCopyTime*/, ms_copy * 1e-3);
+  prof.LogEpochAdd(b->key, 12 /*kLogEpochFeatureBytes*/, b->num_input * row_bytes);
+  prof.LogEpochAdd(b->key, 13 /*kLogEpochMissBytes*/, b->num_miss * row_bytes);
+  prof.LogEpochAdd(b->key, 15 /*kLogEpochNumSample*/, (double)edges);
+}
+
+uint64_t Engine::GetNextBatch() { // operation.cc:366-378 + GraphPool::GetGraphBatch graph_pool.cc:31-49
+  if (current_) {
+    std::lock_guard<std::mutex> lk(pool_mu_);
+    current_->in_use = false; // the engine drops its own reference to the previous batch (:370)
+    current_ = nullptr;
+  }
+  Batch *b = nullptr;
+  {
+    std::unique_lock<std::mutex> lk(pool_mu_);
+    if (pool_.empty() && !bg_.joinable())
+      fatal(__FILE__, __LINE__, "get_next_batch with nothing sampled: call sample_once() or extract_start() first");
+    pool_cv_.wait(lk, [&] { return !pool_.empty() || bg_stop_.load(); });
+    if (pool_.empty()) fatal(__FILE__, __LINE__, "engine shut down while waiting for a batch");
+    b = pool_.front();
+    pool_.pop_front();
+  }
+  Finish(b);
+  current_ = b;
+  return b->key;
+}
+
+void Engine::ExtractStart(int count) { // dist_engine.cc StartExtract: one background sample+extract thread
+  (void)count;
+  SAM_CHECK(!bg_.joinable(), "extract thread already running");
+  bg_ = std::thread([this] {
+    SAM_HIP(hipSetDevice(device_));
+    while (!bg_stop_) {
+      const size_t before_epoch = cur_epoch_;
+      RunSampleOnce();
+      if (cur_epoch_ >= cfg.num_epoch && before_epoch >= cfg.num_epoch) break;
+      if (cur_epoch_ >= cfg.num_epoch) break;
+    }
+  });
+}
+
+Batch *Engine::Current(uint64_t key) {
+  SAM_CHECK(current_ != nullptr, "no current batch");
+  SAM_CHECK(current_->key == key, "key is not the current batch key (adapter.cc:68)");
+  return current_;
+}
+
+void Engine::Retain(uint64_t key) { Current(key)->refs.fetch_add(1); }
+
+void Engine::Release(uint64_t key) {
+  for (auto &b : slots_)
+    if (b->key == key && b->refs.load() > 0) { b->refs.fetch_sub(1); return; }
+}
+
+} // namespace sam

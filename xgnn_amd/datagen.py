@@ -56,3 +56,37 @@ def degree_rank(indptr):
     """cache_by_degree.bin equivalent: node ids by descending in-degree (stable)."""
     deg = (indptr[1:].astype(np.int64) - indptr[:-1].astype(np.int64))
     return np.argsort(-deg, kind="stable").astype(np.uint32)
+
+
+def write_dataset(path, graph, feat=None, label=None, valid_frac=0.02, test_frac=0.05, feat_dtype="F32"):
+    """Write a dataset directory in the reference's on-disk format (datagen/README.md:37-51,
+    samgraph/common/constant.cc:23-51, engine.cc:109-443): meta.txt (tab separated) + raw little-endian
+    arrays: indptr/indices/train_set/test_set/valid_set/cache_by_* uint32, feat row-major, label int64."""
+    import os
+    os.makedirs(path, exist_ok=True)
+    ip, ix, train, meta = graph["indptr"], graph["indices"], graph["train_set"], graph["meta"]
+    n = ip.size - 1
+    rng = np.random.RandomState(7)
+    rest = np.setdiff1d(np.arange(n, dtype=np.uint32), train, assume_unique=False)
+    rng.shuffle(rest)
+    nv, nt = int(n * valid_frac), int(n * test_frac)
+    valid, test = rest[:nv].astype(np.uint32), rest[nv:nv + nt].astype(np.uint32)
+    ip.astype(np.uint32).tofile(os.path.join(path, "indptr.bin"))
+    ix.astype(np.uint32).tofile(os.path.join(path, "indices.bin"))
+    train.astype(np.uint32).tofile(os.path.join(path, "train_set.bin"))
+    valid.tofile(os.path.join(path, "valid_set.bin"))
+    test.tofile(os.path.join(path, "test_set.bin"))
+    if feat is not None:
+        np.ascontiguousarray(feat).tofile(os.path.join(path, "feat.bin"))
+    if label is not None:
+        np.ascontiguousarray(label, dtype=np.int64).tofile(os.path.join(path, "label.bin"))
+    degree_rank(ip).tofile(os.path.join(path, "cache_by_degree.bin"))
+    np.random.RandomState(11).permutation(n).astype(np.uint32).tofile(os.path.join(path, "cache_by_random.bin"))
+    with open(os.path.join(path, "meta.txt"), "w") as f:
+        for k, v in [("NUM_NODE", n), ("NUM_EDGE", ix.size), ("FEAT_DIM", meta["feat_dim"]),
+                     ("NUM_CLASS", meta["num_class"]), ("NUM_TRAIN_SET", train.size), ("NUM_TEST_SET", test.size),
+                     ("NUM_VALID_SET", valid.size)]:
+            f.write(f"{k}\t{v}\n")
+        if feat_dtype != "F32":
+            f.write(f"FEAT_DATA_TYPE\t{feat_dtype}\n")
+    return path
