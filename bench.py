@@ -129,7 +129,7 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     dev = torch.device("cuda", local_rank)
 
-    from xgnn_amd import datagen, ops
+    from xgnn_amd import datagen, ops, parallel
 
     fanouts = [int(x) for x in args.fanout.split(",")]
     graph = datagen.make_graph(args.preset, seed=42)
@@ -164,18 +164,15 @@ def main():
     # DistAlignedShuffler semantics (dist_shuffler_aligned.cc:37-146): pad to a multiple of world,
     # same permutation on every rank, contiguous slice per rank
     train = graph["train_set"]
-    pad = (-len(train)) % world
-    train = np.concatenate([train, train[:pad]])
-    per_rank = len(train) // world
-    steps_per_epoch = (per_rank + args.batch - 1) // args.batch
+    steps_per_epoch = parallel.steps_per_epoch(len(train), world, args.batch)
+    per_rank = len(parallel.pad_train_set(train, world)) // world
 
     epoch_cache = {}
 
     def batch_seeds(step):
         ep, ls = divmod(step, steps_per_epoch)
         if ep not in epoch_cache:
-            perm = np.random.RandomState(ep).permutation(len(train))
-            epoch_cache[ep] = to_dev(train[perm][rank * per_rank:(rank + 1) * per_rank].copy())
+            epoch_cache[ep] = to_dev(parallel.rank_slice(train, world, rank, ep))
         lo = ls * args.batch
         return epoch_cache[ep][lo:min(per_rank, lo + args.batch)]
 
@@ -239,14 +236,8 @@ def main():
 
     stats = torch.tensor([elapsed, float(edges), float(rows), t_sample_ms, t_extract_ms], dtype=torch.float64,
                          device=dev)
-    if world > 1:
-        mx = stats.clone()
-        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
-        sm = stats.clone()
-        dist.all_reduce(sm, op=dist.ReduceOp.SUM)
-        elapsed, edges_all, rows_all = mx[0].item(), sm[1].item(), sm[2].item()
-    else:
-        edges_all, rows_all = float(edges), float(rows)
+    mx, sm = parallel.reduce_stats(stats, dist if world > 1 else None)
+    elapsed, edges_all, rows_all = mx[0].item(), sm[1].item(), sm[2].item()
 
     if rank == 0:
         row_bytes = dim * 4

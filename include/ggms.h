@@ -120,6 +120,35 @@ int ggms_sample_khop0(const ggms_graph_t *graph, const ggms_id_t *input,
                       void *workspace, size_t workspace_bytes,
                       ggms_stream_t stream);
 
+/* GPUSampleWeightedKHop, cuda/cuda_sampling_weighted_khop.cu:132-238 (alias
+ * method, with replacement, stable order by src, adjacent duplicates dropped).
+ * prob_table f32[E], alias_table u32[E] hold GLOBAL node ids
+ * (utility/data-process/toolkit/weight/create_alias_table.cc:154-155).
+ * DeviceNormalGraph only, like the reference (dist/dist_loops.cc:171-172). */
+size_t ggms_sample_weighted_workspace_bytes(size_t num_input, size_t fanout);
+int ggms_sample_weighted_khop(const ggms_graph_t *graph, const float *prob_table,
+                              const ggms_id_t *alias_table,
+                              const ggms_id_t *input, size_t num_input,
+                              size_t fanout, ggms_id_t *out_src,
+                              ggms_id_t *out_dst, uint64_t *num_out_dev,
+                              void *states, size_t num_states, void *workspace,
+                              size_t workspace_bytes, ggms_stream_t stream);
+
+/* GPUSampleRandomWalk + FrequencyHashmap::GetTopK, cuda/cuda_sampling_random_walk.cu:116-165,
+ * cuda/cuda_frequency_hashmap.cu:643-841: per seed, num_walk walks of walk_length steps with restart;
+ * output = the K most visited nodes per seed (count descending, ties by first visit), seeds in input order;
+ * out_data = visit count.  out_* hold num_input * K entries.  walk_length * num_walk <= 128. */
+size_t ggms_sample_random_walk_workspace_bytes(size_t num_input, size_t walk_length,
+                                               size_t num_walk, size_t K);
+size_t ggms_random_walk_num_states(size_t num_input, size_t num_walk); /* cuda_random_states.cu:48-60 */
+int ggms_sample_random_walk(const ggms_graph_t *graph, const ggms_id_t *input,
+                            size_t num_input, size_t walk_length,
+                            double restart_prob, size_t num_walk, size_t K,
+                            ggms_id_t *out_src, ggms_id_t *out_dst,
+                            ggms_id_t *out_data, uint64_t *num_out_dev,
+                            void *states, size_t num_states, void *workspace,
+                            size_t workspace_bytes, ggms_stream_t stream);
+
 /* ---------------------------------------------------------------------------
  * Ordered hash table -- OrderedHashTable, cuda/cuda_hashtable.h:103-153,
  * cuda/cuda_hashtable.cu:699-1064.  Dedup with contiguous, prefix-stable local

@@ -176,6 +176,61 @@ def test_sample_khop0(ops, graphs, gname, n, fanout):
     np.testing.assert_array_equal(host_u32(dst, m), wdst)
 
 
+@pytest.mark.parametrize("gname,n,fanout", [("small", 1, 5), ("small", 300, 25), ("small", 0, 4), ("mid", 8000, 10),
+                                            ("mid", 20000, 25), ("mid", 5000, 3), ("mid", 40000, 15)])
+def test_sample_weighted_khop(ops, graphs, gname, n, fanout):
+    """Alias-method sampler incl. stable sort by src and adjacent-duplicate compaction; duplicated seeds too."""
+    ip, ix, g = graphs[gname]
+    N = ip.size - 1
+    rng = np.random.RandomState(n * 3 + fanout)
+    prob = rng.random_sample(ix.size).astype(np.float32)
+    alias = rng.randint(0, N, ix.size).astype(np.uint32)
+    inp = rng.randint(0, N, n).astype(np.uint32)  # with repeats: the stable sort must keep position order
+    tasks = n * fanout
+    nstates = max(256, min((min(tasks, 512 * 1024) + 255) // 256 * 256, max(tasks, 1)))
+    st_gpu = ops.random_states(nstates, 4242)
+    st_orc = oracle.random_states(nstates, 4242)
+    t_prob, t_alias = dev(prob), dev(alias)
+    for rep in range(2):
+        src, dst, num = ops.sample_weighted_khop(g, t_prob, t_alias,
+                                                 dev(inp) if n else torch.zeros(0, dtype=torch.int32, device="cuda"),
+                                                 fanout, st_gpu)
+        wsrc, wdst = oracle.sample_weighted_khop(ip, ix, prob, alias, inp, fanout, st_orc)
+        m = int(num.item())
+        assert m == wsrc.size
+        np.testing.assert_array_equal(host_u32(src, m), wsrc)
+        np.testing.assert_array_equal(host_u32(dst, m), wdst)
+        got_states = states_np(st_gpu)
+        np.testing.assert_array_equal(got_states[:, 0], st_orc["d"])
+        np.testing.assert_array_equal(got_states[:, 1:], st_orc["v"])
+
+
+@pytest.mark.parametrize("gname,n,wl,p,nw,K", [("small", 1, 3, 0.5, 4, 5), ("small", 300, 3, 0.5, 4, 5),
+                                               ("small", 0, 3, 0.5, 4, 5), ("mid", 8000, 3, 0.5, 4, 5),
+                                               ("mid", 5000, 4, 0.2, 5, 3), ("mid", 3000, 10, 0.1, 10, 20),
+                                               ("mid", 1000, 2, 0.0, 1, 1)])
+def test_sample_random_walk(ops, graphs, gname, n, wl, p, nw, K):
+    """PinSAGE neighbourhood: walks with restart + per-seed top-K by visit count (ties: first visit)."""
+    ip, ix, g = graphs[gname]
+    rng = np.random.RandomState(n + wl * 7 + nw)
+    inp = rng.randint(0, ip.size - 1, n).astype(np.uint32)
+    nstates = max(256, ops.lib().ggms_random_walk_num_states(n, nw))
+    st_gpu = ops.random_states(nstates, 777)
+    st_orc = oracle.random_states(nstates, 777)
+    for rep in range(2):
+        src, dst, data, num = ops.sample_random_walk(
+            g, dev(inp) if n else torch.zeros(0, dtype=torch.int32, device="cuda"), wl, p, nw, K, st_gpu)
+        wsrc, wdst, wdata = oracle.sample_random_walk(ip, ix, inp, wl, p, nw, K, st_orc)
+        m = int(num.item())
+        assert m == wsrc.size
+        np.testing.assert_array_equal(host_u32(src, m), wsrc)
+        np.testing.assert_array_equal(host_u32(dst, m), wdst)
+        np.testing.assert_array_equal(host_u32(data, m), wdata)
+        got_states = states_np(st_gpu)
+        np.testing.assert_array_equal(got_states[:, 0], st_orc["d"])
+        np.testing.assert_array_equal(got_states[:, 1:], st_orc["v"])
+
+
 def test_khop3_properties_full_size(ops):
     """BASELINE-sized layer (88k seeds x fanout 25): distinctness / membership / counts."""
     ip, ix = powerlaw_csr(200_000, mean_deg=40, seed=5, zero_frac=0.01)

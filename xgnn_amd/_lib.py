@@ -37,6 +37,13 @@ SYMBOLS = {
     "ggms_sample_workspace_bytes": (_sz, [_i, _sz, _sz]),
     "ggms_sample_khop3": (_i, [C.POINTER(Graph), _vp, _sz, _sz, _vp, _vp, _vp, _vp, _sz, _vp, _sz, _vp]),
     "ggms_sample_khop0": (_i, [C.POINTER(Graph), _vp, _sz, _sz, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "ggms_sample_weighted_workspace_bytes": (_sz, [_sz, _sz]),
+    "ggms_sample_weighted_khop": (_i, [C.POINTER(Graph), _vp, _vp, _vp, _sz, _sz, _vp, _vp, _vp, _vp, _sz, _vp, _sz,
+                                       _vp]),
+    "ggms_sample_random_walk_workspace_bytes": (_sz, [_sz, _sz, _sz, _sz]),
+    "ggms_random_walk_num_states": (_sz, [_sz, _sz]),
+    "ggms_sample_random_walk": (_i, [C.POINTER(Graph), _vp, _sz, _sz, C.c_double, _sz, _sz, _vp, _vp, _vp, _vp, _vp,
+                                     _sz, _vp, _sz, _vp]),
     "ggms_sample_batch_capacity": (_i, [_sz, C.POINTER(_sz), _u32, C.POINTER(_sz), C.POINTER(_sz), C.POINTER(_sz)]),
     "ggms_sample_batch_workspace_bytes": (_sz, [_sz, C.POINTER(_sz), _u32]),
     "ggms_sample_batch": (_i, [_i, C.POINTER(Graph), _vp, _sz, C.POINTER(_sz), _u32, C.POINTER(HashTable), _vp, _sz,

@@ -1,0 +1,167 @@
+// sample_weighted.hip -- weighted fan-out sampler (alias method, with replacement).
+//
+// Reference: GPUSampleWeightedKHop, cuda/cuda_sampling_weighted_khop.cu:132-238:
+//   sample_weighted_khop :41-76   task t -> seed t / fanout; k = curand % deg; r = curand_uniform;
+//                                 dst = r < prob[off+k] ? indices[off+k] : alias[off+k]
+//                                 (grid-stride over <= 512 K threads, one stored XORWOW state per thread)
+//   cub SortPairs(key = src) :172-181, count_edge / compact_edge :78-128 (drop an entry equal to its successor)
+//
+// Kept bit-for-bit: task -> thread -> RNG stream assignment (span = ceil(min(tasks, 512K) / 256) * 256),
+// two draws per task, the stable order by src, the adjacent-duplicate rule (dedup is partial by design).
+// Redesigned: the stable sort of n*fanout (src, dst) pairs by src is a stable sort of the n SEED POSITIONS
+// by their id (the fanout tasks of a position are contiguous and stay in order), i.e. fanout-times fewer
+// elements through the radix sort; the sorted, expanded stream is never materialised -- the compaction
+// pass reads it through the permutation.
+#include "ggms_internal.h"
+#include "radix_sort.h"
+
+namespace ggms {
+
+constexpr uint64_t kWeightedMaxThreads = 512 * 1024; // Constant::kWeightedKHopMaxThreads, constant.h:72
+
+__global__ __launch_bounds__(kBlock) void k_weighted_draw(const uint32_t *__restrict__ indptr,
+                                                          const uint32_t *__restrict__ indices,
+                                                          const float *__restrict__ prob,
+                                                          const uint32_t *__restrict__ alias,
+                                                          const uint32_t *__restrict__ input, Count n_arg,
+                                                          uint32_t fanout, uint32_t *__restrict__ tmp_dst,
+                                                          uint32_t *__restrict__ states) {
+  const uint64_t n = n_arg.get();
+  const uint64_t num_task = n * fanout;
+  const uint64_t threads = num_task < kWeightedMaxThreads ? num_task : kWeightedMaxThreads;
+  const uint64_t span = (threads + 255) / 256 * 256; // blockDim.x * gridDim.x of the reference launch (:156-160)
+  const uint64_t tid = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (tid >= span || tid >= num_task) return;
+  Xorwow st;
+  st.load(states + 6 * tid);
+  for (uint64_t task = tid; task < num_task; task += span) {
+    const uint32_t rid = input[task / fanout];
+    const uint32_t off = indptr[rid];
+    const uint32_t len = indptr[rid + 1] - off;
+    if (len != 0) {
+      const uint32_t k = st.next() % len;
+      const float r = st.uniform();
+      tmp_dst[task] = (r < prob[off + k]) ? indices[off + k] : alias[off + k];
+    }
+  }
+  st.store(states + 6 * tid);
+}
+
+// sort key of a seed position: its id, or kEmptyKey when it has no neighbour (tmp_src of :58-60)
+__global__ __launch_bounds__(kBlock) void k_weighted_keys(const uint32_t *__restrict__ indptr,
+                                                          const uint32_t *__restrict__ input, Count n_arg,
+                                                          uint32_t *__restrict__ keys, uint32_t *__restrict__ vals) {
+  const uint64_t n = n_arg.get();
+  for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (uint64_t)gridDim.x * kBlock) {
+    const uint32_t rid = input[i];
+    keys[i] = (indptr[rid + 1] == indptr[rid]) ? kEmptyKey : rid;
+    vals[i] = (uint32_t)i;
+  }
+}
+
+// element q of the sorted, expanded stream: rank s = q / fanout, slot j = q % fanout
+struct SortedStream {
+  const uint32_t *keys, *order, *tmp_dst;
+  uint32_t fanout;
+  Count n;
+  __device__ __forceinline__ void at(uint64_t q, uint32_t &src, uint32_t &dst, uint32_t &pos) const {
+    const uint64_t s = q / fanout, j = q - s * fanout;
+    src = keys[s];
+    pos = order[s];
+    dst = tmp_dst[(uint64_t)pos * fanout + j];
+  }
+};
+struct KeepFlag { // count_edge, :78-96
+  SortedStream ss;
+  __device__ __forceinline__ uint32_t operator()(uint64_t q) const {
+    const uint64_t total = ss.n.get() * ss.fanout;
+    if (q >= total) return 0u; // the scan runs over the upper bound n_max * fanout
+    uint32_t src, dst, pos;
+    ss.at(q, src, dst, pos);
+    if (src == kEmptyKey) return 0u;
+    if (q + 1 >= total) return 1u;
+    uint32_t nsrc, ndst, npos;
+    ss.at(q + 1, nsrc, ndst, npos);
+    return (src != nsrc || dst != ndst) ? 1u : 0u;
+  }
+};
+struct KeepEmit { // compact_edge, :98-128
+  SortedStream ss;
+  uint32_t *out_src, *out_dst;
+  const uint32_t *seed_local;
+  int src_local;
+  __device__ __forceinline__ void operator()(uint64_t q, uint32_t keep, uint32_t at) const {
+    if (!keep) return;
+    uint32_t src, dst, pos;
+    ss.at(q, src, dst, pos);
+    out_src[at] = src_local ? (seed_local ? seed_local[pos] : pos) : src;
+    out_dst[at] = dst;
+  }
+};
+
+size_t weighted_ws_words(size_t num_input, size_t fanout) {
+  return num_input * fanout + 4 * num_input + sort_scratch_words(num_input) + tile_scan_words(num_input * fanout) + 64;
+}
+
+int sample_weighted_impl(const uint32_t *indptr, const uint32_t *indices, const float *prob, const uint32_t *alias,
+                         const uint32_t *input, size_t n_max, Count n, uint32_t fanout, uint32_t *out_src,
+                         uint32_t *out_dst, uint64_t *num_out_dev, uint32_t *states, uint32_t *workspace,
+                         const uint32_t *seed_local, int src_local, hipStream_t s) {
+  uint32_t *w = workspace;
+  uint32_t *tmp_dst = w;  w += n_max * fanout;
+  uint32_t *k0 = w;       w += n_max;
+  uint32_t *v0 = w;       w += n_max;
+  uint32_t *k1 = w;       w += n_max;
+  uint32_t *v1 = w;       w += n_max;
+  uint32_t *sort_scr = w; w += sort_scratch_words(n_max);
+  uint32_t *scan_scr = w;
+  const size_t task_max = n_max * fanout;
+  const size_t threads = task_max < kWeightedMaxThreads ? task_max : (size_t)kWeightedMaxThreads;
+  hipLaunchKernelGGL(k_weighted_draw, dim3((unsigned)((threads + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, indptr,
+                     indices, prob, alias, input, n, fanout, tmp_dst, states);
+  GGMS_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_weighted_keys, dim3(grid_for(n_max, kBlock)), dim3(kBlock), 0, s, indptr, input, n, k0, v0);
+  GGMS_LAUNCH_CHECK();
+  int rc = radix_sort_pairs(k0, v0, k1, v1, n_max, n, sort_scr, s);
+  if (rc != GGMS_OK) return rc;
+  const SortedStream ss{k0, v0, tmp_dst, fanout, n};
+  // element count of the compaction = n * fanout with n possibly on the device: a Count cannot multiply,
+  // so KeepFlag bounds itself by ss.n and the scan runs over the upper bound
+  return tile_scan(KeepFlag{ss}, KeepEmit{ss, out_src, out_dst, seed_local, src_local}, task_max,
+                   count_of(task_max), scan_scr, nullptr, nullptr, num_out_dev, s);
+}
+
+} // namespace ggms
+
+using namespace ggms;
+
+extern "C" {
+
+size_t ggms_sample_weighted_workspace_bytes(size_t num_input, size_t fanout) {
+  return weighted_ws_words(num_input, fanout) * sizeof(uint32_t);
+}
+
+int ggms_sample_weighted_khop(const ggms_graph_t *graph, const float *prob_table, const ggms_id_t *alias_table,
+                              const ggms_id_t *input, size_t num_input, size_t fanout, ggms_id_t *out_src,
+                              ggms_id_t *out_dst, uint64_t *num_out_dev, void *states, size_t num_states,
+                              void *workspace, size_t workspace_bytes, ggms_stream_t stream) {
+  GGMS_CHECK_ARG(graph && num_out_dev && fanout > 0);
+  GGMS_CHECK_ARG(graph->num_part == 0); // "this algorithm not support DistGraph engine", dist_loops.cc:171-172
+  hipStream_t s = to_stream(stream);
+  if (num_input == 0) {
+    GGMS_HIP(hipMemsetAsync(num_out_dev, 0, sizeof(uint64_t), s));
+    return GGMS_OK;
+  }
+  GGMS_CHECK_ARG(prob_table && alias_table && input && out_src && out_dst && states && workspace);
+  GGMS_CHECK_ARG((uint64_t)num_input * fanout < (1ull << 32));
+  GGMS_CHECK_ARG(workspace_bytes >= ggms_sample_weighted_workspace_bytes(num_input, fanout));
+  const uint64_t tasks = (uint64_t)num_input * fanout;
+  const uint64_t threads = tasks < kWeightedMaxThreads ? tasks : kWeightedMaxThreads;
+  const uint64_t span = (threads + 255) / 256 * 256;
+  GGMS_CHECK_ARG((span < tasks ? span : tasks) <= num_states); // assert(thread_id < num_random_states), :52
+  return sample_weighted_impl(graph->indptr, graph->indices, prob_table, alias_table, input, num_input,
+                              count_of(num_input), (uint32_t)fanout, out_src, out_dst, num_out_dev, (uint32_t *)states,
+                              (uint32_t *)workspace, nullptr, 0, s);
+}
+
+} // extern "C"

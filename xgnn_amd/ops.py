@@ -110,6 +110,38 @@ def sample_khop0(graph, inp, fanout):
     return _sample("ggms_sample_khop0", KHOP0, graph, inp, fanout, None)
 
 
+def sample_weighted_khop(graph, prob_table, alias_table, inp, fanout, states):
+    """GPUSampleWeightedKHop (cuda_sampling_weighted_khop.cu:132-238)."""
+    _require_gpu(inp)
+    _i32(inp)
+    n = inp.numel()
+    dev = inp.device
+    out_src = torch.empty(max(1, n * fanout), dtype=torch.int32, device=dev)
+    out_dst = torch.empty(max(1, n * fanout), dtype=torch.int32, device=dev)
+    num_out = torch.zeros(1, dtype=torch.int64, device=dev)
+    ws = _workspace(lib().ggms_sample_weighted_workspace_bytes(n, fanout), dev)
+    check(lib().ggms_sample_weighted_khop(C.byref(graph.c), _ptr(prob_table), _ptr(alias_table), _ptr(inp), n, fanout,
+                                          _ptr(out_src), _ptr(out_dst), _ptr(num_out), _ptr(states), states.shape[0],
+                                          _ptr(ws), ws.numel() * 4, _stream()), "ggms_sample_weighted_khop")
+    return out_src, out_dst, num_out
+
+
+def sample_random_walk(graph, inp, walk_length, restart_prob, num_walk, K, states):
+    """GPUSampleRandomWalk + FrequencyHashmap::GetTopK (cuda_sampling_random_walk.cu:116-165)."""
+    _require_gpu(inp)
+    _i32(inp)
+    n = inp.numel()
+    dev = inp.device
+    outs = [torch.empty(max(1, n * K), dtype=torch.int32, device=dev) for _ in range(3)]
+    num_out = torch.zeros(1, dtype=torch.int64, device=dev)
+    ws = _workspace(lib().ggms_sample_random_walk_workspace_bytes(n, walk_length, num_walk, K), dev)
+    check(lib().ggms_sample_random_walk(C.byref(graph.c), _ptr(inp), n, walk_length, restart_prob, num_walk, K,
+                                        _ptr(outs[0]), _ptr(outs[1]), _ptr(outs[2]), _ptr(num_out), _ptr(states),
+                                        states.shape[0], _ptr(ws), ws.numel() * 4, _stream()),
+          "ggms_sample_random_walk")
+    return outs[0], outs[1], outs[2], num_out
+
+
 class OrderedHashTable:
     """OrderedHashTable (cuda_hashtable.h:103-153) over caller-owned device buffers."""
 
