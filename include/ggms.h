@@ -205,19 +205,32 @@ int ggms_map_edges(const ggms_hashtable_t *ht, const ggms_id_t *global_src,
  * pointers with the capacities ggms_sample_batch_capacity reports; fanouts is
  * a host array indexed by layer id.
  * ------------------------------------------------------------------------- */
+/* per-sample-type extras of ggms_sample_batch (NULL for khop0/khop3) */
+typedef struct {
+  const float *prob_table;        /* weighted_khop: dataset->prob_table  (engine.cc:372-384) */
+  const ggms_id_t *alias_table;   /*                dataset->alias_table                      */
+  size_t random_walk_length;      /* random_walk: RunConfig::random_walk_length ...           */
+  double random_walk_restart_prob;
+  size_t num_random_walk;
+  ggms_id_t *const *data;         /* random_walk: HOST array of L device pointers, visit counts
+                                     (TrainGraph::data, dist_loops.cc:314-319)                */
+} ggms_sample_extra_t;
+
 int ggms_sample_batch_capacity(size_t num_seeds, const size_t *fanouts,
                                uint32_t num_layer, size_t *max_input,
                                size_t *max_edges, size_t *max_unique);
-size_t ggms_sample_batch_workspace_bytes(size_t num_seeds,
+size_t ggms_sample_batch_workspace_bytes(int sample_type, size_t num_seeds,
                                          const size_t *fanouts,
-                                         uint32_t num_layer);
+                                         uint32_t num_layer,
+                                         const ggms_sample_extra_t *extra);
 int ggms_sample_batch(int sample_type, const ggms_graph_t *graph,
                       const ggms_id_t *seeds, size_t num_seeds,
                       const size_t *fanouts, uint32_t num_layer,
                       ggms_hashtable_t *ht, void *states, size_t num_states,
                       ggms_id_t *const *row, ggms_id_t *const *col,
-                      uint64_t *counts_dev, void *workspace,
-                      size_t workspace_bytes, ggms_stream_t stream);
+                      uint64_t *counts_dev, const ggms_sample_extra_t *extra,
+                      void *workspace, size_t workspace_bytes,
+                      ggms_stream_t stream);
 
 /* ---------------------------------------------------------------------------
  * Feature extract -- GPUExtract, cuda/cuda_extraction.cu:74-117:

@@ -19,7 +19,7 @@ _LIB = None
 _REF = None
 
 EMPTY_KEY = 0xFFFFFFFF
-KHOP0, KHOP3, CPU_KHOP0 = 0, 7, 100
+KHOP0, WEIGHTED_KHOP, RANDOM_WALK, KHOP3, CPU_KHOP0 = 0, 2, 3, 7, 100
 
 u32p = C.POINTER(C.c_uint32)
 XORWOW_DTYPE = np.dtype([("d", "<u4"), ("v", "<u4", (5,))])
@@ -56,6 +56,7 @@ def lib():
         _LIB.orc_ht_num_items.restype = C.c_size_t
         _LIB.orc_ht_unique.restype = u32p
         _LIB.orc_do_sample.restype = C.c_void_p
+        _LIB.orc_do_sample_ex.restype = C.c_void_p
         _LIB.orc_partition_feature.restype = C.c_size_t
         _LIB.orc_num_cache_node.restype = C.c_uint32
     return _LIB
@@ -246,26 +247,41 @@ class HashTable:
 class _SampleResult(C.Structure):
     _fields_ = [("num_layer", C.c_size_t), ("num_src", C.POINTER(C.c_size_t)),
                 ("num_dst", C.POINTER(C.c_size_t)), ("num_edge", C.POINTER(C.c_size_t)),
-                ("row", C.POINTER(u32p)), ("col", C.POINTER(u32p)),
+                ("row", C.POINTER(u32p)), ("col", C.POINTER(u32p)), ("data", C.POINTER(u32p)),
                 ("input_nodes", u32p), ("num_input_nodes", C.c_size_t)]
 
 
-def do_sample(sample_type, indptr, indices, seeds, fanouts, states=None):
-    """Multi-layer loop.  Returns dict(layers=[{row,col,num_src,num_dst}], input_nodes)."""
+class _SampleExtra(C.Structure):
+    _fields_ = [("prob_table", C.c_void_p), ("alias_table", C.c_void_p), ("walk_length", C.c_size_t),
+                ("restart_prob", C.c_double), ("num_walk", C.c_size_t)]
+
+
+def do_sample(sample_type, indptr, indices, seeds, fanouts, states=None, prob=None, alias=None, walk_length=0,
+              restart_prob=0.0, num_walk=0):
+    """Multi-layer loop.  Returns dict(layers=[{row,col,data,num_src,num_dst}], input_nodes)."""
     indptr, indices, seeds = _u32(indptr), _u32(indices), _u32(seeds)
     f = (C.c_size_t * len(fanouts))(*[int(x) for x in fanouts])
     if states is None:
         states = np.zeros(1, XORWOW_DTYPE)
-    h = lib().orc_do_sample(C.c_int(sample_type), _p(indptr), _p(indices), _sz(indptr.size - 1),
-                            _p(seeds), _sz(seeds.size), f, _sz(len(fanouts)), _p(states),
-                            _sz(states.size))
+    ex = _SampleExtra()
+    if prob is not None:
+        prob = np.ascontiguousarray(prob, np.float32)
+        alias = _u32(alias)
+        ex.prob_table, ex.alias_table = prob.ctypes.data, alias.ctypes.data
+    ex.walk_length, ex.restart_prob, ex.num_walk = walk_length, restart_prob, num_walk
+    h = lib().orc_do_sample_ex(C.c_int(sample_type), _p(indptr), _p(indices), _sz(indptr.size - 1),
+                               _p(seeds), _sz(seeds.size), f, _sz(len(fanouts)), _p(states),
+                               _sz(states.size), C.byref(ex))
     r = C.cast(h, C.POINTER(_SampleResult)).contents
     layers = []
     for i in range(len(fanouts)):
         ne = r.num_edge[i]
         row = np.ctypeslib.as_array(r.row[i], shape=(max(ne, 1),))[:ne].copy()
         col = np.ctypeslib.as_array(r.col[i], shape=(max(ne, 1),))[:ne].copy()
-        layers.append(dict(row=row, col=col, num_src=int(r.num_src[i]), num_dst=int(r.num_dst[i])))
+        data = None
+        if r.data[i]:
+            data = np.ctypeslib.as_array(r.data[i], shape=(max(ne, 1),))[:ne].copy()
+        layers.append(dict(row=row, col=col, data=data, num_src=int(r.num_src[i]), num_dst=int(r.num_dst[i])))
     n = r.num_input_nodes
     inp = np.ctypeslib.as_array(r.input_nodes, shape=(max(n, 1),))[:n].copy()
     lib().orc_sample_result_free(C.c_void_p(h))

@@ -724,6 +724,16 @@ orc_sample_result_t *orc_do_sample(int sample_type, const orc_id_t *indptr,
                                    const orc_id_t *seeds, size_t num_seeds,
                                    const size_t *fanouts, size_t num_layer,
                                    orc_xorwow_t *states, size_t num_states) {
+  return orc_do_sample_ex(sample_type, indptr, indices, num_node, seeds, num_seeds, fanouts, num_layer, states,
+                          num_states, NULL);
+}
+
+orc_sample_result_t *orc_do_sample_ex(int sample_type, const orc_id_t *indptr,
+                                      const orc_id_t *indices, size_t num_node,
+                                      const orc_id_t *seeds, size_t num_seeds,
+                                      const size_t *fanouts, size_t num_layer,
+                                      orc_xorwow_t *states, size_t num_states,
+                                      const orc_sample_extra_t *extra) {
   orc_sample_result_t *r = (orc_sample_result_t *)calloc(1, sizeof(*r));
   r->num_layer = num_layer;
   r->num_src = (size_t *)calloc(num_layer, sizeof(size_t));
@@ -731,6 +741,7 @@ orc_sample_result_t *orc_do_sample(int sample_type, const orc_id_t *indptr,
   r->num_edge = (size_t *)calloc(num_layer, sizeof(size_t));
   r->row = (orc_id_t **)calloc(num_layer, sizeof(orc_id_t *));
   r->col = (orc_id_t **)calloc(num_layer, sizeof(orc_id_t *));
+  r->data = (orc_id_t **)calloc(num_layer, sizeof(orc_id_t *));
   size_t cap = orc_predict_num_nodes(num_seeds, fanouts, num_layer);
   orc_hashtable_t *ht = orc_ht_create(num_node, cap);
   orc_ht_fill_with_duplicates(ht, seeds, num_seeds);
@@ -741,8 +752,18 @@ orc_sample_result_t *orc_do_sample(int sample_type, const orc_id_t *indptr,
     const size_t fanout = fanouts[i];
     orc_id_t *out_src = (orc_id_t *)malloc(sizeof(orc_id_t) * (num_cur * fanout + 1));
     orc_id_t *out_dst = (orc_id_t *)malloc(sizeof(orc_id_t) * (num_cur * fanout + 1));
+    orc_id_t *out_data = NULL;
     size_t num_out = 0;
     switch (sample_type) {
+      case ORC_WEIGHTED_KHOP:
+        orc_sample_weighted_khop(indptr, indices, extra->prob_table, extra->alias_table, cur, num_cur, fanout, states,
+                                 num_states, out_src, out_dst, &num_out);
+        break;
+      case ORC_RANDOM_WALK: /* fanout = num_neighbor = K (operation.cc:174) */
+        out_data = (orc_id_t *)malloc(sizeof(orc_id_t) * (num_cur * fanout + 1));
+        orc_sample_random_walk(indptr, indices, cur, num_cur, extra->walk_length, extra->restart_prob,
+                               extra->num_walk, fanout, states, num_states, out_src, out_dst, out_data, &num_out);
+        break;
       case ORC_KHOP3:
         orc_sample_khop3(indptr, indices, cur, num_cur, fanout, states, num_states, out_src, out_dst, &num_out);
         break;
@@ -764,6 +785,7 @@ orc_sample_result_t *orc_do_sample(int sample_type, const orc_id_t *indptr,
     r->num_edge[i] = num_out;
     r->col[i] = new_src; /* train_graph->col = new_src (dist_loops.cc:306) */
     r->row[i] = new_dst; /* train_graph->row = new_dst (:310)             */
+    r->data[i] = out_data; /* train_graph->data (:314-319)               */
     free(out_src);
     free(out_dst);
     free(cur);
@@ -779,8 +801,8 @@ orc_sample_result_t *orc_do_sample(int sample_type, const orc_id_t *indptr,
 
 void orc_sample_result_free(orc_sample_result_t *r) {
   if (!r) return;
-  for (size_t i = 0; i < r->num_layer; ++i) { free(r->row[i]); free(r->col[i]); }
-  free(r->row); free(r->col);
+  for (size_t i = 0; i < r->num_layer; ++i) { free(r->row[i]); free(r->col[i]); free(r->data[i]); }
+  free(r->row); free(r->col); free(r->data);
   free(r->num_src); free(r->num_dst); free(r->num_edge);
   free(r->input_nodes);
   free(r);

@@ -145,11 +145,19 @@ void orc_ht_map_edges(const orc_hashtable_t *ht, const orc_id_t *src,
                       orc_id_t *new_dst);
 
 /* ---- multi-layer sample loop (dist_loops.cc:62-368, cpu_loops.cc:55-192) */
-enum { ORC_KHOP0 = 0, ORC_KHOP3 = 7, ORC_CPU_KHOP0 = 100 };
+enum { ORC_KHOP0 = 0, ORC_WEIGHTED_KHOP = 2, ORC_RANDOM_WALK = 3, ORC_KHOP3 = 7, ORC_CPU_KHOP0 = 100 };
+typedef struct {
+  const float *prob_table;
+  const orc_id_t *alias_table;
+  size_t walk_length;
+  double restart_prob;
+  size_t num_walk;
+} orc_sample_extra_t;
 typedef struct {
   size_t num_layer;
   size_t *num_src, *num_dst, *num_edge; /* per layer, index = layer id    */
   orc_id_t **row, **col;                /* row = nbr local, col = seed local */
+  orc_id_t **data;                      /* random walk: visit counts (else NULL entries) */
   orc_id_t *input_nodes;                /* final unique list              */
   size_t num_input_nodes;
 } orc_sample_result_t;
@@ -158,6 +166,12 @@ orc_sample_result_t *orc_do_sample(int sample_type, const orc_id_t *indptr,
                                    const orc_id_t *seeds, size_t num_seeds,
                                    const size_t *fanouts, size_t num_layer,
                                    orc_xorwow_t *states, size_t num_states);
+orc_sample_result_t *orc_do_sample_ex(int sample_type, const orc_id_t *indptr,
+                                      const orc_id_t *indices, size_t num_node,
+                                      const orc_id_t *seeds, size_t num_seeds,
+                                      const size_t *fanouts, size_t num_layer,
+                                      orc_xorwow_t *states, size_t num_states,
+                                      const orc_sample_extra_t *extra);
 void orc_sample_result_free(orc_sample_result_t *r);
 
 /* ---- feature cache (cuda_cache_manager_*.{cu,cc}) ----------------------- */

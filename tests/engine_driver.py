@@ -31,6 +31,7 @@ def run_worker(sam, worker_id, num_layers, out_prefix, pipelined):
                "output_nodes": sam.get_graph_output_nodes(key).cpu().numpy()}
         for i, (row, col, ns, nd) in enumerate(sam.get_graph_coo(key, num_layers)):
             rec[f"row{i}"], rec[f"col{i}"] = row.cpu().numpy(), col.cpu().numpy()
+            rec[f"data{i}"] = sam.get_graph_data(key, i).cpu().numpy()
             rec[f"num_src{i}"], rec[f"num_dst{i}"] = ns, nd
             assert sam.get_graph_num_edge(key, i) == row.numel()
         rec["miss_bytes"] = sam.get_log_step_value_by_key(key, sam.kLogL1MissBytes)
@@ -56,6 +57,9 @@ def main():
            "cache_percentage": float(extra.pop("cache_percentage", 0.0)), "max_sampling_jobs": 10,
            "max_copying_jobs": 2, "omp_thread_num": 4, "num_layer": len(fanout), "num_hidden": 256, "lr": 0.003,
            "dropout": 0.5, "num_fanout": len(fanout), "fanout": fanout, "seed": int(extra.pop("seed", 1234))}
+    if cfg["_sample_type"] == sam.kRandomWalk:  # operation.cc:164-175: no fanout keys, num_neighbor per layer
+        cfg.pop("num_fanout"), cfg.pop("fanout")
+        cfg.update(random_walk_length=3, random_walk_restart_prob=0.5, num_random_walk=4, num_neighbor=5)
     cfg.update(extra)
     if arch == "arch1":
         cfg.update(sampler_ctx="cuda:0", trainer_ctx="cuda:0")

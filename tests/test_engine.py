@@ -57,7 +57,8 @@ sam.config({{'dataset_path': '/nonexistent', '_arch': 1}})
     assert "missing config key" in out.stderr
 
 
-def _oracle_batches(d, worker_id, num_worker, batch_size, num_epoch, fanouts, seed, arch6, sample_type="khop3"):
+def _oracle_batches(d, worker_id, num_worker, batch_size, num_epoch, fanouts, seed, arch6, sample_type="khop3",
+                    nstates=None, **kw):
     """Replays shuffler + sampler + extract on the CPU exactly as the engine is specified to."""
     train = d["train"]
     padded = oracle.aligned_pad(train, num_worker)
@@ -67,6 +68,10 @@ def _oracle_batches(d, worker_id, num_worker, batch_size, num_epoch, fanouts, se
     max_seeds = int(batch_size * 1.25) + 1
     nstates = max(oracle.predict_num_nodes(max_seeds, fanouts, len(fanouts) - 1),
                   (oracle.predict_num_nodes(max_seeds, fanouts, len(fanouts) - 1) + 127) // 128 * 8)
+    if sample_type == "weighted_khop":
+        nstates = min(oracle.predict_num_nodes(max_seeds, fanouts, len(fanouts)), 512 * 1024)
+    if sample_type == "random_walk":
+        nstates = (oracle.predict_num_nodes(max_seeds, fanouts, len(fanouts) - 1) + 63) // 64 * 256
     states = oracle.random_states(nstates, seed + 1000003 * worker_id)
     data = padded.copy()
     out = {}
@@ -79,8 +84,9 @@ def _oracle_batches(d, worker_id, num_worker, batch_size, num_epoch, fanouts, se
             if arch6 and ep == 0 and st == 0:
                 size = min(int(size * 1.25), n_local - off)
             seeds = local[off:off + size]
-            code = oracle.KHOP3 if sample_type == "khop3" else oracle.KHOP0
-            res = oracle.do_sample(code, d["ip"], d["ix"], seeds, fanouts, states)
+            code = {"khop3": oracle.KHOP3, "khop0": oracle.KHOP0, "weighted_khop": oracle.WEIGHTED_KHOP,
+                    "random_walk": oracle.RANDOM_WALK}[sample_type]
+            res = oracle.do_sample(code, d["ip"], d["ix"], seeds, fanouts, states, **kw)
             key = ep * n_global + worker_id * n_local_step + st
             out[key] = dict(res=res, seeds=seeds, feat=oracle.extract(d["feat"], res["input_nodes"]),
                             label=d["label"][seeds])
@@ -99,6 +105,8 @@ def _check(npz, want, num_layers):
             np.testing.assert_array_equal(npz[f"{key}:col{i}"].view(np.uint32), w["res"]["layers"][i]["col"])
             assert int(npz[f"{key}:num_src{i}"]) == w["res"]["layers"][i]["num_src"]
             assert int(npz[f"{key}:num_dst{i}"]) == w["res"]["layers"][i]["num_dst"]
+            if w["res"]["layers"][i]["data"] is not None:
+                np.testing.assert_array_equal(npz[f"{key}:data{i}"].view(np.uint32), w["res"]["layers"][i]["data"])
         assert npz[f"{key}:feat"].tobytes() == w["feat"].astype(np.float32).tobytes()
         np.testing.assert_array_equal(npz[f"{key}:label"], w["label"])
         assert float(npz[f"{key}:num_sample"]) == sum(l["row"].size for l in w["res"]["layers"])
@@ -115,6 +123,26 @@ def test_arch1_end_to_end(tmp_path, pipelined, sample_type, table):
     assert r.returncode == 0, r.stderr[-2000:]
     want = _oracle_batches(d, 0, 1, 64, 2, [5, 4], 99, arch6=False, sample_type=sample_type)
     _check(np.load(prefix + ".w0.npz"), want, 2)
+
+
+@pytest.mark.gpu
+def test_arch1_weighted_and_random_walk(tmp_path):
+    """PinSAGE (random walk, train_pinsage.py defaults) and weighted sampling through the engine."""
+    d = make_dataset(tmp_path / "ds")
+    rng = np.random.RandomState(3)
+    prob = rng.random_sample(d["ix"].size).astype(np.float32)
+    alias = rng.randint(0, d["ip"].size - 1, d["ix"].size).astype(np.uint32)
+    prob.tofile(os.path.join(d["path"], "prob_table.bin"))
+    alias.tofile(os.path.join(d["path"], "alias_table.bin"))
+    for stype, fan, kw in [("weighted_khop", [5, 4], dict(prob=prob, alias=alias)),
+                           ("random_walk", [5, 5, 5], dict(walk_length=3, restart_prob=0.5, num_walk=4))]:
+        prefix = str(tmp_path / f"out_{stype}")
+        r = subprocess.run([sys.executable, DRIVER, d["path"], prefix, "arch1", "1", f"sample_type={stype}", "seed=21",
+                            "num_epoch=1", "fanout=" + " ".join(map(str, fan))],
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        want = _oracle_batches(d, 0, 1, 64, 1, fan, 21, arch6=False, sample_type=stype, **kw)
+        _check(np.load(prefix + ".w0.npz"), want, len(fan))
 
 
 @pytest.mark.gpu

@@ -336,3 +336,41 @@ def test_sample_batch_vs_oracle(ops, stype, fanouts, nseed, direct):
             assert (gl["num_src"], gl["num_dst"]) == (wl["num_src"], wl["num_dst"]), (rep, i)
             np.testing.assert_array_equal(host_u32(gl["row"]), wl["row"], err_msg=f"row layer {i} rep {rep}")
             np.testing.assert_array_equal(host_u32(gl["col"]), wl["col"], err_msg=f"col layer {i} rep {rep}")
+
+
+@pytest.mark.parametrize("stype", ["weighted", "random_walk"])
+def test_sample_batch_weighted_and_random_walk(ops, stype):
+    """DoGPUSample with the weighted (alias) sampler and with PinSAGE random walks (row/col/data)."""
+    ip, ix = powerlaw_csr(20_000, mean_deg=30, seed=2)
+    N = ip.size - 1
+    g = ops.DeviceGraph(dev(ip), dev(ix))
+    rng = np.random.RandomState(11)
+    if stype == "weighted":
+        fanouts = [10, 5]
+        prob = rng.random_sample(ix.size).astype(np.float32)
+        alias = rng.randint(0, N, ix.size).astype(np.uint32)
+        t_prob, t_alias = dev(prob), dev(alias)
+        bs = ops.BatchSampler(g, fanouts, 500, sample_type=ops.WEIGHTED_KHOP, seed=5, prob_table=t_prob,
+                              alias_table=t_alias)
+        kw = dict(prob=prob, alias=alias)
+        code = oracle.WEIGHTED_KHOP
+    else:
+        fanouts = [5, 5, 5]  # num_neighbor per layer
+        bs = ops.BatchSampler(g, fanouts, 500, sample_type=ops.RANDOM_WALK, seed=5, random_walk_length=3,
+                              random_walk_restart_prob=0.5, num_random_walk=4)
+        kw = dict(walk_length=3, restart_prob=0.5, num_walk=4)
+        code = oracle.RANDOM_WALK
+    orc_states = oracle.random_states(bs.states.shape[0], 5)
+    for rep in range(2):
+        seeds = rng.permutation(N)[:500].astype(np.uint32)
+        bs.sample(dev(seeds))
+        got = bs.result()
+        want = oracle.do_sample(code, ip, ix, seeds, fanouts, orc_states, **kw)
+        np.testing.assert_array_equal(host_u32(got["input_nodes"]), want["input_nodes"])
+        for i in range(len(fanouts)):
+            gl, wl = got["layers"][i], want["layers"][i]
+            assert (gl["num_src"], gl["num_dst"]) == (wl["num_src"], wl["num_dst"]), (rep, i)
+            np.testing.assert_array_equal(host_u32(gl["row"]), wl["row"])
+            np.testing.assert_array_equal(host_u32(gl["col"]), wl["col"])
+            if stype == "random_walk":
+                np.testing.assert_array_equal(host_u32(gl["data"]), wl["data"])

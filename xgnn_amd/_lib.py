@@ -19,6 +19,12 @@ class Graph(C.Structure):
                 ("num_node", C.c_uint32), ("_pad", C.c_uint32)]
 
 
+class SampleExtra(C.Structure):
+    """ggms_sample_extra_t"""
+    _fields_ = [("prob_table", C.c_void_p), ("alias_table", C.c_void_p), ("random_walk_length", C.c_size_t),
+                ("random_walk_restart_prob", C.c_double), ("num_random_walk", C.c_size_t), ("data", C.c_void_p)]
+
+
 class HashTable(C.Structure):
     """ggms_hashtable_t"""
     _fields_ = [("o2n", C.c_void_p), ("n2o", C.c_void_p), ("num_items_dev", C.c_void_p),
@@ -45,9 +51,9 @@ SYMBOLS = {
     "ggms_sample_random_walk": (_i, [C.POINTER(Graph), _vp, _sz, _sz, C.c_double, _sz, _sz, _vp, _vp, _vp, _vp, _vp,
                                      _sz, _vp, _sz, _vp]),
     "ggms_sample_batch_capacity": (_i, [_sz, C.POINTER(_sz), _u32, C.POINTER(_sz), C.POINTER(_sz), C.POINTER(_sz)]),
-    "ggms_sample_batch_workspace_bytes": (_sz, [_sz, C.POINTER(_sz), _u32]),
+    "ggms_sample_batch_workspace_bytes": (_sz, [_i, _sz, C.POINTER(_sz), _u32, C.POINTER(SampleExtra)]),
     "ggms_sample_batch": (_i, [_i, C.POINTER(Graph), _vp, _sz, C.POINTER(_sz), _u32, C.POINTER(HashTable), _vp, _sz,
-                               C.POINTER(_vp), C.POINTER(_vp), _vp, _vp, _sz, _vp]),
+                               C.POINTER(_vp), C.POINTER(_vp), _vp, C.POINTER(SampleExtra), _vp, _sz, _vp]),
     "ggms_hashtable_num_buckets": (_sz, [_sz]),
     "ggms_hashtable_init": (_i, [C.POINTER(HashTable), _vp]),
     "ggms_hashtable_reset": (_i, [C.POINTER(HashTable), _vp]),

@@ -110,8 +110,11 @@ void Engine::Configure(const std::unordered_map<std::string, std::string> &kv_in
   if (kv.count("gpu_extract") && kv["gpu_extract"] == "True") cfg.gpu_extract = (cfg.arch == kArch6); // :229-235
   if (kv.count("seed")) { cfg.has_seed = true; cfg.seed = std::stoull(kv["seed"]); }
   if (kv.count("hash_table")) cfg.direct_table = kv["hash_table"] != "hashed";
-  SAM_CHECK(cfg.sample_type == GGMS_KHOP3 || cfg.sample_type == GGMS_KHOP0,
-            "sample types built so far: khop0, khop3 (DESIGN.md)");
+  SAM_CHECK(cfg.sample_type == GGMS_KHOP3 || cfg.sample_type == GGMS_KHOP0 || cfg.sample_type == GGMS_WEIGHTED_KHOP ||
+                cfg.sample_type == GGMS_RANDOM_WALK,
+            "sample types built: khop0, khop3, weighted_khop, random_walk (DESIGN.md)");
+  if (cfg.sample_type == GGMS_WEIGHTED_KHOP) // dist_loops.cc:171-172
+    SAM_CHECK(!cfg.use_dist_graph, "this algorithm not support DistGraph engine");
   cfg.configured = true;
 }
 
@@ -194,6 +197,10 @@ void Engine::LoadDataset() {
   ds.train_set = MapFile("train_set.bin", ds.num_train * 4, false);
   ds.test_set = MapFile("test_set.bin", ds.num_test * 4, false);
   ds.valid_set = MapFile("valid_set.bin", ds.num_valid * 4, false);
+  if (cfg.sample_type == GGMS_WEIGHTED_KHOP) { // engine.cc:372-384
+    ds.prob_table = MapFile("prob_table.bin", ds.num_edge * 4, false);
+    ds.alias_table = MapFile("alias_table.bin", ds.num_edge * 4, false);
+  }
   if (cfg.UseGPUCache()) { // engine.cc:395-440
     static const char *rank_files[] = {"cache_by_degree.bin", "cache_by_heuristic.bin", nullptr, "cache_by_degree_hop.bin",
                                        nullptr, "cache_by_fake_optimal.bin", nullptr, "cache_by_random.bin"};
@@ -384,16 +391,28 @@ void Engine::SampleInit(int worker_id, const std::string &ctx) {
   SAM_HIP(hipMalloc((void **)&ht_.n2o, max_unique_ * 4));
   SAM_HIP(hipMalloc((void **)&ht_.num_items_dev, 16));
   SAM_GGMS(ggms_hashtable_init(&ht_, stream_));
+  std::memset(&extra_, 0, sizeof(extra_));
+  if (cfg.sample_type == GGMS_WEIGHTED_KHOP) { // dist_engine.cc:210-213
+    d_prob_ = dev_upload(ds.prob_table.ptr, ds.prob_table.bytes, stream_);
+    d_alias_ = dev_upload(ds.alias_table.ptr, ds.alias_table.bytes, stream_);
+    extra_.prob_table = (const float *)d_prob_;
+    extra_.alias_table = (const ggms_id_t *)d_alias_;
+  }
+  extra_.random_walk_length = cfg.random_walk_length;
+  extra_.random_walk_restart_prob = cfg.random_walk_restart_prob;
+  extra_.num_random_walk = cfg.num_random_walk;
   // GPURandomStates dist_engine.cc:432-433; seed = wall clock unless the "seed" key is given
   num_states_ = ggms_random_states_count(cfg.sample_type, cfg.fanout.data(), L, max_seeds_, cfg.num_random_walk);
   size_t max_in = 0;
   for (auto v : max_input_) max_in = std::max(max_in, v);
   num_states_ = std::max(num_states_, (max_in + 127) / 128 * 8);
+  if (cfg.sample_type == GGMS_RANDOM_WALK)
+    num_states_ = std::max(num_states_, ggms_random_walk_num_states(max_in, cfg.num_random_walk));
   SAM_HIP(hipMalloc(&states_, num_states_ * GGMS_RNG_STATE_BYTES));
   const uint64_t seed = cfg.has_seed ? cfg.seed + 1000003ull * worker_id
                                      : (uint64_t)std::chrono::system_clock::now().time_since_epoch().count();
   SAM_GGMS(ggms_random_states_init(states_, num_states_, seed, stream_));
-  ws_bytes_ = ggms_sample_batch_workspace_bytes(max_seeds_, cfg.fanout.data(), L);
+  ws_bytes_ = ggms_sample_batch_workspace_bytes(cfg.sample_type, max_seeds_, cfg.fanout.data(), L, &extra_);
   SAM_HIP(hipMalloc(&ws_, ws_bytes_));
   SAM_HIP(hipStreamSynchronize(stream_));
   prof.Resize(cfg.num_epoch, num_global_step_);
@@ -471,6 +490,7 @@ void Engine::TrainInit(int worker_id, const std::string &ctx) {
     for (uint32_t i = 0; i < L; ++i) {
       SAM_HIP(hipMalloc((void **)&b->row[i], std::max<size_t>(max_edges_[i], 4) * 4));
       SAM_HIP(hipMalloc((void **)&b->col[i], std::max<size_t>(max_edges_[i], 4) * 4));
+      if (cfg.sample_type == GGMS_RANDOM_WALK) SAM_HIP(hipMalloc((void **)&b->data[i], std::max<size_t>(max_edges_[i], 4) * 4));
     }
     SAM_HIP(hipMalloc((void **)&b->input_nodes, max_unique_ * 4));
     SAM_HIP(hipMalloc((void **)&b->output_nodes, max_seeds_ * 4));
@@ -535,8 +555,11 @@ void Engine::RunSampleOnce() {
   }
   const uint32_t L = (uint32_t)cfg.fanout.size();
   SAM_HIP(hipEventRecord(b->ev_start, stream_));
+  ggms_sample_extra_t extra = extra_;
+  extra.data = b->data.data();
   SAM_GGMS(ggms_sample_batch(cfg.sample_type, &graph_, b->output_nodes, b->num_seeds, cfg.fanout.data(), L, &ht_,
-                             states_, num_states_, b->row.data(), b->col.data(), b->counts_dev, ws_, ws_bytes_, stream_));
+                             states_, num_states_, b->row.data(), b->col.data(), b->counts_dev, &extra, ws_, ws_bytes_,
+                             stream_));
   SAM_HIP(hipEventRecord(b->ev_sampled, stream_));
   uint64_t *n_in = b->counts_dev + 3 * L, *n_miss = b->counts_dev + 3 * L + 1;
   SAM_HIP(hipMemsetAsync(n_miss, 0, 8, stream_));

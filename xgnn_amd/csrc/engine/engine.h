@@ -185,6 +185,8 @@ class Engine {
   ggms_graph_t graph_{};
   // sampler state
   ggms_hashtable_t ht_{};
+  ggms_sample_extra_t extra_{};
+  void *d_prob_ = nullptr, *d_alias_ = nullptr;
   void *states_ = nullptr;
   size_t num_states_ = 0;
   void *ws_ = nullptr;

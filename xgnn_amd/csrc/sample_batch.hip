@@ -21,6 +21,8 @@
 //     for the first layer, whose input is the raw seed list);
 //   * `row` comes from the bucket position remembered at insert time
 //     (item_pos), so the dst half needs no probing either.
+#include <algorithm>
+
 #include "ggms_internal.h"
 #include "tile_scan.h"
 
@@ -67,11 +69,23 @@ int ggms_sample_batch_capacity(size_t num_seeds, const size_t *fanouts, uint32_t
   return GGMS_OK;
 }
 
-size_t ggms_sample_batch_workspace_bytes(size_t num_seeds, const size_t *fanouts, uint32_t num_layer) {
+static size_t sampler_ws_words(int sample_type, const BatchCaps &c, const size_t *fanouts, uint32_t L,
+                               const ggms_sample_extra_t *extra) {
+  size_t w = sample_ws_words(c.max_in_all);
+  for (uint32_t i = 0; i < L; ++i) {
+    if (sample_type == GGMS_WEIGHTED_KHOP) w = std::max(w, weighted_ws_words(c.max_input[i], fanouts[i]));
+    if (sample_type == GGMS_RANDOM_WALK && extra)
+      w = std::max(w, random_walk_ws_words(c.max_input[i], extra->random_walk_length, extra->num_random_walk, fanouts[i]));
+  }
+  return w;
+}
+
+size_t ggms_sample_batch_workspace_bytes(int sample_type, size_t num_seeds, const size_t *fanouts, uint32_t num_layer,
+                                         const ggms_sample_extra_t *extra) {
   if (!fanouts || num_layer < 1 || num_layer > 16) return 0;
   const BatchCaps c = caps_of(num_seeds, fanouts, num_layer);
   const size_t words = num_seeds + 16                      // seed_local
-                       + sample_ws_words(c.max_in_all)     // offsets + scan scratch
+                       + sampler_ws_words(sample_type, c, fanouts, num_layer, extra) // sampler scratch
                        + c.max_e_all + 16                  // global neighbour ids of the layer
                        + ht_ws_words(c.max_e_all);         // item_pos + scan scratch
   return words * sizeof(uint32_t);
@@ -80,12 +94,20 @@ size_t ggms_sample_batch_workspace_bytes(size_t num_seeds, const size_t *fanouts
 int ggms_sample_batch(int sample_type, const ggms_graph_t *graph, const ggms_id_t *seeds, size_t num_seeds,
                       const size_t *fanouts, uint32_t num_layer, ggms_hashtable_t *ht, void *states,
                       size_t num_states, ggms_id_t *const *row, ggms_id_t *const *col, uint64_t *counts_dev,
-                      void *workspace, size_t workspace_bytes, ggms_stream_t stream) {
+                      const ggms_sample_extra_t *extra, void *workspace, size_t workspace_bytes,
+                      ggms_stream_t stream) {
   GGMS_CHECK_ARG(graph && fanouts && ht && row && col && counts_dev);
   GGMS_CHECK_ARG(num_layer >= 1 && num_layer <= 16);
-  GGMS_CHECK_ARG(sample_type == GGMS_KHOP3 || sample_type == GGMS_KHOP0);
+  GGMS_CHECK_ARG(sample_type == GGMS_KHOP3 || sample_type == GGMS_KHOP0 || sample_type == GGMS_WEIGHTED_KHOP ||
+                 sample_type == GGMS_RANDOM_WALK);
   GGMS_CHECK_ARG(num_seeds == 0 || seeds);
-  GGMS_CHECK_ARG(workspace && workspace_bytes >= ggms_sample_batch_workspace_bytes(num_seeds, fanouts, num_layer));
+  GGMS_CHECK_ARG(workspace && workspace_bytes >= ggms_sample_batch_workspace_bytes(sample_type, num_seeds, fanouts,
+                                                                                   num_layer, extra));
+  if (sample_type == GGMS_WEIGHTED_KHOP)
+    GGMS_CHECK_ARG(extra && extra->prob_table && extra->alias_table && graph->num_part == 0 && states);
+  if (sample_type == GGMS_RANDOM_WALK)
+    GGMS_CHECK_ARG(extra && extra->data && extra->random_walk_length > 0 && extra->num_random_walk > 0 && states &&
+                   extra->random_walk_length * extra->num_random_walk <= 128);
   hipStream_t s = to_stream(stream);
   const BatchCaps c = caps_of(num_seeds, fanouts, num_layer);
   GGMS_CHECK_ARG(c.max_input[0] + c.max_edges[0] <= ht->n2o_size);
@@ -97,7 +119,7 @@ int ggms_sample_batch(int sample_type, const ggms_graph_t *graph, const ggms_id_
 
   uint32_t *w = (uint32_t *)workspace;
   uint32_t *seed_local = w;            w += num_seeds + 16;
-  uint32_t *samp_ws = w;               w += sample_ws_words(c.max_in_all);
+  uint32_t *samp_ws = w;               w += sampler_ws_words(sample_type, c, fanouts, num_layer, extra);
   uint32_t *tmp_dst = w;               w += c.max_e_all + 16;
   uint32_t *item_pos = w;              w += c.max_e_all;
   uint32_t *ht_scratch = w;
@@ -129,9 +151,18 @@ int ggms_sample_batch(int sample_type, const ggms_graph_t *graph, const ggms_id_
     } else if (sample_type == GGMS_KHOP3) {
       rc = sample_khop3_impl(g, input, n_max, n, (uint32_t)fanouts[i], col[i], tmp_dst, num_edge, (uint32_t *)states,
                              samp_ws, first ? seed_local : nullptr, 1, ht->n2o, s);
-    } else {
+    } else if (sample_type == GGMS_KHOP0) {
       rc = sample_khop0_impl(g, input, n_max, n, (uint32_t)fanouts[i], col[i], tmp_dst, num_edge, samp_ws,
                              first ? seed_local : nullptr, 1, s);
+    } else if (sample_type == GGMS_WEIGHTED_KHOP) {
+      rc = sample_weighted_impl(graph->indptr, graph->indices, extra->prob_table, extra->alias_table, input, n_max, n,
+                                (uint32_t)fanouts[i], col[i], tmp_dst, num_edge, (uint32_t *)states, samp_ws,
+                                first ? seed_local : nullptr, 1, s);
+    } else { // random walk: fanout[i] = num_neighbor = K (operation.cc:174)
+      rc = sample_random_walk_impl(g, input, n_max, n, (uint32_t)extra->random_walk_length,
+                                   extra->random_walk_restart_prob, (uint32_t)extra->num_random_walk,
+                                   (uint32_t)fanouts[i], col[i], tmp_dst, extra->data[i], num_edge, (uint32_t *)states,
+                                   samp_ws, first ? seed_local : nullptr, 1, s);
     }
     if (rc != GGMS_OK) return rc;
     const Count ne = count_of(e_max, num_edge);

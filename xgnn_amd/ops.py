@@ -263,7 +263,9 @@ def extract_cached(out, nodes, table, parts_table, num_part, host_feat, num=None
 class BatchSampler:
     """DoGPUSample (dist_loops.cc:62-368) as one enqueue: buffers sized once, reused every batch."""
 
-    def __init__(self, graph, fanouts, batch_size, sample_type=KHOP3, seed=0, device="cuda", direct_table=True):
+    def __init__(self, graph, fanouts, batch_size, sample_type=KHOP3, seed=0, device="cuda", direct_table=True,
+                 prob_table=None, alias_table=None, random_walk_length=0, random_walk_restart_prob=0.0,
+                 num_random_walk=0):
         self.graph, self.fanouts, self.sample_type = graph, [int(f) for f in fanouts], sample_type
         L = len(self.fanouts)
         self.L = L
@@ -274,15 +276,33 @@ class BatchSampler:
         check(lib().ggms_sample_batch_capacity(self.max_seeds, self._f, L, mi, me, C.byref(mu)), "capacity")
         self.max_input, self.max_edges, self.max_unique = list(mi), list(me), mu.value
         self.ht = OrderedHashTable(self.max_unique, device, num_node=graph.c.num_node if direct_table else None)
-        nstates = lib().ggms_random_states_count(sample_type, self._f, L, self.max_seeds, 0)
+        nstates = lib().ggms_random_states_count(sample_type, self._f, L, self.max_seeds, num_random_walk)
         nstates = max(nstates, (max(self.max_input) + 127) // 128 * 8)
-        self.states = random_states(nstates, seed, device) if sample_type == KHOP3 else None
+        if sample_type == RANDOM_WALK:
+            nstates = max(nstates, lib().ggms_random_walk_num_states(max(self.max_input), num_random_walk))
+        self.states = random_states(nstates, seed, device) if sample_type != KHOP0 else None
         self.row = [torch.empty(max(1, e), dtype=torch.int32, device=device) for e in self.max_edges]
         self.col = [torch.empty(max(1, e), dtype=torch.int32, device=device) for e in self.max_edges]
         self._row = (C.c_void_p * L)(*[t.data_ptr() for t in self.row])
         self._col = (C.c_void_p * L)(*[t.data_ptr() for t in self.col])
         self.counts = torch.zeros(3 * L + 1, dtype=torch.int64, device=device)
-        self.ws = _workspace(lib().ggms_sample_batch_workspace_bytes(self.max_seeds, self._f, L), device)
+        self.extra = None
+        self.data = None
+        self._keep = (prob_table, alias_table)
+        if sample_type in (WEIGHTED_KHOP, RANDOM_WALK):
+            self.extra = _lib.SampleExtra()
+            self.extra.prob_table = prob_table.data_ptr() if prob_table is not None else None
+            self.extra.alias_table = alias_table.data_ptr() if alias_table is not None else None
+            self.extra.random_walk_length = random_walk_length
+            self.extra.random_walk_restart_prob = random_walk_restart_prob
+            self.extra.num_random_walk = num_random_walk
+            if sample_type == RANDOM_WALK:
+                self.data = [torch.empty(max(1, e), dtype=torch.int32, device=device) for e in self.max_edges]
+                self._data = (C.c_void_p * L)(*[t.data_ptr() for t in self.data])
+                self.extra.data = C.cast(self._data, C.c_void_p)
+        self._extra_ref = C.byref(self.extra) if self.extra is not None else None
+        self.ws = _workspace(lib().ggms_sample_batch_workspace_bytes(sample_type, self.max_seeds, self._f, L,
+                                                                     self._extra_ref), device)
 
     def sample(self, seeds):
         """Enqueue one batch; returns nothing -- read self.counts / row / col / ht.n2o after a sync."""
@@ -292,7 +312,8 @@ class BatchSampler:
         check(lib().ggms_sample_batch(self.sample_type, C.byref(self.graph.c), _ptr(seeds), n, self._f, self.L,
                                       C.byref(self.ht.c), _ptr(self.states),
                                       self.states.shape[0] if self.states is not None else 0, self._row, self._col,
-                                      _ptr(self.counts), _ptr(self.ws), self.ws.numel() * 4, _stream()),
+                                      _ptr(self.counts), self._extra_ref, _ptr(self.ws), self.ws.numel() * 4,
+                                      _stream()),
               "ggms_sample_batch")
 
     def result(self):
@@ -301,5 +322,6 @@ class BatchSampler:
         layers = []
         for i in range(self.L):
             ne = c[3 * i]
-            layers.append(dict(row=self.row[i][:ne], col=self.col[i][:ne], num_src=c[3 * i + 1], num_dst=c[3 * i + 2]))
+            layers.append(dict(row=self.row[i][:ne], col=self.col[i][:ne], num_src=c[3 * i + 1], num_dst=c[3 * i + 2],
+                               data=self.data[i][:ne] if self.data is not None else None))
         return dict(layers=layers, input_nodes=self.ht.n2o[: c[3 * self.L]])
