@@ -67,7 +67,7 @@ int ggms_get_miss_cache_index(const ggms_id_t *table, const ggms_id_t *nodes, si
   return tile_scan(MissFlag{table, nodes},
                    SplitEmit{table, nodes, miss_src_index, miss_dst_index, cache_src_index, cache_dst_index,
                              num_miss_dev, num_cache_dev, n},
-                   num_nodes, n, (uint32_t *)workspace, nullptr, nullptr, nullptr, s);
+                   num_nodes, n, ScanArea{(uint32_t *)workspace, false}, nullptr, nullptr, nullptr, s);
 }
 
 } // extern "C"

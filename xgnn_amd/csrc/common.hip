@@ -1,4 +1,4 @@
-// common.hip -- error plumbing, tile-prefix kernel, XORWOW state pool.
+// common.hip -- error plumbing, XORWOW state pool.
 #include <cstdarg>
 #include <cstdio>
 
@@ -13,32 +13,6 @@ void set_error(const char *fmt, ...) {
   va_start(ap, fmt);
   vsnprintf(g_err, sizeof(g_err), fmt, ap);
   va_end(ap);
-}
-
-__global__ __launch_bounds__(kBlock) void k_tile_prefix(const uint32_t *tile_sums, Count n_arg,
-                                                        uint32_t *tile_prefix, const uint32_t *base_in,
-                                                        uint32_t *total32_out, uint64_t *total64_out,
-                                                        uint64_t *mirror_a, uint64_t *mirror_b) {
-  __shared__ uint32_t smem[kBlock / kWave];
-  const uint64_t n = n_arg.get();
-  const uint64_t num_tiles = (n + kTile - 1) / kTile;
-  const uint32_t base = base_in ? *base_in : 0u;
-  uint32_t running = base;
-  for (uint64_t t0 = 0; t0 < num_tiles; t0 += kBlock) {
-    const uint64_t t = t0 + threadIdx.x;
-    const uint32_t v = (t < num_tiles) ? tile_sums[t] : 0u;
-    uint32_t total;
-    const uint32_t excl = block_exclusive_scan(v, smem, total);
-    if (t < num_tiles) tile_prefix[t] = running + excl;
-    running += total;
-  }
-  if (threadIdx.x == 0) {
-    tile_prefix[num_tiles] = running;
-    if (total32_out) *total32_out = running;
-    if (total64_out) *total64_out = (uint64_t)(running - base);
-    if (mirror_a) *mirror_a = (uint64_t)running;
-    if (mirror_b) *mirror_b = (uint64_t)running;
-  }
 }
 
 // cuda_random_states.cu:36-46

@@ -1,6 +1,6 @@
 // ggms_internal.h -- cross-file C++ entry points (count-on-device variants of the leaf ops).
 #pragma once
-#include "ggms_device.h"
+#include "tile_scan.h"
 
 namespace ggms {
 
@@ -8,30 +8,31 @@ namespace ggms {
 size_t sample_ws_words(size_t num_input);
 int sample_khop3_impl(GraphView g, const uint32_t *input, size_t n_max, Count n, uint32_t fanout, uint32_t *out_src,
                       uint32_t *out_dst, uint64_t *num_out_dev, uint32_t *states, uint32_t *workspace,
-                      const uint32_t *seed_local, int src_local, const uint32_t *local_to_global, hipStream_t s);
+                      const uint32_t *seed_local, int src_local, const uint32_t *local_to_global, hipStream_t s,
+                      ScanArea *shared_scan = nullptr);
 int sample_khop0_impl(GraphView g, const uint32_t *input, size_t n_max, Count n, uint32_t fanout, uint32_t *out_src,
                       uint32_t *out_dst, uint64_t *num_out_dev, uint32_t *workspace, const uint32_t *seed_local,
-                      int src_local, hipStream_t s);
+                      int src_local, hipStream_t s, ScanArea *shared_scan = nullptr);
 
 // sample_weighted.hip
 size_t weighted_ws_words(size_t num_input, size_t fanout);
 int sample_weighted_impl(const uint32_t *indptr, const uint32_t *indices, const float *prob, const uint32_t *alias,
                          const uint32_t *input, size_t n_max, Count n, uint32_t fanout, uint32_t *out_src,
                          uint32_t *out_dst, uint64_t *num_out_dev, uint32_t *states, uint32_t *workspace,
-                         const uint32_t *seed_local, int src_local, hipStream_t s);
+                         const uint32_t *seed_local, int src_local, hipStream_t s, ScanArea *shared_scan = nullptr);
 // sample_random_walk.hip
 size_t random_walk_ws_words(size_t num_input, size_t walk_length, size_t num_walk, size_t K);
 int sample_random_walk_impl(GraphView g, const uint32_t *input, size_t n_max, Count n, uint32_t walk_length,
                             double restart_prob, uint32_t num_walk, uint32_t K, uint32_t *out_src, uint32_t *out_dst,
                             uint32_t *out_data, uint64_t *num_out_dev, uint32_t *states, uint32_t *workspace,
-                            const uint32_t *seed_local, int src_local, hipStream_t s);
+                            const uint32_t *seed_local, int src_local, hipStream_t s, ScanArea *shared_scan = nullptr);
 
 // hashtable.hip
 size_t ht_ws_words(size_t num_input);
 // insert + ordered local-id assignment; item_pos[i] = bucket of input[i] (hashed layout only).
 // mirror_a/b (optional): 64-bit device slots that also receive the new item count
 int ht_fill_impl(const ggms_hashtable_t *ht, const uint32_t *input, size_t n_max, Count n, uint32_t *item_pos,
-                 uint32_t *scratch, uint64_t *mirror_a, uint64_t *mirror_b, hipStream_t s);
+                 ScanArea scan, uint64_t *mirror_a, uint64_t *mirror_b, hipStream_t s);
 // out[i] = local id of the i-th inserted item (hashed: through item_pos; direct: through keys)
 int ht_map_by_pos(const ggms_hashtable_t *ht, const uint32_t *item_pos, const uint32_t *keys, size_t n_max, Count n,
                   uint32_t *out, hipStream_t s);

@@ -170,7 +170,7 @@ __global__ __launch_bounds__(kBlock) void k_map_by_pos(Table t, const uint32_t *
 size_t ht_ws_words(size_t num_input) { return num_input + tile_scan_words(num_input) + 16; }
 
 int ht_fill_impl(const ggms_hashtable_t *ht, const uint32_t *input, size_t n_max, Count n, uint32_t *item_pos,
-                 uint32_t *scratch, uint64_t *mirror_a, uint64_t *mirror_b, hipStream_t s) {
+                 ScanArea scratch, uint64_t *mirror_a, uint64_t *mirror_b, hipStream_t s) {
   if (n_max == 0) return GGMS_OK;
   Table t = table_of(ht);
   const int grid = grid_for(n_max, kBlock);
@@ -251,8 +251,8 @@ int ggms_hashtable_fill_with_duplicates(ggms_hashtable_t *ht, const ggms_id_t *i
     GGMS_CHECK_ARG(workspace_bytes >= ggms_hashtable_workspace_bytes(num_input));
     GGMS_CHECK_ARG(num_input < (1ull << 32));
     uint32_t *item_pos = (uint32_t *)workspace;
-    int rc = ht_fill_impl(ht, input, num_input, count_of(num_input), item_pos, item_pos + num_input, nullptr,
-                          nullptr, s);
+    int rc = ht_fill_impl(ht, input, num_input, count_of(num_input), item_pos,
+                          ScanArea{item_pos + num_input, false}, nullptr, nullptr, s);
     if (rc != GGMS_OK) return rc;
   }
   if (unique_out) {

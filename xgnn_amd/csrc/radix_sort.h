@@ -120,7 +120,7 @@ inline int radix_sort_pairs(uint32_t *k0, uint32_t *v0, uint32_t *k1, uint32_t *
     hipLaunchKernelGGL(k_sort_hist, dim3(grid), dim3(kBlock), 0, s, ki, n, shift, hist, tiles);
     GGMS_LAUNCH_CHECK();
     int rc = tile_scan(HistValue{hist}, HistStore{hist}, 256 * (size_t)tiles, count_of(256 * (size_t)tiles),
-                       scan_scratch, nullptr, nullptr, nullptr, s);
+                       ScanArea{scan_scratch, pass != 0}, nullptr, nullptr, nullptr, s); // one clear for 4 passes
     if (rc != GGMS_OK) return rc;
     hipLaunchKernelGGL(k_sort_scatter, dim3(grid), dim3(kBlock), 0, s, ki, vi, ko, vo, n, shift, hist, tiles);
     GGMS_LAUNCH_CHECK();

@@ -87,7 +87,8 @@ size_t ggms_sample_batch_workspace_bytes(int sample_type, size_t num_seeds, cons
   const size_t words = num_seeds + 16                      // seed_local
                        + sampler_ws_words(sample_type, c, fanouts, num_layer, extra) // sampler scratch
                        + c.max_e_all + 16                  // global neighbour ids of the layer
-                       + ht_ws_words(c.max_e_all);         // item_pos + scan scratch
+                       + c.max_e_all + 16                  // item_pos (hashed table layout)
+                       + tile_scan_words(std::max(c.max_e_all, c.max_in_all)) + 16; // ONE scan area for the batch
   return words * sizeof(uint32_t);
 }
 
@@ -121,14 +122,21 @@ int ggms_sample_batch(int sample_type, const ggms_graph_t *graph, const ggms_id_
   uint32_t *seed_local = w;            w += num_seeds + 16;
   uint32_t *samp_ws = w;               w += sampler_ws_words(sample_type, c, fanouts, num_layer, extra);
   uint32_t *tmp_dst = w;               w += c.max_e_all + 16;
-  uint32_t *item_pos = w;              w += c.max_e_all;
-  uint32_t *ht_scratch = w;
+  uint32_t *item_pos = w;              w += c.max_e_all + 16;
+  // every ordered scan of the batch (seed offsets, owner flags) shares one control/descriptor area that is
+  // cleared once here: descriptors are epoch-tagged, the control words re-arm themselves
+  ScanArea scan{w, true};
+  const size_t scan_items = std::max(c.max_e_all, c.max_in_all);
+  {
+    int rc0 = clear_scan_area(scan.words, scan_items, s);
+    if (rc0 != GGMS_OK) return rc0;
+  }
 
   const GraphView g = view_of(graph);
   int rc = ggms_hashtable_reset(ht, stream); // hash_table->Reset, dist_loops.cc:105
   if (rc != GGMS_OK) return rc;
   // FillWithDupRevised(seeds), dist_loops.cc:110-111 (item_pos doubles as scratch here)
-  rc = ht_fill_impl(ht, seeds, num_seeds, count_of(num_seeds), item_pos, ht_scratch, nullptr, nullptr, s);
+  rc = ht_fill_impl(ht, seeds, num_seeds, count_of(num_seeds), item_pos, scan, nullptr, nullptr, s);
   if (rc != GGMS_OK) return rc;
   // local ids of the raw seeds (they may repeat): first-layer `col`
   rc = ht_map_by_pos(ht, item_pos, seeds, num_seeds, count_of(num_seeds), seed_local, s);
@@ -150,10 +158,10 @@ int ggms_sample_batch(int sample_type, const ggms_graph_t *graph, const ggms_id_
       GGMS_HIP(hipMemsetAsync(num_edge, 0, sizeof(uint64_t), s));
     } else if (sample_type == GGMS_KHOP3) {
       rc = sample_khop3_impl(g, input, n_max, n, (uint32_t)fanouts[i], col[i], tmp_dst, num_edge, (uint32_t *)states,
-                             samp_ws, first ? seed_local : nullptr, 1, ht->n2o, s);
+                             samp_ws, first ? seed_local : nullptr, 1, ht->n2o, s, &scan);
     } else if (sample_type == GGMS_KHOP0) {
       rc = sample_khop0_impl(g, input, n_max, n, (uint32_t)fanouts[i], col[i], tmp_dst, num_edge, samp_ws,
-                             first ? seed_local : nullptr, 1, s);
+                             first ? seed_local : nullptr, 1, s, &scan);
     } else if (sample_type == GGMS_WEIGHTED_KHOP) {
       rc = sample_weighted_impl(graph->indptr, graph->indices, extra->prob_table, extra->alias_table, input, n_max, n,
                                 (uint32_t)fanouts[i], col[i], tmp_dst, num_edge, (uint32_t *)states, samp_ws,
@@ -172,7 +180,7 @@ int ggms_sample_batch(int sample_type, const ggms_graph_t *graph, const ggms_id_
       GGMS_LAUNCH_CHECK();
       continue;
     }
-    rc = ht_fill_impl(ht, tmp_dst, e_max, ne, item_pos, ht_scratch, num_src, next_dst, s); // FillWithDuplicates, :279
+    rc = ht_fill_impl(ht, tmp_dst, e_max, ne, item_pos, scan, num_src, next_dst, s); // FillWithDuplicates, :279
     if (rc != GGMS_OK) return rc;
     rc = ht_map_by_pos(ht, item_pos, tmp_dst, e_max, ne, row[i], s);    // GPUMapEdges dst half, :296
     if (rc != GGMS_OK) return rc;

@@ -19,7 +19,7 @@
 //   * khop0: one lane per logical reservoir lane (32 per seed, as the RNG stream
 //     assignment demands); the racy atomicExch (khop0.cu:144-148) becomes an LDS
 //     atomicMax on the candidate position, i.e. highest-j-wins, deterministic.
-#include "tile_scan.h"
+#include "ggms_internal.h"
 
 namespace ggms {
 
@@ -282,10 +282,11 @@ size_t sample_ws_words(size_t num_input) { return num_input + tile_scan_words(nu
 // offsets by exclusive scan of min(deg, fanout), then the sampler proper
 int sample_khop3_impl(GraphView g, const uint32_t *input, size_t n_max, Count n, uint32_t fanout, uint32_t *out_src,
                       uint32_t *out_dst, uint64_t *num_out_dev, uint32_t *states, uint32_t *workspace,
-                      const uint32_t *seed_local, int src_local, const uint32_t *local_to_global, hipStream_t s) {
+                      const uint32_t *seed_local, int src_local, const uint32_t *local_to_global, hipStream_t s,
+                      ScanArea *shared_scan) {
   uint32_t *offset = workspace;
-  uint32_t *scratch = offset + n_max;
-  int rc = tile_scan(SeedCount{g, input, fanout}, StoreOffset{offset}, n_max, n, scratch, nullptr, nullptr,
+  const ScanArea sa = shared_scan ? *shared_scan : ScanArea{offset + n_max, false};
+  int rc = tile_scan(SeedCount{g, input, fanout}, StoreOffset{offset}, n_max, n, sa, nullptr, nullptr,
                      num_out_dev, s);
   if (rc != GGMS_OK) return rc;
   const int grid = grid_for((n_max + 127) / 128, 1);
@@ -303,10 +304,10 @@ int sample_khop3_impl(GraphView g, const uint32_t *input, size_t n_max, Count n,
 
 int sample_khop0_impl(GraphView g, const uint32_t *input, size_t n_max, Count n, uint32_t fanout, uint32_t *out_src,
                       uint32_t *out_dst, uint64_t *num_out_dev, uint32_t *workspace, const uint32_t *seed_local,
-                      int src_local, hipStream_t s) {
+                      int src_local, hipStream_t s, ScanArea *shared_scan) {
   uint32_t *offset = workspace;
-  uint32_t *scratch = offset + n_max;
-  int rc = tile_scan(SeedCount{g, input, fanout}, StoreOffset{offset}, n_max, n, scratch, nullptr, nullptr,
+  const ScanArea sa = shared_scan ? *shared_scan : ScanArea{offset + n_max, false};
+  int rc = tile_scan(SeedCount{g, input, fanout}, StoreOffset{offset}, n_max, n, sa, nullptr, nullptr,
                      num_out_dev, s);
   if (rc != GGMS_OK) return rc;
   const size_t num_blocks = (n_max + 63) / 64;

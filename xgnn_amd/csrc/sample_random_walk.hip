@@ -148,7 +148,7 @@ int random_walk_raw_impl(GraphView g, const uint32_t *input, size_t n_max, Count
 int sample_random_walk_impl(GraphView g, const uint32_t *input, size_t n_max, Count n, uint32_t walk_length,
                             double restart_prob, uint32_t num_walk, uint32_t K, uint32_t *out_src, uint32_t *out_dst,
                             uint32_t *out_data, uint64_t *num_out_dev, uint32_t *states, uint32_t *workspace,
-                            const uint32_t *seed_local, int src_local, hipStream_t s) {
+                            const uint32_t *seed_local, int src_local, hipStream_t s, ScanArea *shared_scan) {
   const uint32_t per = walk_length * num_walk;
   uint32_t *w = workspace;
   uint32_t *tmp_src = w; w += n_max * per;
@@ -162,8 +162,9 @@ int sample_random_walk_impl(GraphView g, const uint32_t *input, size_t n_max, Co
   hipLaunchKernelGGL(k_walk_topk, dim3(grid_for(n_max, kWave)), dim3(kWave), 2 * per * kWave * sizeof(uint32_t), s,
                      tmp_src, tmp_dst, n, per, K, pad_dst, pad_cnt, num_top);
   GGMS_LAUNCH_CHECK();
+  const ScanArea sa = shared_scan ? *shared_scan : ScanArea{scan_scr, false};
   return tile_scan(TopCount{num_top}, TopEmit{input, pad_dst, pad_cnt, K, out_src, out_dst, out_data, seed_local, src_local},
-                   n_max, n, scan_scr, nullptr, nullptr, num_out_dev, s);
+                   n_max, n, sa, nullptr, nullptr, num_out_dev, s);
 }
 
 } // namespace ggms

@@ -106,7 +106,7 @@ size_t weighted_ws_words(size_t num_input, size_t fanout) {
 int sample_weighted_impl(const uint32_t *indptr, const uint32_t *indices, const float *prob, const uint32_t *alias,
                          const uint32_t *input, size_t n_max, Count n, uint32_t fanout, uint32_t *out_src,
                          uint32_t *out_dst, uint64_t *num_out_dev, uint32_t *states, uint32_t *workspace,
-                         const uint32_t *seed_local, int src_local, hipStream_t s) {
+                         const uint32_t *seed_local, int src_local, hipStream_t s, ScanArea *shared_scan) {
   uint32_t *w = workspace;
   uint32_t *tmp_dst = w;  w += n_max * fanout;
   uint32_t *k0 = w;       w += n_max;
@@ -127,8 +127,9 @@ int sample_weighted_impl(const uint32_t *indptr, const uint32_t *indices, const 
   const SortedStream ss{k0, v0, tmp_dst, fanout, n};
   // element count of the compaction = n * fanout with n possibly on the device: a Count cannot multiply,
   // so KeepFlag bounds itself by ss.n and the scan runs over the upper bound
+  const ScanArea sa = shared_scan ? *shared_scan : ScanArea{scan_scr, false};
   return tile_scan(KeepFlag{ss}, KeepEmit{ss, out_src, out_dst, seed_local, src_local}, task_max,
-                   count_of(task_max), scan_scr, nullptr, nullptr, num_out_dev, s);
+                   count_of(task_max), sa, nullptr, nullptr, num_out_dev, s);
 }
 
 } // namespace ggms

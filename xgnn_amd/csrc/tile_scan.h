@@ -1,19 +1,27 @@
-// tile_scan.h -- ordered (stable) device-wide exclusive scan / compaction frame.
+// tile_scan.h -- ordered (stable) device-wide exclusive scan / compaction, count on the device.
 //
-// Replaces the reference's {count kernel, cub::DeviceScan::ExclusiveSum over
-// grid+1 entries, compact kernel with cub::BlockScan} triple
-// (e.g. cuda_sampling_khop3.cu:148-230,286-295; cuda_hashtable.cu:197-232,
-// 406-458; cuda_cache_manager_device.cu:40-169) with three launches that never
-// return to the host: the element count may live in device memory.
+// Replaces the reference's {count kernel, cub::DeviceScan::ExclusiveSum over grid+1 entries, compact
+// kernel with cub::BlockScan} triple (e.g. cuda_sampling_khop3.cu:148-230,286-295; cuda_hashtable.cu:
+// 197-232,406-458; cuda_cache_manager_device.cu:40-169) and its intermediate host syncs.
+// Two interchangeable forms (same results, same scratch): three launches (default, see scan_three_pass)
+// and one launch with decoupled look-back.
 //
-//   phase 1  k_tile_reduce : tile_sums[t]   = sum of value(i) over tile t
-//   phase 2  k_tile_prefix : tile_prefix[t] = base + exclusive sum (one block)
-//   phase 3  k_tile_apply  : emit(i, value(i), global exclusive prefix of i)
-//
-// Tile = 1024 items = 4 rounds of 256 threads (coalesced, item = tile*1024 +
-// round*256 + thread), the same item->position mapping as the reference's
-// kCudaTileSize/kCudaBlockSize idiom, so output order is the input order.
+// Single pass, decoupled look-back:
+//   * tiles of 1024 items (4 rounds of 256 threads, item = tile*1024 + round*256 + thread -- the
+//     reference's kCudaTileSize/kCudaBlockSize mapping, so output order = input order);
+//   * a block takes the next tile from an atomic ticket, so a tile's predecessors are always owned by
+//     blocks that are already running (forward progress without co-residency assumptions);
+//   * per tile one 64-bit descriptor {epoch : 30 | flag : 2 | value : 32}: flag A = tile aggregate,
+//     P = inclusive prefix.  Data and tag travel in ONE 8-byte relaxed agent-scope atomic store / load
+//     (no separate flag, hence no release/acquire pair to get wrong across XCDs); a word whose epoch is
+//     not the launch's epoch is "not yet written", so descriptors are never cleared between launches;
+//   * the element count may live in device memory (ggms::Count): no host round trip.
+// Control words {ticket, done} must be zero when a launch starts; the last block to leave re-zeroes
+// them.  Callers clear the control + descriptor region once (hipMemsetAsync) per API call / per batch.
 #pragma once
+
+#include <atomic>
+#include <cstdlib>
 
 #include "ggms_device.h"
 
@@ -22,9 +30,125 @@ namespace ggms {
 constexpr uint32_t kTile = 1024;
 
 inline size_t num_tiles_for(size_t n) { return (n + kTile - 1) / kTile; }
-// scratch for tile_sums + tile_prefix (+1 each), in uint32 words
-inline size_t tile_scan_words(size_t n) { return 2 * (num_tiles_for(n) + 2); }
+// scratch in uint32 words: 4 control words + one 64-bit descriptor per tile
+inline size_t tile_scan_words(size_t n) { return 12 + 2 * (num_tiles_for(n) + 1); }
 
+// where a scan keeps its control words + descriptors; `cleared` = the caller zeroed it already (one
+// memset per batch instead of one per scan; descriptors are epoch-tagged, so scans may share an area)
+struct ScanArea {
+  uint32_t *words;
+  bool cleared;
+};
+
+inline uint32_t next_scan_epoch() {
+  static std::atomic<uint32_t> g{0};
+  uint32_t e;
+  do { e = (g.fetch_add(1) + 1) & 0x3fffffffu; } while (e == 0);
+  return e;
+}
+
+__device__ __forceinline__ unsigned long long scan_desc(uint32_t epoch, uint32_t flag, uint32_t value) {
+  return ((unsigned long long)((epoch << 2) | flag) << 32) | value;
+}
+
+template <typename ValueF, typename EmitF>
+__global__ __launch_bounds__(kBlock) void k_tile_scan(ValueF value, EmitF emit, Count n_arg, uint32_t *ctl,
+                                                      unsigned long long *desc, uint32_t epoch,
+                                                      const uint32_t *base_in, uint32_t *total32_out,
+                                                      uint64_t *total64_out, uint64_t *mirror_a, uint64_t *mirror_b) {
+  constexpr uint32_t ROUNDS = kTile / kBlock, FLAG_A = 1, FLAG_P = 2;
+  __shared__ uint32_t smem[kBlock / kWave];
+  __shared__ uint32_t s_tile, s_prefix;
+  const uint64_t n = n_arg.get();
+  const uint64_t num_tiles = (n + kTile - 1) / kTile;
+  const uint32_t base = base_in ? *base_in : 0u; // read before anybody can overwrite it (total32_out may alias)
+  for (;;) {
+    if (threadIdx.x == 0) s_tile = atomicAdd(&ctl[0], 1u);
+    __syncthreads();
+    const uint64_t tile = s_tile;
+    if (tile >= num_tiles) break;
+    uint32_t v[ROUNDS], excl[ROUNDS];
+    uint32_t running = 0;
+#pragma unroll
+    for (uint32_t r = 0; r < ROUNDS; ++r) {
+      const uint64_t i = tile * kTile + r * kBlock + threadIdx.x;
+      v[r] = (i < n) ? value(i) : 0u;
+      uint32_t total;
+      excl[r] = running + block_exclusive_scan(v[r], smem, total);
+      running += total;
+    }
+    if (threadIdx.x < kWave) { // wave 0 publishes and looks back, 64 predecessors per step
+      const uint32_t lane = threadIdx.x;
+      uint32_t prefix = base;
+      if (tile == 0) {
+        if (lane == 0)
+          __hip_atomic_store(&desc[0], scan_desc(epoch, FLAG_P, base + running), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      } else {
+        if (lane == 0)
+          __hip_atomic_store(&desc[tile], scan_desc(epoch, FLAG_A, running), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        uint32_t acc = 0;
+        int64_t start = (int64_t)tile - 1; // nearest predecessor is read by lane 0
+        for (uint32_t spins = 0;; ++spins) {
+          if (spins > (1u << 22)) break; // bounded: a protocol error must not hang the GPU (result is then wrong, not stuck)
+          const int64_t t = start - (int64_t)lane;
+          unsigned long long d = scan_desc(epoch, FLAG_P, 0); // lanes past tile 0 read as "prefix 0"
+          if (t >= 0) d = __hip_atomic_load(&desc[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const uint32_t tag = (uint32_t)(d >> 32);
+          const bool ready = (tag >> 2) == epoch && (tag & 3u) != 0;
+          const uint64_t pmask = __ballot(ready && (tag & 3u) == FLAG_P);
+          const uint64_t rmask = __ballot(ready);
+          const uint32_t first_p = pmask ? (uint32_t)__builtin_ctzll(pmask) : 64u;
+          const uint64_t needed = first_p < 64u ? ((first_p == 63u) ? ~0ull : ((1ull << (first_p + 1)) - 1ull)) : ~0ull;
+          if ((rmask & needed) != needed) { // a descriptor between us and the nearest prefix is not written yet
+            __builtin_amdgcn_s_sleep(1);
+            continue;
+          }
+          const uint32_t mine = (lane <= first_p || first_p == 64u) ? (uint32_t)d : 0u;
+          acc += wave_reduce_sum(mine);
+          if (first_p < 64u) break;
+          start -= kWave;
+        }
+        prefix = acc; // already includes `base` through tile 0's inclusive prefix
+        if (lane == 0)
+          __hip_atomic_store(&desc[tile], scan_desc(epoch, FLAG_P, prefix + running), __ATOMIC_RELAXED,
+                             __HIP_MEMORY_SCOPE_AGENT);
+      }
+      if (lane == 0) {
+        s_prefix = prefix;
+        if (tile + 1 == num_tiles) { // the last tile knows the grand total
+          const uint32_t total = prefix + running;
+          if (total32_out) *total32_out = total;
+          if (total64_out) *total64_out = (uint64_t)(total - base);
+          if (mirror_a) *mirror_a = (uint64_t)total;
+          if (mirror_b) *mirror_b = (uint64_t)total;
+        }
+      }
+    }
+    __syncthreads();
+    const uint32_t prefix = s_prefix;
+#pragma unroll
+    for (uint32_t r = 0; r < ROUNDS; ++r) {
+      const uint64_t i = tile * kTile + r * kBlock + threadIdx.x;
+      if (i < n) emit(i, v[r], prefix + excl[r]);
+    }
+    __syncthreads(); // s_tile / s_prefix are rewritten next iteration
+  }
+  if (threadIdx.x == 0) {
+    if (num_tiles == 0 && blockIdx.x == 0) { // empty input: totals = base
+      if (total32_out) *total32_out = base;
+      if (total64_out) *total64_out = 0;
+      if (mirror_a) *mirror_a = (uint64_t)base;
+      if (mirror_b) *mirror_b = (uint64_t)base;
+    }
+    // the last block out re-arms the control words for the next launch on this scratch
+    if (atomicAdd(&ctl[1], 1u) == gridDim.x - 1) {
+      ctl[0] = 0;
+      ctl[1] = 0;
+    }
+  }
+}
+
+// ---- three-launch variant (reduce / prefix / apply): the default ----
 template <typename ValueF>
 __global__ __launch_bounds__(kBlock) void k_tile_reduce(ValueF value, Count n_arg, uint32_t *tile_sums) {
   __shared__ uint32_t smem[kBlock / kWave];
@@ -45,12 +169,6 @@ __global__ __launch_bounds__(kBlock) void k_tile_reduce(ValueF value, Count n_ar
   }
 }
 
-// One block.  tile_prefix[t] = base + sum_{u<t} tile_sums[u]; totals out.
-// mirror_a / mirror_b (optional): 64-bit copies of base + total (e.g. "frontier size" slots).
-__global__ __launch_bounds__(kBlock) void k_tile_prefix(const uint32_t *tile_sums, Count n_arg,
-                                                        uint32_t *tile_prefix, const uint32_t *base_in,
-                                                        uint32_t *total32_out, uint64_t *total64_out,
-                                                        uint64_t *mirror_a, uint64_t *mirror_b);
 
 template <typename ValueF, typename EmitF>
 __global__ __launch_bounds__(kBlock) void k_tile_apply(ValueF value, EmitF emit, Count n_arg,
@@ -73,21 +191,77 @@ __global__ __launch_bounds__(kBlock) void k_tile_apply(ValueF value, EmitF emit,
 }
 
 // Host helper: run the three phases on `stream`.  scratch: tile_scan_words(n_max) uint32.
+
+template <int DUMMY>
+__global__ __launch_bounds__(kBlock) void k_tile_prefix_t(const uint32_t *tile_sums, Count n_arg,
+                                                        uint32_t *tile_prefix, const uint32_t *base_in,
+                                                        uint32_t *total32_out, uint64_t *total64_out,
+                                                        uint64_t *mirror_a, uint64_t *mirror_b) {
+  __shared__ uint32_t smem[kBlock / kWave];
+  const uint64_t n = n_arg.get();
+  const uint64_t num_tiles = (n + kTile - 1) / kTile;
+  const uint32_t base = base_in ? *base_in : 0u;
+  uint32_t running = base;
+  for (uint64_t t0 = 0; t0 < num_tiles; t0 += kBlock) {
+    const uint64_t t = t0 + threadIdx.x;
+    const uint32_t v = (t < num_tiles) ? tile_sums[t] : 0u;
+    uint32_t total;
+    const uint32_t excl = block_exclusive_scan(v, smem, total);
+    if (t < num_tiles) tile_prefix[t] = running + excl;
+    running += total;
+  }
+  if (threadIdx.x == 0) {
+    tile_prefix[num_tiles] = running;
+    if (total32_out) *total32_out = running;
+    if (total64_out) *total64_out = (uint64_t)(running - base);
+    if (mirror_a) *mirror_a = (uint64_t)running;
+    if (mirror_b) *mirror_b = (uint64_t)running;
+  }
+}
+
+
+// Default: three launches.  A/B on MI355X (bench.py, same box): 0.403 ms vs 0.414 ms of sampling per batch for
+// the single-pass kernel -- the look-back saves a launch and one predicate evaluation but its 1-tile-per-block
+// latency chain costs as much -- and the three-launch form has no inter-workgroup wait at all.
+// GGMS_SCAN=1 selects the single-pass kernel.
+inline bool scan_three_pass() {
+  static const bool v = [] { const char *e = getenv("GGMS_SCAN"); return !(e && e[0] == '1'); }();
+  return v;
+}
+
+// Host helper.  scratch: tile_scan_words(n_max) uint32, 8-byte aligned; its control words must be zero
+// (clear_scratch = true issues the memset here; batch callers clear once and pass false).
+inline uint32_t *scan_align(uint32_t *p) { return (uint32_t *)(((uintptr_t)p + 7) & ~(uintptr_t)7); }
+
+inline int clear_scan_area(uint32_t *words, size_t n_max, hipStream_t stream) {
+  GGMS_HIP(hipMemsetAsync(scan_align(words), 0, (tile_scan_words(n_max) - 2) * sizeof(uint32_t), stream));
+  return GGMS_OK;
+}
+
 template <typename ValueF, typename EmitF>
-inline int tile_scan(ValueF value, EmitF emit, size_t n_max, Count n, uint32_t *scratch,
+inline int tile_scan(ValueF value, EmitF emit, size_t n_max, Count n, ScanArea area,
                      const uint32_t *base_in, uint32_t *total32_out, uint64_t *total64_out,
                      hipStream_t stream, uint64_t *mirror_a = nullptr, uint64_t *mirror_b = nullptr) {
   const size_t nt = num_tiles_for(n_max);
-  uint32_t *tile_sums = scratch;
-  uint32_t *tile_prefix = scratch + nt + 2;
+  uint32_t *ctl = scan_align(area.words); // 64-bit descriptors need 8-byte alignment
+  unsigned long long *desc = reinterpret_cast<unsigned long long *>(ctl + 8);
+  if (!area.cleared) {
+    int rc = clear_scan_area(area.words, n_max, stream);
+    if (rc != GGMS_OK) return rc;
+  }
   const int grid = grid_for(nt, 1);
-  hipLaunchKernelGGL((k_tile_reduce<ValueF>), dim3(grid), dim3(kBlock), 0, stream, value, n, tile_sums);
-  GGMS_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_tile_prefix, dim3(1), dim3(kBlock), 0, stream, tile_sums, n, tile_prefix, base_in,
-                     total32_out, total64_out, mirror_a, mirror_b);
-  GGMS_LAUNCH_CHECK();
-  hipLaunchKernelGGL((k_tile_apply<ValueF, EmitF>), dim3(grid), dim3(kBlock), 0, stream, value, emit, n,
-                     tile_prefix);
+  if (scan_three_pass()) { // tile_sums / tile_prefix live in the descriptor words (same footprint)
+    uint32_t *tile_sums = ctl + 8;
+    uint32_t *tile_prefix = tile_sums + nt + 1;
+    hipLaunchKernelGGL((k_tile_reduce<ValueF>), dim3(grid), dim3(kBlock), 0, stream, value, n, tile_sums);
+    hipLaunchKernelGGL((k_tile_prefix_t<0>), dim3(1), dim3(kBlock), 0, stream, tile_sums, n, tile_prefix, base_in,
+                       total32_out, total64_out, mirror_a, mirror_b);
+    hipLaunchKernelGGL((k_tile_apply<ValueF, EmitF>), dim3(grid), dim3(kBlock), 0, stream, value, emit, n, tile_prefix);
+    GGMS_LAUNCH_CHECK();
+    return GGMS_OK;
+  }
+  hipLaunchKernelGGL((k_tile_scan<ValueF, EmitF>), dim3(grid), dim3(kBlock), 0, stream, value, emit, n, ctl, desc,
+                     next_scan_epoch(), base_in, total32_out, total64_out, mirror_a, mirror_b);
   GGMS_LAUNCH_CHECK();
   return GGMS_OK;
 }
