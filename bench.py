@@ -38,6 +38,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batches", type=int, default=3)
     ap.add_argument("--host-profile", action="store_true", help="print host enqueue time per section to stderr")
+    ap.add_argument("--cache-ratio", type=float, default=1.0,
+                    help="fraction of feature rows (by degree rank) resident in HBM; the rest is gathered from "
+                         "pinned host memory by the same kernel (GGMS host tier). 1.0 = BASELINE configs[1]")
     return ap.parse_args()
 
 
@@ -141,17 +144,29 @@ def main():
 
     indptr, indices = to_dev(graph["indptr"]), to_dev(graph["indices"])
     g = ops.DeviceGraph(indptr, indices)
-    # features: feat[i, j] = float((i*dim + j) & 0xFFFF), generated on the device
-    feat = torch.arange(N * dim, dtype=torch.int64, device=dev).bitwise_and_(0xFFFF).to(torch.float32).view(N, dim)
     labels = (torch.arange(N, dtype=torch.int64, device=dev) % meta["num_class"]).contiguous()
-    # cache_ratio = 1.0, degree policy: slot r holds node rank[r]; table[node] = slot
+
+    def feat_rows(node_ids, out):
+        """feat[i, j] = float((i*dim + j) & 0xFFFF), generated in place for the given node ids."""
+        cols = torch.arange(dim, dtype=torch.int64, device=out.device)
+        step = 1 << 22
+        for lo in range(0, node_ids.numel(), step):
+            ids = node_ids[lo:lo + step].to(out.device, torch.int64)
+            out[lo:lo + step] = ((ids[:, None] * dim + cols[None, :]) & 0xFFFF).to(torch.float32)
+
+    # degree policy: cache slot r holds node rank[r] (r < num_cached); table[node] = slot or kEmptyKey
     rank_list = datagen.degree_rank(graph["indptr"])
     t_rank = to_dev(rank_list)
-    cache = ops.extract(feat, t_rank)
-    table = torch.empty(N, dtype=torch.int32, device=dev)
-    table[t_rank.long()] = torch.arange(N, dtype=torch.int32, device=dev)
-    del feat
+    num_cached = int(N * args.cache_ratio)
+    cache = torch.empty((max(num_cached, 1), dim), dtype=torch.float32, device=dev)
+    feat_rows(t_rank[:num_cached], cache)
+    table = torch.full((N,), -1, dtype=torch.int32, device=dev)  # 0xffffffff
+    table[t_rank[:num_cached].long()] = torch.arange(num_cached, dtype=torch.int32, device=dev)
     ptab = ops.part_pointer_table([cache], dev)
+    host_feat = None
+    if num_cached < N:  # host tier: the full table in pinned host memory, read zero-copy by the gather kernel
+        host_feat = torch.empty((N, dim), dtype=torch.float32, pin_memory=True)
+        feat_rows(torch.arange(N, dtype=torch.int64), host_feat)
 
     code = ops.KHOP3 if args.sample_type == "khop3" else ops.KHOP0
     sampler = ops.BatchSampler(g, fanouts, args.batch, sample_type=code, seed=0x5EED + rank, device=dev)
@@ -196,7 +211,7 @@ def main():
         if timed_idx is not None:
             ev[timed_idx][1].record()
         h3 = time.perf_counter()
-        ops.extract_cached(out, sampler.ht.n2o, table, ptab, 0, None, num=sampler.max_unique, num_dev=n_in,
+        ops.extract_cached(out, sampler.ht.n2o, table, ptab, 0, host_feat, num=sampler.max_unique, num_dev=n_in,
                            num_miss=nmiss)
         h4 = time.perf_counter()
         if timed_idx is not None:
@@ -265,7 +280,8 @@ def main():
             "config": {
                 "workload": f"{args.preset}-shaped power-law CSR N={N} E={meta['num_edge']} f32 dim {dim}, "
                             f"GraphSAGE fanout {fanouts} {args.sample_type}, batch {args.batch}, "
-                            f"graph+features in HBM (cache_ratio 1.0), seeds DP over {world} GPU(s)",
+                            f"graph in HBM, feature cache_ratio {args.cache_ratio} (rest in pinned host DRAM), "
+                            f"seeds DP over {world} GPU(s)",
                 "global_batch": args.batch * world,
                 "parallelism": f"dp{world}",
             },

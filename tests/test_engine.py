@@ -188,3 +188,34 @@ def test_arch6_two_workers_one_gpu(tmp_path, opts):
             for key, wv in want.items():
                 nmiss = int((~cached[wv["res"]["input_nodes"]]).sum())
                 assert float(npz[f"{key}:miss_bytes"]) == nmiss * d["feat"].shape[1] * 4
+
+
+@pytest.mark.gpu
+def test_cpp_driver_over_the_c_abi(tmp_path):
+    """A pure C++ caller (tools/samgraph_no_train.cc, the role of samgraph/main.cc) drives the same ABI."""
+    exe = os.path.join(ROOT, "build", "samgraph_no_train")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "xgnn_amd", "csrc"), "driver"])
+    d = make_dataset(tmp_path / "ds")
+    r = subprocess.run([exe, "--dataset-path", d["path"], "--batch-size", "64", "--num-epoch", "2", "--fanout", "5 4",
+                        "--seed", "3"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("[epoch")]
+    assert len(lines) == 2 and "8 steps" in lines[0]
+    # same seed => same number of sampled edges as the oracle replay
+    want = _oracle_batches(d, 0, 1, 64, 2, [5, 4], 3, arch6=False)
+    for ep, line in enumerate(lines):
+        ts = float(line.split("sample ")[1].split(" s")[0])
+        seps = float(line.split("-> ")[1].split(" M SEPS")[0])
+        edges = sum(sum(l["row"].size for l in w["res"]["layers"]) for k, w in want.items() if k // 8 == ep)
+        assert abs(seps * 1e6 * ts - edges) <= max(2e-3 * edges, 600)  # printed with 4/3 digits
+
+
+@pytest.mark.gpu
+def test_single_pass_scan_variant():
+    """GGMS_SCAN=1 selects the decoupled look-back form of every ordered scan: same results."""
+    env = dict(os.environ, GGMS_SCAN="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_parity.py"), "-m", "gpu",
+                        "-q", "-x", "-k", "hashtable or sample_batch_vs_oracle or get_miss_cache or weighted or khop3"],
+                       capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:]

@@ -22,10 +22,11 @@ def powerlaw_degrees(num_node, mean_deg, alpha, dmax, rng):
     """d_v = min(dmax, floor(c * u^-alpha)), c tuned so that the mean is mean_deg."""
     u = rng.random_sample(num_node)
     base = u ** (-alpha)
+    calib = base if num_node <= (1 << 22) else base[:: num_node // (1 << 22)]  # calibrate c on a subsample
     lo, hi = 1e-3, 1e6
     for _ in range(60):  # bisection on c
         c = 0.5 * (lo + hi)
-        m = np.minimum(dmax, np.floor(c * base)).mean()
+        m = np.minimum(dmax, np.floor(c * calib)).mean()
         if m < mean_deg:
             lo = c
         else:
