@@ -36,8 +36,11 @@ def parse():
     ap.add_argument("--fanout", default="25,10")
     ap.add_argument("--sample-type", default="khop3", choices=["khop3", "khop0"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-batches", type=int, default=3)
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline: keep sampling mini-batches this long")
     ap.add_argument("--host-profile", action="store_true", help="print host enqueue time per section to stderr")
+    ap.add_argument("--no-overlap", action="store_true",
+                    help="one stream: extract of batch k and sampling of batch k+1 run back to back "
+                         "(default: two streams, the HBM-bound gather overlaps the latency-bound sampler)")
     ap.add_argument("--cache-ratio", type=float, default=1.0,
                     help="fraction of feature rows (by degree rank) resident in HBM; the rest is gathered from "
                          "pinned host memory by the same kernel (GGMS host tier). 1.0 = BASELINE configs[1]")
@@ -68,9 +71,9 @@ def measured_traffic():
     return d
 
 
-def cpu_baseline(graph, fanouts, batch, feat_dim, n_batches):
+def cpu_baseline(graph, fanouts, batch, feat_dim, seconds):
     """CPU leg: the oracle (port) and, when shipped, the reference's own CPU leaves (oracle/_ref).
-    Bounded sample: n_batches mini-batches of the same workload on all host cores."""
+    Bounded sample: mini-batches of the same workload on the usable host cores for about `seconds` of CPU work."""
     import oracle
     cores = usable_cores()
     ip, ix, train = graph["indptr"], graph["indices"], graph["train_set"]
@@ -81,7 +84,14 @@ def cpu_baseline(graph, fanouts, batch, feat_dim, n_batches):
     extract = oracle.ref_cpu_extract if have_ref else oracle.extract
     t_sample = t_remap = t_extract = 0.0
     edges = rows = 0
-    for b in range(n_batches):
+    n_batches = 0
+    per_epoch = max(1, len(train) // batch)
+    t_begin = time.perf_counter()
+    while time.perf_counter() - t_begin < seconds or n_batches < 3:
+        b = n_batches % per_epoch
+        if b == 0 and n_batches:
+            train = train[np.random.RandomState(n_batches).permutation(len(train))]
+        n_batches += 1
         seeds = train[b * batch:(b + 1) * batch]
         ht = oracle.HashTable(n_node, oracle.predict_num_nodes(len(seeds), fanouts, len(fanouts)) + 1)
         t0 = time.perf_counter()
@@ -169,12 +179,16 @@ def main():
         feat_rows(torch.arange(N, dtype=torch.int64), host_feat)
 
     code = ops.KHOP3 if args.sample_type == "khop3" else ops.KHOP0
-    sampler = ops.BatchSampler(g, fanouts, args.batch, sample_type=code, seed=0x5EED + rank, device=dev)
-    out = torch.empty((sampler.max_unique, dim), dtype=torch.float32, device=dev)
-    out_label = torch.empty(sampler.max_seeds, dtype=torch.int64, device=dev)
+    NSLOT = 2  # batch slots, as in the engine: outputs of batch k stay valid while batch k+1 is sampled
+    sampler = ops.BatchSampler(g, fanouts, args.batch, sample_type=code, seed=0x5EED + rank, device=dev,
+                               num_slots=NSLOT)
+    out = [torch.empty((sampler.max_unique, dim), dtype=torch.float32, device=dev) for _ in range(NSLOT)]
+    out_label = [torch.empty(sampler.max_seeds, dtype=torch.int64, device=dev) for _ in range(NSLOT)]
     nmiss = torch.zeros(1, dtype=torch.int64, device=dev)
     L = len(fanouts)
-    n_in = sampler.counts[3 * L:3 * L + 1]  # device count of input nodes (view)
+    s_sample = torch.cuda.Stream(device=dev)
+    s_extract = s_sample if args.no_overlap else torch.cuda.Stream(device=dev)
+    slot_free = [None] * NSLOT  # event: the slot's previous extract has finished
 
     # DistAlignedShuffler semantics (dist_shuffler_aligned.cc:37-146): pad to a multiple of world,
     # same permutation on every rank, contiguous slice per rank
@@ -196,29 +210,42 @@ def main():
     all_seeds = [batch_seeds(s) for s in range(args.warmup + args.steps)]
 
     acc = torch.zeros(3 * L + 1, dtype=torch.int64, device=dev)
-    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
-
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(args.steps)]
     host_t = [0.0] * 6
 
     def run_step(step, timed_idx=None):
         seeds = all_seeds[step]
+        slot = step % NSLOT
         h0 = time.perf_counter()
-        if timed_idx is not None:
-            ev[timed_idx][0].record()
-        h1 = time.perf_counter()
-        sampler.sample(seeds)
-        h2 = time.perf_counter()
-        if timed_idx is not None:
-            ev[timed_idx][1].record()
+        with torch.cuda.stream(s_sample):
+            if slot_free[slot] is not None:
+                s_sample.wait_event(slot_free[slot])
+            if timed_idx is not None:
+                ev[timed_idx][0].record(s_sample)
+            h1 = time.perf_counter()
+            sampler.sample(seeds, slot=slot, copy_input_nodes=True)
+            h2 = time.perf_counter()
+            sampled = torch.cuda.Event()
+            sampled.record(s_sample)
+            if timed_idx is not None:
+                ev[timed_idx][1].record(s_sample)
         h3 = time.perf_counter()
-        ops.extract_cached(out, sampler.ht.n2o, table, ptab, 0, host_feat, num=sampler.max_unique, num_dev=n_in,
-                           num_miss=nmiss)
-        h4 = time.perf_counter()
-        if timed_idx is not None:
-            ev[timed_idx][2].record()
-        ops.extract(labels, seeds, out=out_label[:seeds.numel()])
-        h5 = time.perf_counter()
-        acc.add_(sampler.counts)
+        with torch.cuda.stream(s_extract):
+            s_extract.wait_event(sampled)
+            counts = sampler.counts_slots[slot]
+            if timed_idx is not None:
+                ev[timed_idx][2].record(s_extract)
+            ops.extract_cached(out[slot], sampler.input_nodes[slot], table, ptab, 0, host_feat,
+                               num=sampler.max_unique, num_dev=counts[3 * L:3 * L + 1], num_miss=nmiss)
+            if timed_idx is not None:
+                ev[timed_idx][3].record(s_extract)
+            h4 = time.perf_counter()
+            ops.extract(labels, seeds, out=out_label[slot][:seeds.numel()])
+            h5 = time.perf_counter()
+            acc.add_(counts)
+            done = torch.cuda.Event()
+            done.record(s_extract)
+            slot_free[slot] = done
         h6 = time.perf_counter()
         for i, (a, b) in enumerate([(h0, h1), (h1, h2), (h2, h3), (h3, h4), (h4, h5), (h5, h6)]):
             host_t[i] += b - a
@@ -243,11 +270,26 @@ def main():
         names = ["ev0", "sample", "ev1", "extract_cached", "ev2+label", "acc"]
         print("host enqueue ms/step:", {n: round(1e3 * t / (args.steps + args.warmup), 4) for n, t in zip(names, host_t)},
               file=sys.stderr)
+    # the same gather with nothing beside it (one stream), for reference next to the in-pipeline figure
+    serial_us = None
+    if not args.no_overlap:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        reps = 10
+        counts = sampler.counts_slots[(args.warmup + args.steps - 1) % NSLOT]
+        slot = (args.warmup + args.steps - 1) % NSLOT
+        e0.record()
+        for _ in range(reps):
+            ops.extract_cached(out[slot], sampler.input_nodes[slot], table, ptab, 0, host_feat,
+                               num=sampler.max_unique, num_dev=counts[3 * L:3 * L + 1], num_miss=nmiss)
+        e1.record()
+        torch.cuda.synchronize()
+        serial_us = e0.elapsed_time(e1) / reps * 1e3
+        serial_rows = int(counts[3 * L].item())
     c = acc.cpu().tolist()
     edges = sum(c[3 * i] for i in range(L))
     rows = c[3 * L]
-    t_sample_ms = sum(e[0].elapsed_time(e[1]) for e in ev)
-    t_extract_ms = sum(e[1].elapsed_time(e[2]) for e in ev)
+    t_sample_ms = sum(e[0].elapsed_time(e[1]) for e in ev)   # on the sampling stream
+    t_extract_ms = sum(e[2].elapsed_time(e[3]) for e in ev)  # HIP events on the stream the gather is launched on
 
     stats = torch.tensor([elapsed, float(edges), float(rows), t_sample_ms, t_extract_ms], dtype=torch.float64,
                          device=dev)
@@ -284,6 +326,7 @@ def main():
                             f"seeds DP over {world} GPU(s)",
                 "global_batch": args.batch * world,
                 "parallelism": f"dp{world}",
+                "streams": "1 (serial)" if args.no_overlap else "2 (extract of batch k overlaps sampling of batch k+1)",
             },
             "feature_extract_GBps": rows_all * row_bytes / (t_extract_ms / 1e3) / 1e9 if world == 1
             else rows_all * row_bytes / elapsed / 1e9,
@@ -302,9 +345,14 @@ def main():
                 "avg_launch_us": avg_launch_s * 1e6,
                 "traffic_source": tr["source"] if tr else None,
             },
+            "roofline_alone": None if serial_us is None else {
+                "note": "same kernel, last batch's rows, nothing running beside it (10 launches after the timed region)",
+                "avg_launch_us": serial_us, "achieved": serial_rows * (4 + 2 * row_bytes) / (serial_us * 1e-6) / 1e9,
+                "frac": serial_rows * (4 + 2 * row_bytes) / (serial_us * 1e-6) / 1e9 / 8000.0,
+            },
         }
         if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(graph, fanouts, args.batch, dim, args.cpu_batches)
+            res["cpu_baseline"] = cpu_baseline(graph, fanouts, args.batch, dim, args.cpu_seconds)
         print(json.dumps(res))
     if world > 1:
         dist.destroy_process_group()

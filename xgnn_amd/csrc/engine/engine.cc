@@ -374,6 +374,7 @@ void Engine::SampleInit(int worker_id, const std::string &ctx) {
   device_ = parse_device(ctx);
   SAM_HIP(hipSetDevice(device_));
   SAM_HIP(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+  SAM_HIP(hipStreamCreateWithFlags(&stream_extract_, hipStreamNonBlocking));
   UploadGraph();
   ShufflerInit();
   const uint32_t L = (uint32_t)cfg.fanout.size();
@@ -523,6 +524,7 @@ void Engine::Shutdown() {
   pool_cv_.notify_all();
   if (bg_.joinable()) bg_.join();
   if (stream_) (void)hipStreamSynchronize(stream_);
+  if (stream_extract_) (void)hipStreamSynchronize(stream_extract_);
 }
 
 // ------------------------------------------------------------------ hot loop
@@ -560,24 +562,30 @@ void Engine::RunSampleOnce() {
   SAM_GGMS(ggms_sample_batch(cfg.sample_type, &graph_, b->output_nodes, b->num_seeds, cfg.fanout.data(), L, &ht_,
                              states_, num_states_, b->row.data(), b->col.data(), b->counts_dev, &extra, ws_, ws_bytes_,
                              stream_));
-  SAM_HIP(hipEventRecord(b->ev_sampled, stream_));
   uint64_t *n_in = b->counts_dev + 3 * L, *n_miss = b->counts_dev + 3 * L + 1;
   SAM_HIP(hipMemsetAsync(n_miss, 0, 8, stream_));
-  // input nodes = the table's unique list (task->input_nodes, dist_loops.cc:357); it is overwritten by the
-  // next batch, so the slot keeps its own copy
+  // input nodes = the table's unique list (task->input_nodes, dist_loops.cc:357); the next batch's sampling
+  // overwrites it, so the slot keeps its own copy and the gather below reads that copy
   SAM_GGMS(ggms_gather_scatter(b->input_nodes, ht_.n2o, nullptr, nullptr, max_unique_, n_in, 1, GGMS_I32, stream_));
+  SAM_HIP(hipEventRecord(b->ev_sampled, stream_));
+  // The gather is HBM-bound, the sampler latency-bound: they run on separate streams so that batch k's
+  // extract overlaps batch k+1's sampling (the reference serialises them, dist_loops_arch6.cc:248-251)
+  hipStream_t xs = stream_extract_;
+  SAM_HIP(hipStreamWaitEvent(xs, b->ev_sampled, 0));
   if (cfg.UseGPUCache()) {
     // DoArch6GetCacheMissIndex + DoArch6GPUCacheFeatureCopy (dist_loops.cc:1015-1285) in one pass
-    SAM_GGMS(ggms_extract_cached(b->feat, ht_.n2o, max_unique_, n_in, cache_table_, (const void *const *)d_cache_parts_tab_,
-                                 num_cache_part_, feat_src_, ds.feat_dim, ds.feat_dtype, n_miss, stream_));
+    SAM_GGMS(ggms_extract_cached(b->feat, b->input_nodes, max_unique_, n_in, cache_table_,
+                                 (const void *const *)d_cache_parts_tab_, num_cache_part_, feat_src_, ds.feat_dim,
+                                 ds.feat_dtype, n_miss, xs));
   } else {
     // DoGPUFeatureExtract (cuda/cuda_loops.cc, dist_loops.cc:585-634)
-    SAM_GGMS(ggms_gather_scatter(b->feat, feat_src_, ht_.n2o, nullptr, max_unique_, n_in, ds.feat_dim, ds.feat_dtype, stream_));
+    SAM_GGMS(ggms_gather_scatter(b->feat, feat_src_, b->input_nodes, nullptr, max_unique_, n_in, ds.feat_dim,
+                                 ds.feat_dtype, xs));
   }
   // DoGPULabelExtract, dist_loops.cc:938-974
-  SAM_GGMS(ggms_extract(b->label, label_src_, b->output_nodes, b->num_seeds, 1, GGMS_I64, stream_));
-  SAM_HIP(hipMemcpyAsync(b->counts, b->counts_dev, (3 * L + 4) * 8, hipMemcpyDeviceToHost, stream_));
-  SAM_HIP(hipEventRecord(b->ev_done, stream_));
+  SAM_GGMS(ggms_extract(b->label, label_src_, b->output_nodes, b->num_seeds, 1, GGMS_I64, xs));
+  SAM_HIP(hipMemcpyAsync(b->counts, b->counts_dev, (3 * L + 4) * 8, hipMemcpyDeviceToHost, xs));
+  SAM_HIP(hipEventRecord(b->ev_done, xs));
   {
     std::lock_guard<std::mutex> lk(pool_mu_);
     pool_.push_back(b); // graph_pool->Submit

@@ -177,7 +177,8 @@ class Engine {
 
   bool data_ready_ = false, sample_ready_ = false, train_ready_ = false, shutdown_ = false;
   int worker_id_ = 0, device_ = 0;
-  hipStream_t stream_ = nullptr;
+  hipStream_t stream_ = nullptr;         // shuffle + sampling (latency-bound)
+  hipStream_t stream_extract_ = nullptr; // feature / label gather (HBM-bound): overlaps the next batch's sampling
   // device graph
   uint32_t *d_indptr_ = nullptr, *d_indices_ = nullptr;
   std::vector<void *> part_indptr_, part_indices_; // P+1 entries (slot P = host CSR)

@@ -195,7 +195,13 @@ static int launch_gather(char *out, Rows rows, const uint32_t *dst_index, size_t
   static const bool env_nts = [] { const char *e = getenv("GGMS_EXTRACT_NT_STORE"); return !(e && e[0] == '0'); }();
   const bool nt = env_nt;
   const uint32_t magic = rc == 1 ? 0u : (uint32_t)(((1ull << 32) + rc - 1) / rc);
-  const int grid = grid_for(n_max, kBlock); // one wave per 64 rows
+  // one wave per 64 rows, grid-stride.  The grid is capped at ONE 4-wave block per CU (GGMS_EXTRACT_BLOCKS,
+  // default 256): with 8 x 16-B loads per lane in flight that already streams at the rate of a full-occupancy
+  // launch (measured 236 us vs 244 us at 2048 blocks, products batch), and the free wave slots let the next
+  // batch's latency-bound sampling kernels run beside the gather on another stream (step 0.68 -> 0.55 ms).
+  static const int max_blocks = [] { const char *e = getenv("GGMS_EXTRACT_BLOCKS"); int v = e ? atoi(e) : 256; return v > 0 ? v : 256; }();
+  int grid = grid_for(n_max, kBlock);
+  if (grid > max_blocks) grid = max_blocks;
 #define GGMS_LAUNCH(CB, ID, NT)                                                                         \
   do {                                                                                                   \
     if (env_nts)                                                                                         \

@@ -265,7 +265,7 @@ class BatchSampler:
 
     def __init__(self, graph, fanouts, batch_size, sample_type=KHOP3, seed=0, device="cuda", direct_table=True,
                  prob_table=None, alias_table=None, random_walk_length=0, random_walk_restart_prob=0.0,
-                 num_random_walk=0):
+                 num_random_walk=0, num_slots=1):
         self.graph, self.fanouts, self.sample_type = graph, [int(f) for f in fanouts], sample_type
         L = len(self.fanouts)
         self.L = L
@@ -281,11 +281,19 @@ class BatchSampler:
         if sample_type == RANDOM_WALK:
             nstates = max(nstates, lib().ggms_random_walk_num_states(max(self.max_input), num_random_walk))
         self.states = random_states(nstates, seed, device) if sample_type != KHOP0 else None
-        self.row = [torch.empty(max(1, e), dtype=torch.int32, device=device) for e in self.max_edges]
-        self.col = [torch.empty(max(1, e), dtype=torch.int32, device=device) for e in self.max_edges]
-        self._row = (C.c_void_p * L)(*[t.data_ptr() for t in self.row])
-        self._col = (C.c_void_p * L)(*[t.data_ptr() for t in self.col])
-        self.counts = torch.zeros(3 * L + 1, dtype=torch.int64, device=device)
+        # output slots (the engine's batch slots): a batch's COO / counts / input-node copy stay valid while the
+        # next batch is being sampled
+        self.num_slots = num_slots
+        self.rows = [[torch.empty(max(1, e), dtype=torch.int32, device=device) for e in self.max_edges]
+                     for _ in range(num_slots)]
+        self.cols = [[torch.empty(max(1, e), dtype=torch.int32, device=device) for e in self.max_edges]
+                     for _ in range(num_slots)]
+        self._rows = [(C.c_void_p * L)(*[t.data_ptr() for t in r]) for r in self.rows]
+        self._cols = [(C.c_void_p * L)(*[t.data_ptr() for t in c]) for c in self.cols]
+        self.counts_slots = [torch.zeros(3 * L + 1, dtype=torch.int64, device=device) for _ in range(num_slots)]
+        self.input_nodes = [torch.empty(self.max_unique, dtype=torch.int32, device=device) for _ in range(num_slots)]
+        self.row, self.col, self.counts = self.rows[0], self.cols[0], self.counts_slots[0]
+        self._row, self._col = self._rows[0], self._cols[0]
         self.extra = None
         self.data = None
         self._keep = (prob_table, alias_table)
@@ -304,17 +312,22 @@ class BatchSampler:
         self.ws = _workspace(lib().ggms_sample_batch_workspace_bytes(sample_type, self.max_seeds, self._f, L,
                                                                      self._extra_ref), device)
 
-    def sample(self, seeds):
-        """Enqueue one batch; returns nothing -- read self.counts / row / col / ht.n2o after a sync."""
+    def sample(self, seeds, slot=0, copy_input_nodes=False):
+        """Enqueue one batch into output slot `slot`; read counts / row / col / ht.n2o after a sync.
+        copy_input_nodes: also copy the unique list (ht.n2o, reused by the next batch) into the slot."""
         _i32(seeds)
         n = seeds.numel()
         assert n <= self.max_seeds
+        counts = self.counts_slots[slot]
         check(lib().ggms_sample_batch(self.sample_type, C.byref(self.graph.c), _ptr(seeds), n, self._f, self.L,
                                       C.byref(self.ht.c), _ptr(self.states),
-                                      self.states.shape[0] if self.states is not None else 0, self._row, self._col,
-                                      _ptr(self.counts), self._extra_ref, _ptr(self.ws), self.ws.numel() * 4,
-                                      _stream()),
+                                      self.states.shape[0] if self.states is not None else 0, self._rows[slot],
+                                      self._cols[slot], _ptr(counts), self._extra_ref, _ptr(self.ws),
+                                      self.ws.numel() * 4, _stream()),
               "ggms_sample_batch")
+        if copy_input_nodes:
+            gather_scatter(self.input_nodes[slot], self.ht.n2o, None, None, num=self.max_unique,
+                           num_dev=counts[3 * self.L:3 * self.L + 1])
 
     def result(self):
         """Sync and slice the outputs (host round trip: for tests and hand-off, not for the hot loop)."""
