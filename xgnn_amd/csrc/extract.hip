@@ -173,6 +173,13 @@ __global__ __launch_bounds__(kBlock) void k_gather_rows(char *__restrict__ out, 
   }
 }
 
+// identity copy of `n` rows (src_index == dst_index == NULL): plain coalesced stream, count on the device
+__global__ __launch_bounds__(kBlock) void k_copy_words(uint32_t *__restrict__ dst, const uint32_t *__restrict__ src,
+                                                       Count n_arg, uint32_t words_per_row) {
+  const uint64_t n = n_arg.get() * words_per_row;
+  for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (uint64_t)gridDim.x * kBlock) dst[i] = src[i];
+}
+
 static inline int pick_chunk(size_t row_bytes, uintptr_t align_bits) {
   for (int cb = 16; cb > 1; cb >>= 1)
     if (row_bytes % cb == 0 && (align_bits % cb) == 0) return cb;
@@ -258,6 +265,12 @@ int ggms_gather_scatter(void *out, const void *src, const ggms_id_t *src_index, 
   if (num == 0) return GGMS_OK;
   GGMS_CHECK_ARG(out && src);
   const size_t row_bytes = dim * es;
+  if (!src_index && !dst_index && row_bytes % 4 == 0 && (((uintptr_t)out | (uintptr_t)src) & 3) == 0) {
+    hipLaunchKernelGGL(k_copy_words, dim3(grid_for(num * (row_bytes / 4), kBlock * 4)), dim3(kBlock), 0, to_stream(stream),
+                       (uint32_t *)out, (const uint32_t *)src, count_of(num, num_dev), (uint32_t)(row_bytes / 4));
+    GGMS_LAUNCH_CHECK();
+    return GGMS_OK;
+  }
   const int cb = pick_chunk(row_bytes, (uintptr_t)out | (uintptr_t)src);
   PlainRows rows{(const char *)src, src_index, row_bytes};
   return launch_gather((char *)out, rows, dst_index, num, count_of(num, num_dev), row_bytes, cb, nullptr,

@@ -177,6 +177,7 @@ int ht_fill_impl(const ggms_hashtable_t *ht, const uint32_t *input, size_t n_max
   if (ht->direct) {
     hipLaunchKernelGGL(k_ht_insert<true>, dim3(grid), dim3(kBlock), 0, s, t, input, n, item_pos);
     GGMS_LAUNCH_CHECK();
+    scratch.stash = item_pos; // the direct layout does not use item_pos: it holds the owner flags between passes
     return tile_scan(OwnerFlag<true>{t, input}, AssignLocal<true>{t, input, input}, n_max, n, scratch,
                      ht->num_items_dev, ht->num_items_dev, nullptr, s, mirror_a, mirror_b);
   }

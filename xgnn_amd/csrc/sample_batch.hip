@@ -127,7 +127,7 @@ int ggms_sample_batch(int sample_type, const ggms_graph_t *graph, const ggms_id_
   // cleared once here: descriptors are epoch-tagged, the control words re-arm themselves
   ScanArea scan{w, true};
   const size_t scan_items = std::max(c.max_e_all, c.max_in_all);
-  {
+  if (!scan_three_pass()) { // only the single-pass form keeps control words in the area
     int rc0 = clear_scan_area(scan.words, scan_items, s);
     if (rc0 != GGMS_OK) return rc0;
   }
