@@ -137,10 +137,17 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (MI355X); there is no CPU fallback for the product path")
-    torch.cuda.set_device(local_rank)
+    # test hooks (one-GPU box): GGMS_BENCH_DEVICE pins every rank to one device, GGMS_BENCH_BACKEND=gloo avoids
+    # RCCL's one-rank-per-GPU rule.  The driver's multi-GPU runs use neither: one rank per GPU over RCCL.
+    dev_index = int(os.environ.get("GGMS_BENCH_DEVICE", local_rank))
+    backend = os.environ.get("GGMS_BENCH_BACKEND", "nccl")
+    torch.cuda.set_device(dev_index)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    dev = torch.device("cuda", local_rank)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend)
+    dev = torch.device("cuda", dev_index)
 
     from xgnn_amd import datagen, ops, parallel
 
@@ -291,10 +298,13 @@ def main():
     t_sample_ms = sum(e[0].elapsed_time(e[1]) for e in ev)   # on the sampling stream
     t_extract_ms = sum(e[2].elapsed_time(e[3]) for e in ev)  # HIP events on the stream the gather is launched on
 
-    stats = torch.tensor([elapsed, float(edges), float(rows), t_sample_ms, t_extract_ms], dtype=torch.float64,
-                         device=dev)
+    feat_rate = rows * dim * 4 / (t_extract_ms / 1e3) / 1e9  # this rank's GB/s over its own gather time
+    stats = torch.tensor([elapsed, float(edges), float(rows), t_sample_ms, t_extract_ms, feat_rate],
+                         dtype=torch.float64, device=dev)
+    if world > 1 and backend != "nccl":
+        stats = stats.cpu()
     mx, sm = parallel.reduce_stats(stats, dist if world > 1 else None)
-    elapsed, edges_all, rows_all = mx[0].item(), sm[1].item(), sm[2].item()
+    elapsed, edges_all, rows_all, feat_rate_all = mx[0].item(), sm[1].item(), sm[2].item(), sm[5].item()
 
     if rank == 0:
         row_bytes = dim * 4
@@ -328,8 +338,7 @@ def main():
                 "parallelism": f"dp{world}",
                 "streams": "1 (serial)" if args.no_overlap else "2 (extract of batch k overlaps sampling of batch k+1)",
             },
-            "feature_extract_GBps": rows_all * row_bytes / (t_extract_ms / 1e3) / 1e9 if world == 1
-            else rows_all * row_bytes / elapsed / 1e9,
+            "feature_extract_GBps": feat_rate_all,  # sum over ranks of rows*dim*4 / (time inside the gather kernel)
             "per_gpu": {
                 "sample_ms_per_step": t_sample_ms / args.steps,
                 "extract_ms_per_step": t_extract_ms / args.steps,
