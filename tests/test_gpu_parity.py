@@ -374,3 +374,53 @@ def test_sample_batch_weighted_and_random_walk(ops, stype):
             np.testing.assert_array_equal(host_u32(gl["col"]), wl["col"])
             if stype == "random_walk":
                 np.testing.assert_array_equal(host_u32(gl["data"]), wl["data"])
+
+
+def test_full_size_batch_properties(ops):
+    """BASELINE configs[1] size (products-shaped, batch 8000, fanout [25,10]): size-independent properties
+    instead of an oracle replay -- determinism, hashed == direct table, structural validity of the COO."""
+    from xgnn_amd import datagen
+    g = datagen.make_graph("products", seed=42)
+    ip, ix = g["indptr"], g["indices"]
+    N = ip.size - 1
+    graph = ops.DeviceGraph(dev(ip), dev(ix))
+    seeds = g["train_set"][:8000]
+    results = []
+    for direct in (True, False, True):
+        bs = ops.BatchSampler(graph, [25, 10], 8000, sample_type=ops.KHOP3, seed=0x5EED, direct_table=direct)
+        bs.sample(dev(seeds))
+        r = bs.result()
+        results.append(dict(inp=host_u32(r["input_nodes"]).copy(),
+                            layers=[(host_u32(l["row"]).copy(), host_u32(l["col"]).copy(), l["num_src"], l["num_dst"])
+                                    for l in r["layers"]]))
+    a = results[0]
+    for b in results[1:]:  # same seeds + same RNG seed: bit-identical, whatever the table layout
+        np.testing.assert_array_equal(a["inp"], b["inp"])
+        for la, lb in zip(a["layers"], b["layers"]):
+            np.testing.assert_array_equal(la[0], lb[0])
+            np.testing.assert_array_equal(la[1], lb[1])
+            assert la[2:] == lb[2:]
+    inp = a["inp"]
+    assert np.unique(inp).size == inp.size                      # dedup: no node twice
+    np.testing.assert_array_equal(inp[:8000], seeds)            # seeds keep local ids 0..7999 (prefix stability)
+    deg = (ip[1:].astype(np.int64) - ip[:-1].astype(np.int64))
+    (row1, col1, nsrc1, ndst1), (row0, col0, nsrc0, ndst0) = a["layers"][1], a["layers"][0]
+    assert ndst1 == 8000 and ndst0 == nsrc1 and nsrc0 == inp.size and nsrc1 <= nsrc0
+    for row, col, nsrc, ndst in a["layers"]:
+        assert row.max() < nsrc and col.max() < ndst
+        # per seed exactly min(deg, fanout) edges, seeds in order
+        assert (np.diff(col.astype(np.int64)) >= 0).all()
+    cnt1 = np.bincount(col1, minlength=ndst1)
+    np.testing.assert_array_equal(cnt1, np.minimum(deg[inp[:ndst1]], 10))
+    cnt0 = np.bincount(col0, minlength=ndst0)
+    np.testing.assert_array_equal(cnt0, np.minimum(deg[inp[:ndst0]], 25))
+    # every sampled edge exists in the CSR: neighbour inp[row] is in the list of seed inp[col] (sampled check)
+    rng = np.random.RandomState(0)
+    for e in rng.randint(0, row0.size, 2000):
+        s, d = inp[col0[e]], inp[row0[e]]
+        assert d in ix[ip[s]:ip[s + 1]]
+    # first occurrence order: local ids of new nodes increase with the position of their first edge
+    first_pos = np.full(nsrc0, row0.size, np.int64)
+    np.minimum.at(first_pos, row0, np.arange(row0.size))
+    new = np.arange(ndst0, nsrc0)
+    assert (np.diff(first_pos[new]) > 0).all()
