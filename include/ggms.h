@@ -245,6 +245,10 @@ int ggms_extract(void *dst, const void *src, const ggms_id_t *index,
  * Feature cache -- GPUCacheManager, cuda/cuda_cache_manager_device.cu.
  * table[node] = cache slot or kEmptyKey.
  * ------------------------------------------------------------------------- */
+/* presample ranking (dist/pre_sampler.cc:79-111): freq[nodes[i]] += 1 (the reference copies the batch's
+ * input nodes to the host and counts there); num may be overridden by a device count. */
+int ggms_count_nodes(uint32_t *freq, const ggms_id_t *nodes, size_t num_nodes,
+                     const uint64_t *num_nodes_dev, ggms_stream_t stream);
 size_t ggms_cache_index_workspace_bytes(size_t num_nodes);
 /* GetMissCacheIndex :355-441 (kernels :40-169): stable split of `nodes` into
  * miss (src = global id, dst = output row) and hit (src = slot, dst = row). */

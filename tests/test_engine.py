@@ -58,7 +58,7 @@ sam.config({{'dataset_path': '/nonexistent', '_arch': 1}})
 
 
 def _oracle_batches(d, worker_id, num_worker, batch_size, num_epoch, fanouts, seed, arch6, sample_type="khop3",
-                    nstates=None, **kw):
+                    nstates=None, states=None, **kw):
     """Replays shuffler + sampler + extract on the CPU exactly as the engine is specified to."""
     train = d["train"]
     padded = oracle.aligned_pad(train, num_worker)
@@ -72,7 +72,8 @@ def _oracle_batches(d, worker_id, num_worker, batch_size, num_epoch, fanouts, se
         nstates = min(oracle.predict_num_nodes(max_seeds, fanouts, len(fanouts)), 512 * 1024)
     if sample_type == "random_walk":
         nstates = (oracle.predict_num_nodes(max_seeds, fanouts, len(fanouts) - 1) + 63) // 64 * 256
-    states = oracle.random_states(nstates, seed + 1000003 * worker_id)
+    if states is None:
+        states = oracle.random_states(nstates, seed + 1000003 * worker_id)
     data = padded.copy()
     out = {}
     for ep in range(num_epoch):
@@ -219,3 +220,40 @@ def test_single_pass_scan_variant():
                         "-q", "-x", "-k", "hashtable or sample_batch_vs_oracle or get_miss_cache or weighted or khop3"],
                        capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-2000:]
+
+
+@pytest.mark.gpu
+def test_arch6_presample_cache_policy(tmp_path):
+    """cache_policy = pre_sample (dist/pre_sampler.cc:39-139): worker 0 samples `presample_epoch` epochs of the
+    whole train set, ranks nodes by (visit count << 32 | id) descending, and that ranking fills the cache."""
+    d = make_dataset(tmp_path / "ds")
+    prefix = str(tmp_path / "out")
+    env = dict(os.environ, SAMGRAPH_FORCE_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    seed, bs, fan, ratio = 17, 64, [5, 4], 0.3
+    r = subprocess.run([sys.executable, DRIVER, d["path"], prefix, "arch6", "2", f"seed={seed}", f"batch_size={bs}",
+                        "fanout=5 4", "cache_policy=pre_sample", "presample_epoch=2", f"cache_percentage={ratio}",
+                        "part_cache=True", "gpu_extract=True"], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    # oracle replay of the presample on worker 0's RNG states
+    max_seeds = int(bs * 1.25) + 1
+    nst = oracle.predict_num_nodes(max_seeds, fan, len(fan) - 1)
+    st0 = oracle.random_states(nst, seed)
+    N = d["ip"].size - 1
+    freq = np.zeros(N, np.uint64)
+    train = d["train"].copy()
+    for e in range(2):
+        train = oracle.shuffle_minstd0(train, seed + 0x5A5A5A + e)
+        for off in range(0, train.size, bs):
+            res = oracle.do_sample(oracle.KHOP3, d["ip"], d["ix"], train[off:off + bs], fan, st0)
+            freq[res["input_nodes"]] += 1
+    keys = (freq << np.uint64(32)) | np.arange(N, dtype=np.uint64)
+    rank = (np.sort(keys)[::-1] & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+    cached = np.zeros(N, bool)
+    cached[rank[: int(N * ratio)]] = True
+    for w in range(2):
+        want = _oracle_batches(d, w, 2, bs, 2, fan, seed, arch6=True, states=st0 if w == 0 else None)
+        npz = np.load(f"{prefix}.w{w}.npz")
+        _check(npz, want, 2)
+        for key, wv in want.items():
+            nmiss = int((~cached[wv["res"]["input_nodes"]]).sum())
+            assert float(npz[f"{key}:miss_bytes"]) == nmiss * d["feat"].shape[1] * 4

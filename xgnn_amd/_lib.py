@@ -61,6 +61,7 @@ SYMBOLS = {
     "ggms_hashtable_fill_with_duplicates": (_i, [C.POINTER(HashTable), _vp, _sz, _vp, _vp, _sz, _vp]),
     "ggms_map_edges": (_i, [C.POINTER(HashTable), _vp, _vp, _vp, _vp, _sz, _vp]),
     "ggms_extract": (_i, [_vp, _vp, _vp, _sz, _sz, _i, _vp]),
+    "ggms_count_nodes": (_i, [_vp, _vp, _sz, _vp, _vp]),
     "ggms_cache_index_workspace_bytes": (_sz, [_sz]),
     "ggms_get_miss_cache_index": (_i, [_vp, _vp, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "ggms_gather_scatter": (_i, [_vp, _vp, _vp, _vp, _sz, _vp, _sz, _i, _vp]),

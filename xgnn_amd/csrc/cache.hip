@@ -41,11 +41,29 @@ struct SplitEmit {
   }
 };
 
+// presample: freq[node] += 1 for every node of the batch (dist/pre_sampler.cc:101-105 does this on the host)
+__global__ __launch_bounds__(kBlock) void k_count_nodes(uint32_t *__restrict__ freq, const uint32_t *__restrict__ nodes,
+                                                        Count n_arg) {
+  const uint64_t n = n_arg.get();
+  for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (uint64_t)gridDim.x * kBlock)
+    atomicAdd(&freq[nodes[i]], 1u);
+}
+
 } // namespace ggms
 
 using namespace ggms;
 
 extern "C" {
+
+int ggms_count_nodes(uint32_t *freq, const ggms_id_t *nodes, size_t num_nodes, const uint64_t *num_nodes_dev,
+                     ggms_stream_t stream) {
+  if (num_nodes == 0) return GGMS_OK;
+  GGMS_CHECK_ARG(freq && nodes);
+  hipLaunchKernelGGL(k_count_nodes, dim3(grid_for(num_nodes, kBlock)), dim3(kBlock), 0, to_stream(stream), freq, nodes,
+                     count_of(num_nodes, num_nodes_dev));
+  GGMS_LAUNCH_CHECK();
+  return GGMS_OK;
+}
 
 size_t ggms_cache_index_workspace_bytes(size_t num_nodes) {
   return (tile_scan_words(num_nodes) + 16) * sizeof(uint32_t);

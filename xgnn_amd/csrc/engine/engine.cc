@@ -108,6 +108,7 @@ void Engine::Configure(const std::unordered_map<std::string, std::string> &kv_in
     cfg.part_cache = true;
   }
   if (kv.count("gpu_extract") && kv["gpu_extract"] == "True") cfg.gpu_extract = (cfg.arch == kArch6); // :229-235
+  if (kv.count("presample_epoch")) cfg.presample_epoch = std::stoull(kv["presample_epoch"]); // operation.cc:184-189
   if (kv.count("seed")) { cfg.has_seed = true; cfg.seed = std::stoull(kv["seed"]); }
   if (kv.count("hash_table")) cfg.direct_table = kv["hash_table"] != "hashed";
   SAM_CHECK(cfg.sample_type == GGMS_KHOP3 || cfg.sample_type == GGMS_KHOP0 || cfg.sample_type == GGMS_WEIGHTED_KHOP ||
@@ -204,9 +205,17 @@ void Engine::LoadDataset() {
   if (cfg.UseGPUCache()) { // engine.cc:395-440
     static const char *rank_files[] = {"cache_by_degree.bin", "cache_by_heuristic.bin", nullptr, "cache_by_degree_hop.bin",
                                        nullptr, "cache_by_fake_optimal.bin", nullptr, "cache_by_random.bin"};
-    SAM_CHECK(cfg.cache_policy >= 0 && cfg.cache_policy < 8 && rank_files[cfg.cache_policy],
-              "cache policy not built (presample / dynamic): see DESIGN.md");
-    ds.ranking_nodes = MapFile(rank_files[cfg.cache_policy], ds.num_node * 4, false);
+    if (cfg.UsePresample()) {
+      // filled by worker 0 in SampleInit, read by every worker (dist_engine.cc:455-466): shared pages
+      ds.ranking_nodes.bytes = ds.num_node * 4;
+      ds.ranking_nodes.ptr = mmap(nullptr, ds.ranking_nodes.bytes, PROT_READ | PROT_WRITE, MAP_SHARED | MAP_ANONYMOUS, -1, 0);
+      SAM_CHECK(ds.ranking_nodes.ptr != MAP_FAILED, "ranking mmap failed");
+      ds.ranking_nodes.shared_anon = true;
+    } else {
+      SAM_CHECK(cfg.cache_policy >= 0 && cfg.cache_policy < 8 && rank_files[cfg.cache_policy],
+                "cache policy not built (presample_static / dynamic): see DESIGN.md");
+      ds.ranking_nodes = MapFile(rank_files[cfg.cache_policy], ds.num_node * 4, false);
+    }
   }
 }
 
@@ -417,7 +426,63 @@ void Engine::SampleInit(int worker_id, const std::string &ctx) {
   SAM_HIP(hipMalloc(&ws_, ws_bytes_));
   SAM_HIP(hipStreamSynchronize(stream_));
   prof.Resize(cfg.num_epoch, num_global_step_);
+  if (cfg.UsePresample()) { // dist_engine.cc:455-466: worker 0 ranks the nodes, everybody waits
+    auto t0 = std::chrono::steady_clock::now();
+    if (worker_id_ == 0) Presample();
+    Barrier();
+    prof.LogInit(/*kLogInitL2Presample*/ 8, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+  }
   sample_ready_ = true;
+}
+
+// PreSampler (dist/pre_sampler.cc:39-139): sample `presample_epoch` epochs of the WHOLE train set with a
+// GPUShuffler of its own, count how often each node is an input node, rank by (freq << 32 | id) descending.
+// Counting happens on the device (one atomicAdd per input node) instead of D2H copy + OpenMP loop.
+void Engine::Presample() {
+  const uint32_t L = (uint32_t)cfg.fanout.size();
+  const size_t n_train = ds.num_train;
+  const size_t steps = (n_train + cfg.batch_size - 1) / cfg.batch_size; // drop_last = false, :41-42
+  std::vector<uint32_t> data((const uint32_t *)ds.train_set.ptr, (const uint32_t *)ds.train_set.ptr + n_train);
+  uint32_t *d_train = nullptr, *d_freq = nullptr;
+  uint64_t *d_counts = nullptr;
+  SAM_HIP(hipMalloc((void **)&d_train, std::max<size_t>(n_train, 1) * 4));
+  SAM_HIP(hipMalloc((void **)&d_freq, ds.num_node * 4));
+  SAM_HIP(hipMalloc((void **)&d_counts, (3 * L + 4) * 8));
+  SAM_HIP(hipMemsetAsync(d_freq, 0, ds.num_node * 4, stream_));
+  std::vector<uint32_t *> row(L), col(L), dat(L, nullptr);
+  for (uint32_t i = 0; i < L; ++i) {
+    SAM_HIP(hipMalloc((void **)&row[i], std::max<size_t>(max_edges_[i], 4) * 4));
+    SAM_HIP(hipMalloc((void **)&col[i], std::max<size_t>(max_edges_[i], 4) * 4));
+    if (cfg.sample_type == GGMS_RANDOM_WALK) SAM_HIP(hipMalloc((void **)&dat[i], std::max<size_t>(max_edges_[i], 4) * 4));
+  }
+  for (size_t e = 0; e < cfg.presample_epoch; ++e) {
+    const uint64_t seed = cfg.has_seed ? cfg.seed + 0x5a5a5aull + e
+                                       : (uint64_t)std::chrono::system_clock::now().time_since_epoch().count();
+    auto g = std::default_random_engine(seed); // GPUShuffler::ReShuffle, cuda_shuffler.cc:89-110
+    for (size_t i = 0; n_train && i < n_train - 1; i++) {
+      std::uniform_int_distribution<size_t> d(i, n_train - 1);
+      std::swap(data[i], data[d(g)]);
+    }
+    SAM_HIP(hipMemcpyAsync(d_train, data.data(), n_train * 4, hipMemcpyHostToDevice, stream_));
+    for (size_t s = 0; s < steps; ++s) {
+      const size_t off = s * cfg.batch_size, size = std::min(cfg.batch_size, n_train - off);
+      ggms_sample_extra_t extra = extra_;
+      extra.data = dat.data();
+      SAM_GGMS(ggms_sample_batch(cfg.sample_type, &graph_, d_train + off, size, cfg.fanout.data(), L, &ht_, states_,
+                                 num_states_, row.data(), col.data(), d_counts, &extra, ws_, ws_bytes_, stream_));
+      SAM_GGMS(ggms_count_nodes(d_freq, ht_.n2o, max_unique_, d_counts + 3 * L, stream_));
+    }
+    SAM_HIP(hipStreamSynchronize(stream_)); // `data` is reshuffled on the host next
+  }
+  std::vector<uint32_t> freq(ds.num_node);
+  SAM_HIP(hipMemcpy(freq.data(), d_freq, ds.num_node * 4, hipMemcpyDeviceToHost));
+  std::vector<uint64_t> keys(ds.num_node);
+  for (size_t i = 0; i < ds.num_node; ++i) keys[i] = ((uint64_t)freq[i] << 32) | (uint64_t)i; // :45-50
+  std::sort(keys.begin(), keys.end(), std::greater<uint64_t>());                            // :113-119
+  uint32_t *rank = (uint32_t *)ds.ranking_nodes.ptr;
+  for (size_t i = 0; i < ds.num_node; ++i) rank[i] = (uint32_t)keys[i]; // GetRankNode :141-151
+  for (uint32_t i = 0; i < L; ++i) { (void)hipFree(row[i]); (void)hipFree(col[i]); if (dat[i]) (void)hipFree(dat[i]); }
+  (void)hipFree(d_train); (void)hipFree(d_freq); (void)hipFree(d_counts);
 }
 
 void Engine::BuildCache() {

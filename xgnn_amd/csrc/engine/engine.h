@@ -69,6 +69,8 @@ struct RunConfig {
   bool has_seed = false;
   uint64_t seed = 0;
   bool direct_table = true;
+  size_t presample_epoch = 0;
+  bool UsePresample() const { return UseGPUCache() && (cache_policy == 2 /*kCacheByPreSample*/); }
   bool UseGPUCache() const { return cache_percentage > 0 && arch != kArch1; } // run_config.h:124-126
 };
 
@@ -171,6 +173,7 @@ class Engine {
   void Reshuffle();
   // GGMS
   void UploadGraph();
+  void Presample();
   void BuildCache();
   Batch *AcquireSlot();
   void Finish(Batch *b);
