@@ -120,6 +120,16 @@ int ggms_sample_khop0(const ggms_graph_t *graph, const ggms_id_t *input,
                       void *workspace, size_t workspace_bytes,
                       ggms_stream_t stream);
 
+/* GPUSampleKHop2 (ORIGIN_KHOP2), cuda/cuda_sampling_khop2.cu:196-262.  In-place
+ * partial Fisher-Yates: graph->indices is PERMUTED (the reference const_casts it,
+ * cuda_loops.cc:163); unsharded graphs only (dist_loops.cc:219); the seeds of one
+ * call must be distinct.  num_states >= ceil(num_input/1024)*256 (khop2.cu:57). */
+int ggms_sample_khop2(const ggms_graph_t *graph, const ggms_id_t *input,
+                      size_t num_input, size_t fanout, ggms_id_t *out_src,
+                      ggms_id_t *out_dst, uint64_t *num_out_dev, void *states,
+                      size_t num_states, void *workspace,
+                      size_t workspace_bytes, ggms_stream_t stream);
+
 /* GPUSampleWeightedKHop, cuda/cuda_sampling_weighted_khop.cu:132-238 (alias
  * method, with replacement, stable order by src, adjacent duplicates dropped).
  * prob_table f32[E], alias_table u32[E] hold GLOBAL node ids

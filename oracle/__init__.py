@@ -19,7 +19,7 @@ _LIB = None
 _REF = None
 
 EMPTY_KEY = 0xFFFFFFFF
-KHOP0, WEIGHTED_KHOP, RANDOM_WALK, KHOP3, CPU_KHOP0 = 0, 2, 3, 7, 100
+KHOP0, WEIGHTED_KHOP, RANDOM_WALK, KHOP2, KHOP3, CPU_KHOP0 = 0, 2, 3, 5, 7, 100
 
 u32p = C.POINTER(C.c_uint32)
 XORWOW_DTYPE = np.dtype([("d", "<u4"), ("v", "<u4", (5,))])
@@ -101,6 +101,11 @@ def xorwow_stream(seed, n):
     return np.array([lib().orc_xorwow_next(_p(st)) for _ in range(n)], dtype=np.uint32)
 
 
+def xorwow_next(state):
+    """Advance a 1-element XORWOW_DTYPE array by one curand() draw; returns the draw."""
+    return int(lib().orc_xorwow_next(_p(state)))
+
+
 def shuffle_minstd0(data, seed):
     d = _u32(data).copy()
     lib().orc_shuffle_minstd0(_p(d), _sz(d.size), C.c_uint64(int(seed)))
@@ -140,6 +145,17 @@ def sample_khop3(indptr, indices, inp, fanout, states):
     src, dst = _alloc_out(inp.size, fanout)
     n = C.c_size_t(0)
     lib().orc_sample_khop3(_p(indptr), _p(indices), _p(inp), _sz(inp.size), _sz(fanout),
+                           _p(states), _sz(states.size), _p(src), _p(dst), C.byref(n))
+    return src[: n.value].copy(), dst[: n.value].copy()
+
+
+def sample_khop2(indptr, indices, inp, fanout, states):
+    """`indices` must be a writable contiguous uint32 array: it is permuted in place, like the reference's."""
+    assert indices.dtype == np.uint32 and indices.flags.c_contiguous and indices.flags.writeable
+    indptr, inp = _u32(indptr), _u32(inp)
+    src, dst = _alloc_out(inp.size, fanout)
+    n = C.c_size_t(0)
+    lib().orc_sample_khop2(_p(indptr), _p(indices), _p(inp), _sz(inp.size), _sz(fanout),
                            _p(states), _sz(states.size), _p(src), _p(dst), C.byref(n))
     return src[: n.value].copy(), dst[: n.value].copy()
 

@@ -418,6 +418,57 @@ void orc_sample_khop3(const orc_id_t *indptr, const orc_id_t *indices,
   free(tmp_dst);
 }
 
+/* cuda_sampling_khop2.cu:46-95 (ORIGIN_KHOP2 is #defined at :35).  Block b = 256
+ * threads over the tile [1024b, 1024b+1024); thread t owns RNG state i = 256b + t
+ * and serves seeds 1024b + t + 256r, r = 0..3, in order.  A seed with more than
+ * `fanout` neighbours takes a partial Fisher-Yates pass over ITS OWN slice of
+ * `indices`, in place: draw j picks position curand % (len - j), emits it, and
+ * swaps it with position len-j-1.  The CSR is therefore mutated, and the next
+ * call sees the permuted lists.  Deterministic as long as the seeds of one call
+ * are distinct (they are: layer inputs come out of the dedup table). */
+void orc_sample_khop2(const orc_id_t *indptr, orc_id_t *indices,
+                      const orc_id_t *input, size_t num_input, size_t fanout,
+                      orc_xorwow_t *states, size_t num_states,
+                      orc_id_t *out_src, orc_id_t *out_dst, size_t *num_out) {
+  const size_t BLOCK = 256, TILE = 1024;
+  orc_id_t *tmp_src = (orc_id_t *)malloc(sizeof(orc_id_t) * (num_input * fanout + 1));
+  orc_id_t *tmp_dst = (orc_id_t *)malloc(sizeof(orc_id_t) * (num_input * fanout + 1));
+  const size_t num_blocks = (num_input + TILE - 1) / TILE;
+  for (size_t b = 0; b < num_blocks; ++b) {
+    for (size_t t = 0; t < BLOCK; ++t) {
+      const size_t i = b * BLOCK + t;
+      assert(i < num_states); /* :57 */
+      (void)num_states;
+      orc_xorwow_t st = states[i];
+      for (size_t index = TILE * b + t; index < TILE * (b + 1); index += BLOCK) {
+        if (index >= num_input) continue;
+        const orc_id_t rid = input[index];
+        const orc_id_t off = indptr[rid];
+        const orc_id_t len = indptr[rid + 1] - off;
+        orc_id_t *ts = tmp_src + index * fanout, *td = tmp_dst + index * fanout;
+        if (len <= fanout) {
+          size_t j = 0;
+          for (; j < len; ++j) { ts[j] = rid; td[j] = indices[off + j]; }
+          for (; j < fanout; ++j) { ts[j] = ORC_EMPTY_KEY; td[j] = ORC_EMPTY_KEY; }
+        } else {
+          for (size_t j = 0; j < fanout; ++j) {
+            const size_t sel = orc_xorwow_next(&st) % (len - j);
+            const orc_id_t picked = indices[off + sel];
+            ts[j] = rid;
+            td[j] = picked;
+            indices[off + sel] = indices[off + len - j - 1];
+            indices[off + len - j - 1] = picked;
+          }
+        }
+      }
+      states[i] = st;
+    }
+  }
+  *num_out = compact_tmp(tmp_src, tmp_dst, num_input, fanout, out_src, out_dst);
+  free(tmp_src);
+  free(tmp_dst);
+}
+
 /* cuda_sampling_khop0.cu:102-153 (NEW_ALGO is #defined at :37).  Block =
  * 4 warps of 32 lanes, 64 seeds per block; lane (b, x, w) seeds a fresh
  * generator with (b*128 + x*4 + w) + num_input and keeps it across the warp's
@@ -766,6 +817,10 @@ orc_sample_result_t *orc_do_sample_ex(int sample_type, const orc_id_t *indptr,
         break;
       case ORC_KHOP3:
         orc_sample_khop3(indptr, indices, cur, num_cur, fanout, states, num_states, out_src, out_dst, &num_out);
+        break;
+      case ORC_KHOP2:
+        orc_sample_khop2(indptr, (orc_id_t *)indices, cur, num_cur, fanout, states, num_states, out_src, out_dst,
+                         &num_out); /* const_cast, cuda_loops.cc:163 */
         break;
       case ORC_KHOP0:
         orc_sample_khop0(indptr, indices, cur, num_cur, fanout, out_src, out_dst, &num_out);

@@ -67,7 +67,8 @@ def _oracle_batches(d, worker_id, num_worker, batch_size, num_epoch, fanouts, se
     n_global = n_local_step * num_worker
     max_seeds = int(batch_size * 1.25) + 1
     nstates = max(oracle.predict_num_nodes(max_seeds, fanouts, len(fanouts) - 1),
-                  (oracle.predict_num_nodes(max_seeds, fanouts, len(fanouts) - 1) + 127) // 128 * 8)
+                  (oracle.predict_num_nodes(max_seeds, fanouts, len(fanouts) - 1) + 127) // 128 * 8,
+                  (oracle.predict_num_nodes(max_seeds, fanouts, len(fanouts) - 1) + 1023) // 1024 * 256)
     if sample_type == "weighted_khop":
         nstates = min(oracle.predict_num_nodes(max_seeds, fanouts, len(fanouts)), 512 * 1024)
     if sample_type == "random_walk":
@@ -85,7 +86,7 @@ def _oracle_batches(d, worker_id, num_worker, batch_size, num_epoch, fanouts, se
             if arch6 and ep == 0 and st == 0:
                 size = min(int(size * 1.25), n_local - off)
             seeds = local[off:off + size]
-            code = {"khop3": oracle.KHOP3, "khop0": oracle.KHOP0, "weighted_khop": oracle.WEIGHTED_KHOP,
+            code = {"khop3": oracle.KHOP3, "khop0": oracle.KHOP0, "khop2": oracle.KHOP2, "weighted_khop": oracle.WEIGHTED_KHOP,
                     "random_walk": oracle.RANDOM_WALK}[sample_type]
             res = oracle.do_sample(code, d["ip"], d["ix"], seeds, fanouts, states, **kw)
             key = ep * n_global + worker_id * n_local_step + st
@@ -114,7 +115,8 @@ def _check(npz, want, num_layers):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("pipelined,sample_type,table", [(0, "khop3", "direct"), (1, "khop3", "hashed"), (0, "khop0", "direct")])
+@pytest.mark.parametrize("pipelined,sample_type,table", [(0, "khop3", "direct"), (1, "khop3", "hashed"), (0, "khop0", "direct"),
+                                                         (1, "khop2", "direct")])
 def test_arch1_end_to_end(tmp_path, pipelined, sample_type, table):
     d = make_dataset(tmp_path / "ds")
     prefix = str(tmp_path / "out")

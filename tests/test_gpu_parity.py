@@ -176,6 +176,47 @@ def test_sample_khop0(ops, graphs, gname, n, fanout):
     np.testing.assert_array_equal(host_u32(dst, m), wdst)
 
 
+@pytest.mark.parametrize("gname,n,fanout", [("small", 1, 5), ("small", 300, 25), ("small", 0, 4), ("small", 1025, 3),
+                                            ("mid", 8000, 10), ("mid", 20000, 25), ("mid", 4097, 64)])
+def test_sample_khop2(ops, graphs, gname, n, fanout):
+    """In-place partial Fisher-Yates (khop2.cu:46-95): edges, RNG states AND the permuted CSR must match."""
+    ip, ix, _ = graphs[gname]
+    ix_orc = ix.copy()
+    t_ix = dev(ix)  # private copy: the sampler permutes it
+    g = ops.DeviceGraph(dev(ip), t_ix)
+    rng = np.random.RandomState(n * 3 + fanout)
+    inp = rng.permutation(ip.size - 1)[:n].astype(np.uint32)  # distinct seeds (see include/ggms.h)
+    nstates = max(256, (n + 1023) // 1024 * 256)
+    st_gpu = ops.random_states(nstates, 0x5EED2)
+    st_orc = oracle.random_states(nstates, 0x5EED2)
+    for rep in range(3):  # the second and third call sample from the permuted lists
+        src, dst, num = ops.sample_khop2(g, dev(inp) if n else torch.zeros(0, dtype=torch.int32, device="cuda"),
+                                         fanout, st_gpu)
+        wsrc, wdst = oracle.sample_khop2(ip, ix_orc, inp, fanout, st_orc)
+        m = int(num.item())
+        assert m == wsrc.size
+        np.testing.assert_array_equal(host_u32(src, m), wsrc)
+        np.testing.assert_array_equal(host_u32(dst, m), wdst)
+        np.testing.assert_array_equal(host_u32(t_ix), ix_orc)
+        got_states = states_np(st_gpu)
+        np.testing.assert_array_equal(got_states[:, 0], st_orc["d"])
+        np.testing.assert_array_equal(got_states[:, 1:], st_orc["v"])
+    # a permutation of each list, never a change of its contents
+    for v in inp[:50]:
+        assert sorted(ix_orc[ip[v]:ip[v + 1]]) == sorted(ix[ip[v]:ip[v + 1]])
+
+
+def test_sample_khop2_rejects_sharded_graph(ops):
+    ip, ix = powerlaw_csr(1000, mean_deg=8, seed=5)
+    from oracle import partition_graph
+    parts = [partition_graph(ip, ix, r, 2, 500) for r in range(2)]
+    pip = [dev(p[0]) for p in parts] + [dev(ip)]
+    pix = [dev(p[1]) for p in parts] + [dev(ix)]
+    g = ops.DeviceGraph(None, None, part_indptr=pip, part_indices=pix, num_cache_node=1000)
+    with pytest.raises(RuntimeError):
+        ops.sample_khop2(g, dev(np.arange(10, dtype=np.uint32)), 3, ops.random_states(256, 1))
+
+
 @pytest.mark.parametrize("gname,n,fanout", [("small", 1, 5), ("small", 300, 25), ("small", 0, 4), ("mid", 8000, 10),
                                             ("mid", 20000, 25), ("mid", 5000, 3), ("mid", 40000, 15)])
 def test_sample_weighted_khop(ops, graphs, gname, n, fanout):
@@ -312,30 +353,34 @@ def test_partition_cache_paths(ops, P, dim):
 
 # ------------------------------------------------------- multi-layer batch
 @pytest.mark.parametrize("direct", [True, False])
-@pytest.mark.parametrize("stype", ["khop3", "khop0"])
+@pytest.mark.parametrize("stype", ["khop3", "khop0", "khop2"])
 @pytest.mark.parametrize("fanouts,nseed", [([25, 10], 1000), ([5, 10, 15], 300), ([3], 129), ([25, 10], 0)])
 def test_sample_batch_vs_oracle(ops, stype, fanouts, nseed, direct):
     """DoGPUSample (dist_loops.cc:62-368): row/col/num_src/num_dst per layer + input nodes."""
     ip, ix = powerlaw_csr(20_000, mean_deg=30, seed=2)
-    g = ops.DeviceGraph(dev(ip), dev(ix))
+    t_ix = dev(ix)
+    g = ops.DeviceGraph(dev(ip), t_ix)
     rng = np.random.RandomState(len(fanouts) * 1000 + nseed)
-    code = ops.KHOP3 if stype == "khop3" else ops.KHOP0
+    code = {"khop3": ops.KHOP3, "khop0": ops.KHOP0, "khop2": ops.KHOP2}[stype]
+    ocode = {"khop3": oracle.KHOP3, "khop0": oracle.KHOP0, "khop2": oracle.KHOP2}[stype]
     bs = ops.BatchSampler(g, fanouts, max(nseed, 1), sample_type=code, seed=77, direct_table=direct)
-    orc_states = oracle.random_states(bs.states.shape[0], 77) if stype == "khop3" else None
+    orc_states = oracle.random_states(bs.states.shape[0], 77) if stype != "khop0" else None
+    ix = ix.copy()  # khop2 permutes the oracle's CSR too
     for rep in range(3):
         seeds = rng.permutation(20_000)[:nseed].astype(np.uint32)
-        if rep == 2 and nseed > 10:
+        if rep == 2 and nseed > 10 and stype != "khop2":  # khop2 needs distinct seeds (both sides race otherwise)
             seeds[5] = seeds[0]  # duplicated seed: local ids of raw seeds go through the table
         t_seeds = dev(seeds) if nseed else torch.zeros(0, dtype=torch.int32, device="cuda")
         bs.sample(t_seeds)
         got = bs.result()
-        want = oracle.do_sample(oracle.KHOP3 if stype == "khop3" else oracle.KHOP0, ip, ix, seeds, fanouts, orc_states)
+        want = oracle.do_sample(ocode, ip, ix, seeds, fanouts, orc_states)
         np.testing.assert_array_equal(host_u32(got["input_nodes"]), want["input_nodes"])
         for i in range(len(fanouts)):
             gl, wl = got["layers"][i], want["layers"][i]
             assert (gl["num_src"], gl["num_dst"]) == (wl["num_src"], wl["num_dst"]), (rep, i)
             np.testing.assert_array_equal(host_u32(gl["row"]), wl["row"], err_msg=f"row layer {i} rep {rep}")
             np.testing.assert_array_equal(host_u32(gl["col"]), wl["col"], err_msg=f"col layer {i} rep {rep}")
+    np.testing.assert_array_equal(host_u32(t_ix), ix)  # untouched, or permuted identically (khop2)
 
 
 @pytest.mark.parametrize("stype", ["weighted", "random_walk"])

@@ -111,10 +111,10 @@ void Engine::Configure(const std::unordered_map<std::string, std::string> &kv_in
   if (kv.count("presample_epoch")) cfg.presample_epoch = std::stoull(kv["presample_epoch"]); // operation.cc:184-189
   if (kv.count("seed")) { cfg.has_seed = true; cfg.seed = std::stoull(kv["seed"]); }
   if (kv.count("hash_table")) cfg.direct_table = kv["hash_table"] != "hashed";
-  SAM_CHECK(cfg.sample_type == GGMS_KHOP3 || cfg.sample_type == GGMS_KHOP0 || cfg.sample_type == GGMS_WEIGHTED_KHOP ||
-                cfg.sample_type == GGMS_RANDOM_WALK,
-            "sample types built: khop0, khop3, weighted_khop, random_walk (DESIGN.md)");
-  if (cfg.sample_type == GGMS_WEIGHTED_KHOP) // dist_loops.cc:171-172
+  SAM_CHECK(cfg.sample_type == GGMS_KHOP3 || cfg.sample_type == GGMS_KHOP0 || cfg.sample_type == GGMS_KHOP2 ||
+                cfg.sample_type == GGMS_WEIGHTED_KHOP || cfg.sample_type == GGMS_RANDOM_WALK,
+            "sample types built: khop0, khop2, khop3, weighted_khop, random_walk (DESIGN.md)");
+  if (cfg.sample_type == GGMS_WEIGHTED_KHOP || cfg.sample_type == GGMS_KHOP2) // dist_loops.cc:171-172,219-220
     SAM_CHECK(!cfg.use_dist_graph, "this algorithm not support DistGraph engine");
   cfg.configured = true;
 }
@@ -416,6 +416,7 @@ void Engine::SampleInit(int worker_id, const std::string &ctx) {
   size_t max_in = 0;
   for (auto v : max_input_) max_in = std::max(max_in, v);
   num_states_ = std::max(num_states_, (max_in + 127) / 128 * 8);
+  num_states_ = std::max(num_states_, (max_in + 1023) / 1024 * 256); // khop2: one stream per thread of a 1024-seed tile
   if (cfg.sample_type == GGMS_RANDOM_WALK)
     num_states_ = std::max(num_states_, ggms_random_walk_num_states(max_in, cfg.num_random_walk));
   SAM_HIP(hipMalloc(&states_, num_states_ * GGMS_RNG_STATE_BYTES));

@@ -99,8 +99,8 @@ int ggms_sample_batch(int sample_type, const ggms_graph_t *graph, const ggms_id_
                       ggms_stream_t stream) {
   GGMS_CHECK_ARG(graph && fanouts && ht && row && col && counts_dev);
   GGMS_CHECK_ARG(num_layer >= 1 && num_layer <= 16);
-  GGMS_CHECK_ARG(sample_type == GGMS_KHOP3 || sample_type == GGMS_KHOP0 || sample_type == GGMS_WEIGHTED_KHOP ||
-                 sample_type == GGMS_RANDOM_WALK);
+  GGMS_CHECK_ARG(sample_type == GGMS_KHOP3 || sample_type == GGMS_KHOP0 || sample_type == GGMS_KHOP2 ||
+                 sample_type == GGMS_WEIGHTED_KHOP || sample_type == GGMS_RANDOM_WALK);
   GGMS_CHECK_ARG(num_seeds == 0 || seeds);
   GGMS_CHECK_ARG(workspace && workspace_bytes >= ggms_sample_batch_workspace_bytes(sample_type, num_seeds, fanouts,
                                                                                    num_layer, extra));
@@ -113,6 +113,10 @@ int ggms_sample_batch(int sample_type, const ggms_graph_t *graph, const ggms_id_
   const BatchCaps c = caps_of(num_seeds, fanouts, num_layer);
   GGMS_CHECK_ARG(c.max_input[0] + c.max_edges[0] <= ht->n2o_size);
   GGMS_CHECK_ARG(c.max_input[0] + c.max_edges[0] < (1ull << 32));
+  if (sample_type == GGMS_KHOP2) { // unsharded CSR, mutated in place (dist_loops.cc:217-224)
+    GGMS_CHECK_ARG(graph->num_part == 0 && graph->indptr && graph->indices);
+    GGMS_CHECK_ARG(states && (c.max_in_all + 1023) / 1024 * 256 <= num_states);
+  }
   if (sample_type == GGMS_KHOP3) {
     GGMS_CHECK_ARG(states && (c.max_in_all + 127) / 128 * 8 <= num_states);
     for (uint32_t i = 0; i < num_layer; ++i) GGMS_CHECK_ARG(fanouts[i] > 0 && fanouts[i] < 128);
@@ -161,6 +165,10 @@ int ggms_sample_batch(int sample_type, const ggms_graph_t *graph, const ggms_id_
                              samp_ws, first ? seed_local : nullptr, 1, ht->n2o, s, &scan);
     } else if (sample_type == GGMS_KHOP0) {
       rc = sample_khop0_impl(g, input, n_max, n, (uint32_t)fanouts[i], col[i], tmp_dst, num_edge, samp_ws,
+                             first ? seed_local : nullptr, 1, s, &scan);
+    } else if (sample_type == GGMS_KHOP2) {
+      rc = sample_khop2_impl(graph->indptr, const_cast<uint32_t *>(graph->indices), graph->num_node, input, n_max, n,
+                             (uint32_t)fanouts[i], col[i], tmp_dst, num_edge, (uint32_t *)states, samp_ws,
                              first ? seed_local : nullptr, 1, s, &scan);
     } else if (sample_type == GGMS_WEIGHTED_KHOP) {
       rc = sample_weighted_impl(graph->indptr, graph->indices, extra->prob_table, extra->alias_table, input, n_max, n,

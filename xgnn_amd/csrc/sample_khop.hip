@@ -1,7 +1,8 @@
-// sample_khop.hip -- uniform fan-out neighbour samplers (khop3, khop0).
+// sample_khop.hip -- uniform fan-out neighbour samplers (khop3, khop0, khop2).
 //
 // Reference: GPUSampleKHop3 (cuda/cuda_sampling_khop3.cu:76-146, host :234-318) and
-// GPUSampleKHop0 NEW_ALGO (cuda/cuda_sampling_khop0.cu:102-153, host :243-335).
+// GPUSampleKHop0 NEW_ALGO (cuda/cuda_sampling_khop0.cu:102-153, host :243-335),
+// GPUSampleKHop2 ORIGIN_KHOP2 (cuda/cuda_sampling_khop2.cu:46-95, host :196-262).
 //
 // What is kept bit-for-bit: which RNG stream serves which seed, the order in
 // which a stream's draws are consumed, and the (seed order, slot order) layout
@@ -277,6 +278,60 @@ __global__ __launch_bounds__(128) void k_sample_khop0(GraphView g, const uint32_
   }
 }
 
+// ---- khop2 (in-place partial Fisher-Yates) -----------------------------------
+// Thread t of block b owns stream 256 b + t and serves seeds 1024 b + t + 256 r, r = 0..3
+// (khop2.cu:53-61).  Draw j of a seed picks position curand % (len - j) of the seed's own
+// neighbour list, emits it and swaps it to the shrinking tail (:82-91): `indices` is
+// permuted in place and the next batch samples from the permuted lists.  One lane per
+// stream, as the stream assignment demands; a draw costs one round trip to the list
+// (both loads issue together, the stores are fire-and-forget; same-lane accesses to one
+// address stay in program order).  The compact COO is written directly at the seed's
+// scanned offset.  Seeds of one call must be distinct (two copies of a seed would race
+// on the same list, as they do in the reference).
+__global__ __launch_bounds__(kBlock) void k_sample_khop2(const uint32_t *__restrict__ indptr, uint32_t *indices,
+                                                         const uint32_t *__restrict__ input, Count n_arg,
+                                                         uint32_t fanout, const uint32_t *__restrict__ offset,
+                                                         uint32_t *__restrict__ out_src,
+                                                         uint32_t *__restrict__ out_dst,
+                                                         uint32_t *__restrict__ states, SrcMode sm) {
+  const uint64_t n = n_arg.get();
+  const uint64_t num_tiles = (n + 1023) / 1024;
+  for (uint64_t b = blockIdx.x; b < num_tiles; b += gridDim.x) {
+    const uint64_t sid = b * kBlock + threadIdx.x;
+    Xorwow st;
+    st.load(states + 6 * sid);
+    bool drew = false;
+    for (uint32_t r = 0; r < 4; ++r) {
+      const uint64_t index = b * 1024 + threadIdx.x + (uint64_t)r * kBlock;
+      if (index >= n) break;
+      const uint32_t rid = input[index];
+      const uint32_t off = indptr[rid], len = indptr[rid + 1] - off;
+      const uint32_t o = offset[index];
+      const uint32_t sv = sm.value(rid, index);
+      uint32_t *list = indices + off;
+      if (len <= fanout) {
+        for (uint32_t j = 0; j < len; ++j) {
+          out_src[o + j] = sv;
+          out_dst[o + j] = list[j];
+        }
+      } else {
+        drew = true;
+        for (uint32_t j = 0; j < fanout; ++j) {
+          const uint32_t sel = st.next() % (len - j);
+          const uint32_t tail = len - j - 1;
+          const uint32_t picked = list[sel];
+          const uint32_t moved = list[tail];
+          out_src[o + j] = sv;
+          out_dst[o + j] = picked;
+          list[sel] = moved;
+          list[tail] = picked;
+        }
+      }
+    }
+    if (drew) st.store(states + 6 * sid);
+  }
+}
+
 size_t sample_ws_words(size_t num_input) { return num_input + tile_scan_words(num_input) + 16; }
 
 // offsets by exclusive scan of min(deg, fanout), then the sampler proper
@@ -313,6 +368,23 @@ int sample_khop0_impl(GraphView g, const uint32_t *input, size_t n_max, Count n,
   const size_t num_blocks = (n_max + 63) / 64;
   hipLaunchKernelGGL(k_sample_khop0, dim3(grid_for(num_blocks, 1)), dim3(128), 4 * fanout * sizeof(uint32_t), s, g,
                      input, n, fanout, offset, out_src, out_dst, SrcMode{seed_local, src_local});
+  GGMS_LAUNCH_CHECK();
+  return GGMS_OK;
+}
+
+int sample_khop2_impl(const uint32_t *indptr, uint32_t *indices, size_t num_node, const uint32_t *input, size_t n_max,
+                      Count n, uint32_t fanout, uint32_t *out_src, uint32_t *out_dst, uint64_t *num_out_dev,
+                      uint32_t *states, uint32_t *workspace, const uint32_t *seed_local, int src_local, hipStream_t s,
+                      ScanArea *shared_scan) {
+  (void)num_node;
+  uint32_t *offset = workspace;
+  const GraphView g{indptr, indices, nullptr, nullptr, 0, 0};
+  const ScanArea sa = shared_scan ? *shared_scan : ScanArea{offset + n_max, false};
+  int rc = tile_scan(SeedCount{g, input, fanout}, StoreOffset{offset}, n_max, n, sa, nullptr, nullptr,
+                     num_out_dev, s);
+  if (rc != GGMS_OK) return rc;
+  hipLaunchKernelGGL(k_sample_khop2, dim3(grid_for((n_max + 1023) / 1024, 1)), dim3(kBlock), 0, s, indptr, indices,
+                     input, n, fanout, offset, out_src, out_dst, states, SrcMode{seed_local, src_local});
   GGMS_LAUNCH_CHECK();
   return GGMS_OK;
 }
@@ -362,6 +434,26 @@ int ggms_sample_khop0(const ggms_graph_t *graph, const ggms_id_t *input, size_t 
   GGMS_CHECK_ARG((uint64_t)num_input * fanout < (1ull << 32));
   return sample_khop0_impl(view_of(graph), input, num_input, count_of(num_input), (uint32_t)fanout, out_src, out_dst,
                            num_out_dev, (uint32_t *)workspace, nullptr, 0, s);
+}
+
+int ggms_sample_khop2(const ggms_graph_t *graph, const ggms_id_t *input, size_t num_input, size_t fanout,
+                      ggms_id_t *out_src, ggms_id_t *out_dst, uint64_t *num_out_dev, void *states,
+                      size_t num_states, void *workspace, size_t workspace_bytes, ggms_stream_t stream) {
+  GGMS_CHECK_ARG(graph && num_out_dev);
+  GGMS_CHECK_ARG(fanout > 0);
+  GGMS_CHECK_ARG(graph->num_part == 0); // CHECK(use_dist_graph == false), dist_loops.cc:219
+  hipStream_t s = to_stream(stream);
+  if (num_input == 0) {
+    GGMS_HIP(hipMemsetAsync(num_out_dev, 0, sizeof(uint64_t), s));
+    return GGMS_OK;
+  }
+  GGMS_CHECK_ARG(input && out_src && out_dst && states && workspace && graph->indptr && graph->indices);
+  GGMS_CHECK_ARG(workspace_bytes >= ggms_sample_workspace_bytes(GGMS_KHOP2, num_input, fanout));
+  GGMS_CHECK_ARG((uint64_t)num_input * fanout < (1ull << 32));
+  GGMS_CHECK_ARG((num_input + 1023) / 1024 * 256 <= num_states); // assert(i < num_random_states), khop2.cu:57
+  return sample_khop2_impl(graph->indptr, const_cast<uint32_t *>(graph->indices), graph->num_node, input, num_input,
+                           count_of(num_input), (uint32_t)fanout, out_src, out_dst, num_out_dev, (uint32_t *)states,
+                           (uint32_t *)workspace, nullptr, 0, s);
 }
 
 } // extern "C"

@@ -89,8 +89,8 @@ def _sample(fn_name, sample_type, graph, inp, fanout, states):
     num_out = torch.zeros(1, dtype=torch.int64, device=dev)
     wsb = lib().ggms_sample_workspace_bytes(sample_type, n, fanout)
     ws = _workspace(wsb, dev)
-    if fn_name == "ggms_sample_khop3":
-        rc = lib().ggms_sample_khop3(C.byref(graph.c), _ptr(inp), n, fanout, _ptr(out_src), _ptr(out_dst),
+    if fn_name in ("ggms_sample_khop3", "ggms_sample_khop2"):
+        rc = getattr(lib(), fn_name)(C.byref(graph.c), _ptr(inp), n, fanout, _ptr(out_src), _ptr(out_dst),
                                      _ptr(num_out), _ptr(states), states.shape[0], _ptr(ws), ws.numel() * 4,
                                      _stream())
     else:
@@ -108,6 +108,11 @@ def sample_khop3(graph, inp, fanout, states):
 def sample_khop0(graph, inp, fanout):
     """GPUSampleKHop0 (cuda_sampling_khop0.cu:243-335)."""
     return _sample("ggms_sample_khop0", KHOP0, graph, inp, fanout, None)
+
+
+def sample_khop2(graph, inp, fanout, states):
+    """GPUSampleKHop2 (cuda_sampling_khop2.cu:196-262).  Permutes graph.indices in place, like the reference."""
+    return _sample("ggms_sample_khop2", KHOP2, graph, inp, fanout, states)
 
 
 def sample_weighted_khop(graph, prob_table, alias_table, inp, fanout, states):
@@ -277,7 +282,7 @@ class BatchSampler:
         self.max_input, self.max_edges, self.max_unique = list(mi), list(me), mu.value
         self.ht = OrderedHashTable(self.max_unique, device, num_node=graph.c.num_node if direct_table else None)
         nstates = lib().ggms_random_states_count(sample_type, self._f, L, self.max_seeds, num_random_walk)
-        nstates = max(nstates, (max(self.max_input) + 127) // 128 * 8)
+        nstates = max(nstates, (max(self.max_input) + 127) // 128 * 8, (max(self.max_input) + 1023) // 1024 * 256)
         if sample_type == RANDOM_WALK:
             nstates = max(nstates, lib().ggms_random_walk_num_states(max(self.max_input), num_random_walk))
         self.states = random_states(nstates, seed, device) if sample_type != KHOP0 else None
