@@ -216,6 +216,17 @@ def cpu_sample_khop0(indptr, indices, inp, fanout, num_threads=1):
     return src[: n.value].copy(), dst[: n.value].copy()
 
 
+def cpu_sample_khop2(indptr, indices, inp, fanout, num_threads=1):
+    """CPUSampleKHop2 restated; `indices` (writable uint32) is permuted in place."""
+    assert indices.dtype == np.uint32 and indices.flags.c_contiguous and indices.flags.writeable
+    indptr, inp = _u32(indptr), _u32(inp)
+    src, dst = _alloc_out(inp.size, fanout)
+    n = C.c_size_t(0)
+    lib().orc_cpu_sample_khop2(_p(indptr), _p(indices), _p(inp), _sz(inp.size), _p(src), _p(dst),
+                               C.byref(n), _sz(fanout), C.c_int(num_threads))
+    return src[: n.value].copy(), dst[: n.value].copy()
+
+
 def extract(src, index, num_threads=1):
     """out[i, :] = src[index[i], :] for a 2-D (or 1-D) array of any dtype."""
     src = np.ascontiguousarray(src)
@@ -383,6 +394,19 @@ def ref_cpu_sample_khop0(indptr, indices, inp, fanout, num_threads=1):
     n = C.c_size_t(0)
     r.ref_set_omp_threads(C.c_int(num_threads))
     r.ref_cpu_sample_khop0(_p(indptr), _p(indices), _p(inp), _sz(inp.size), _p(src), _p(dst),
+                           C.byref(n), _sz(fanout))
+    return src[: n.value].copy(), dst[: n.value].copy()
+
+
+def ref_cpu_sample_khop2(indptr, indices, inp, fanout, num_threads=1):
+    """The reference's CPUSampleKHop2 object; `indices` is permuted in place."""
+    assert indices.dtype == np.uint32 and indices.flags.c_contiguous and indices.flags.writeable
+    r = ref_lib()
+    indptr, inp = _u32(indptr), _u32(inp)
+    src, dst = _alloc_out(inp.size, fanout)
+    n = C.c_size_t(0)
+    r.ref_set_omp_threads(C.c_int(num_threads))
+    r.ref_cpu_sample_khop2(_p(indptr), _p(indices), _p(inp), _sz(inp.size), _p(src), _p(dst),
                            C.byref(n), _sz(fanout))
     return src[: n.value].copy(), dst[: n.value].copy()
 

@@ -266,6 +266,57 @@ uint32_t orc_cpu_random_id(uint32_t lo, uint32_t hi) {
   return orc_mt19937_uniform_u32(&tl_gen, lo, hi);
 }
 
+/* cpu_sampling_khop2.cc:29-76: the CPU twin of the in-place Fisher-Yates sampler.
+ * Draw j picks k = RandomID(0, len-j-1) (inclusive bound, so k <= len-j-1),
+ * emits indices[off+k], then swaps positions k and len-j-1. */
+void orc_cpu_sample_khop2(const orc_id_t *indptr, orc_id_t *indices,
+                          const orc_id_t *input, size_t num_input,
+                          orc_id_t *out_src, orc_id_t *out_dst,
+                          size_t *num_out, size_t fanout, int num_threads) {
+  int all_has_fanout = 1;
+  (void)num_threads;
+#ifdef _OPENMP
+#pragma omp parallel for num_threads(num_threads) reduction(&& : all_has_fanout)
+#endif
+  for (size_t i = 0; i < num_input; ++i) {
+    const orc_id_t rid = input[i];
+    const orc_id_t off = indptr[rid];
+    const orc_id_t len = indptr[rid + 1] - off;
+    all_has_fanout = all_has_fanout && (len >= fanout);
+    if (len <= fanout) {
+      size_t j = 0;
+      for (; j < len; ++j) {
+        out_src[i * fanout + j] = rid;
+        out_dst[i * fanout + j] = indices[off + j];
+      }
+      for (; j < fanout; ++j) {
+        out_src[i * fanout + j] = ORC_EMPTY_KEY;
+        out_dst[i * fanout + j] = ORC_EMPTY_KEY;
+      }
+    } else {
+      for (size_t j = 0; j < fanout; ++j) {
+        const orc_id_t k = orc_cpu_random_id(0, (orc_id_t)(len - j - 1));
+        const orc_id_t picked = indices[off + k];
+        out_src[i * fanout + j] = rid;
+        out_dst[i * fanout + j] = picked;
+        indices[off + k] = indices[off + len - j - 1];
+        indices[off + len - j - 1] = picked;
+      }
+    }
+  }
+  if (!all_has_fanout) {
+    size_t total = num_input * fanout, w = 0;
+    for (size_t r = 0; r < total; ++r)
+      if (out_src[r] != ORC_EMPTY_KEY) out_src[w++] = out_src[r];
+    *num_out = w;
+    w = 0;
+    for (size_t r = 0; r < total; ++r)
+      if (out_dst[r] != ORC_EMPTY_KEY) out_dst[w++] = out_dst[r];
+  } else {
+    *num_out = num_input * fanout;
+  }
+}
+
 /* cpu_sampling_khop0.cc:29-83 */
 void orc_cpu_sample_khop0(const orc_id_t *indptr, const orc_id_t *indices,
                           const orc_id_t *input, size_t num_input,

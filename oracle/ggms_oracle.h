@@ -87,6 +87,11 @@ void orc_cpu_sample_khop0(const orc_id_t *indptr, const orc_id_t *indices,
                           const orc_id_t *input, size_t num_input,
                           orc_id_t *out_src, orc_id_t *out_dst,
                           size_t *num_out, size_t fanout, int num_threads);
+/* cpu_sampling_khop2.cc:29-76; MUTATES indices */
+void orc_cpu_sample_khop2(const orc_id_t *indptr, orc_id_t *indices,
+                          const orc_id_t *input, size_t num_input,
+                          orc_id_t *out_src, orc_id_t *out_dst,
+                          size_t *num_out, size_t fanout, int num_threads);
 /* cpu_extraction.cc:31-90 (row copy; dim*esize = row_bytes) */
 void orc_extract(void *dst, const void *src, const orc_id_t *index,
                  size_t num_index, size_t row_bytes, int num_threads);

@@ -5,6 +5,7 @@
  * Makefile compiles *in place* from /root/reference (no reference source is
  * copied into this repository).  Linked objects:
  *   samgraph/common/cpu/cpu_sampling_khop0.cc   CPUSampleKHop0
+ *   samgraph/common/cpu/cpu_sampling_khop2.cc   CPUSampleKHop2
  *   samgraph/common/cpu/cpu_random.cc           RandomID
  *   samgraph/common/cpu/cpu_extraction.cc       CPUExtract
  *   samgraph/common/{run_config,logging,constant}.cc   (their link deps)
@@ -54,6 +55,15 @@ void ref_cpu_sample_khop0(const uint32_t *indptr, const uint32_t *indices,
                           uint32_t *out_src, uint32_t *out_dst,
                           size_t *num_out, size_t fanout) {
   cpu::CPUSampleKHop0(indptr, indices, input, num_input, out_src, out_dst,
+                      num_out, fanout);
+}
+
+/* cpu/cpu_sampling_khop2.cc:29-76 (permutes `indices` in place) */
+void ref_cpu_sample_khop2(const uint32_t *indptr, uint32_t *indices,
+                          const uint32_t *input, size_t num_input,
+                          uint32_t *out_src, uint32_t *out_dst,
+                          size_t *num_out, size_t fanout) {
+  cpu::CPUSampleKHop2(indptr, indices, input, num_input, out_src, out_dst,
                       num_out, fanout);
 }
 

@@ -4,7 +4,7 @@ Run in the build container only (needs /root/reference):
 
     make -C oracle ref && python tests/golden/gen_golden.py
 
-It drives oracle/_ref/libref_cpu.so -- cpu/cpu_sampling_khop0.cc,
+It drives oracle/_ref/libref_cpu.so -- cpu/cpu_sampling_khop0.cc, cpu/cpu_sampling_khop2.cc,
 cpu/cpu_random.cc, cpu/cpu_extraction.cc compiled in place from
 /root/reference/samgraph/common -- on seeded inputs and stores inputs +
 outputs under tests/golden/.  Only data is stored, no reference text.
@@ -74,6 +74,30 @@ def main():
         out[f"khop0_{ci}_dst"] = dst
         order.append(f"{gname}:{fanout}")
     out["khop0_order"] = np.array(order)
+
+    # ---- CPUSampleKHop2 (in-place Fisher-Yates), continuing on the SAME RandomID stream; each graph's
+    # `indices` is permuted by the calls, so the calls on one graph chain and the final lists are stored
+    order2 = []
+    mutable = {k: (ip, ix.copy()) for k, (ip, ix) in graphs.items()}
+    calls2 = [
+        ("toy", np.array([0, 3, 1, 2], np.uint32), 2),
+        ("toy", np.array([3, 1], np.uint32), 3),
+        ("pl200", rng.permutation(200)[:64].astype(np.uint32), 5),
+        ("pl200", np.arange(200, dtype=np.uint32), 25),
+        ("pl200", np.zeros(0, np.uint32), 4),
+        ("pl2k", rng.permutation(2000)[:800].astype(np.uint32), 10),
+        ("pl2k", rng.permutation(2000)[:1500].astype(np.uint32), 25),
+        ("pl2k", rng.randint(0, 2000, 100).astype(np.uint32), 1),  # repeated seeds: sequential at 1 thread
+    ]
+    for ci, (gname, inp, fanout) in enumerate(calls2):
+        ip, ix = mutable[gname]
+        src, dst = oracle.ref_cpu_sample_khop2(ip, ix, inp, fanout, num_threads=1)
+        out[f"khop2_{ci}_input"] = inp
+        out[f"khop2_{ci}_src"] = src
+        out[f"khop2_{ci}_dst"] = dst
+        out[f"khop2_{ci}_indices_after"] = ix.copy()
+        order2.append(f"{gname}:{fanout}")
+    out["khop2_order"] = np.array(order2)
 
     # ---- CPUExtract over the dtypes the reference dispatches (cpu_extraction.cc:66-90)
     rng = np.random.RandomState(11)
