@@ -34,7 +34,7 @@ def parse():
     ap.add_argument("--preset", default="products")
     ap.add_argument("--batch", type=int, default=8000)
     ap.add_argument("--fanout", default="25,10")
-    ap.add_argument("--sample-type", default="khop3", choices=["khop3", "khop0", "khop2"])
+    ap.add_argument("--sample-type", default="khop3", choices=["khop3", "khop0", "khop2", "khop1"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline: keep sampling mini-batches this long")
     ap.add_argument("--host-profile", action="store_true", help="print host enqueue time per section to stderr")
@@ -185,7 +185,7 @@ def main():
         host_feat = torch.empty((N, dim), dtype=torch.float32, pin_memory=True)
         feat_rows(torch.arange(N, dtype=torch.int64), host_feat)
 
-    code = {"khop3": ops.KHOP3, "khop0": ops.KHOP0, "khop2": ops.KHOP2}[args.sample_type]
+    code = {"khop3": ops.KHOP3, "khop0": ops.KHOP0, "khop2": ops.KHOP2, "khop1": ops.KHOP1}[args.sample_type]
     NSLOT = 2  # batch slots, as in the engine: outputs of batch k stay valid while batch k+1 is sampled
     sampler = ops.BatchSampler(g, fanouts, args.batch, sample_type=code, seed=0x5EED + rank, device=dev,
                                num_slots=NSLOT)

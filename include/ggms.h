@@ -120,6 +120,16 @@ int ggms_sample_khop0(const ggms_graph_t *graph, const ggms_id_t *input,
                       void *workspace, size_t workspace_bytes,
                       ggms_stream_t stream);
 
+/* GPUSampleKHop1, cuda/cuda_sampling_khop1.cu:130-236: uniform WITH replacement,
+ * stable order by src id, an edge equal to its successor dropped.  Unsharded graphs
+ * only (dist_loops.cc:167-168).  Workspace: ggms_sample_weighted_workspace_bytes.
+ * num_states >= min(tasks, roundup256(min(tasks, 512K))), tasks = num_input*fanout. */
+int ggms_sample_khop1(const ggms_graph_t *graph, const ggms_id_t *input,
+                      size_t num_input, size_t fanout, ggms_id_t *out_src,
+                      ggms_id_t *out_dst, uint64_t *num_out_dev, void *states,
+                      size_t num_states, void *workspace,
+                      size_t workspace_bytes, ggms_stream_t stream);
+
 /* GPUSampleKHop2 (ORIGIN_KHOP2), cuda/cuda_sampling_khop2.cu:196-262.  In-place
  * partial Fisher-Yates: graph->indices is PERMUTED (the reference const_casts it,
  * cuda_loops.cc:163); unsharded graphs only (dist_loops.cc:219); the seeds of one

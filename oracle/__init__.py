@@ -19,7 +19,7 @@ _LIB = None
 _REF = None
 
 EMPTY_KEY = 0xFFFFFFFF
-KHOP0, WEIGHTED_KHOP, RANDOM_WALK, KHOP2, KHOP3, CPU_KHOP0 = 0, 2, 3, 5, 7, 100
+KHOP0, KHOP1, WEIGHTED_KHOP, RANDOM_WALK, KHOP2, KHOP3, CPU_KHOP0 = 0, 1, 2, 3, 5, 7, 100
 
 u32p = C.POINTER(C.c_uint32)
 XORWOW_DTYPE = np.dtype([("d", "<u4"), ("v", "<u4", (5,))])
@@ -145,6 +145,15 @@ def sample_khop3(indptr, indices, inp, fanout, states):
     src, dst = _alloc_out(inp.size, fanout)
     n = C.c_size_t(0)
     lib().orc_sample_khop3(_p(indptr), _p(indices), _p(inp), _sz(inp.size), _sz(fanout),
+                           _p(states), _sz(states.size), _p(src), _p(dst), C.byref(n))
+    return src[: n.value].copy(), dst[: n.value].copy()
+
+
+def sample_khop1(indptr, indices, inp, fanout, states):
+    indptr, indices, inp = _u32(indptr), _u32(indices), _u32(inp)
+    src, dst = _alloc_out(inp.size, fanout)
+    n = C.c_size_t(0)
+    lib().orc_sample_khop1(_p(indptr), _p(indices), _p(inp), _sz(inp.size), _sz(fanout),
                            _p(states), _sz(states.size), _p(src), _p(dst), C.byref(n))
     return src[: n.value].copy(), dst[: n.value].copy()
 

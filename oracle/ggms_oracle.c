@@ -593,13 +593,13 @@ static void stable_sort_kv32(kv32_t *a, size_t n) {
 
 /* cuda_sampling_weighted_khop.cu:41-76 (sample), :172-181 (stable radix sort
  * by src), :78-128 (adjacent-duplicate compaction), launch :156-164. */
-void orc_sample_weighted_khop(const orc_id_t *indptr, const orc_id_t *indices,
-                              const float *prob_table,
-                              const orc_id_t *alias_table,
-                              const orc_id_t *input, size_t num_input,
-                              size_t fanout, orc_xorwow_t *states,
-                              size_t num_states, orc_id_t *out_src,
-                              orc_id_t *out_dst, size_t *num_out) {
+static void sample_with_replacement(const orc_id_t *indptr, const orc_id_t *indices,
+                                    const float *prob_table, /* NULL: uniform (khop1) */
+                                    const orc_id_t *alias_table,
+                                    const orc_id_t *input, size_t num_input,
+                                    size_t fanout, orc_xorwow_t *states,
+                                    size_t num_states, orc_id_t *out_src,
+                                    orc_id_t *out_dst, size_t *num_out) {
   const size_t num_task = num_input * fanout;
   const size_t kMaxThreads = 512 * 1024, kBlock = 256; /* constant.h:66,72 */
   if (num_task == 0) { *num_out = 0; return; }
@@ -622,8 +622,12 @@ void orc_sample_weighted_khop(const orc_id_t *indptr, const orc_id_t *indices,
       } else {
         kv[task].key = rid;
         size_t k = orc_xorwow_next(&st) % len;
-        float r = orc_xorwow_uniform(&st);
-        kv[task].val = (r < prob_table[off + k]) ? indices[off + k] : alias_table[off + k];
+        if (prob_table) {
+          float r = orc_xorwow_uniform(&st);
+          kv[task].val = (r < prob_table[off + k]) ? indices[off + k] : alias_table[off + k];
+        } else {
+          kv[task].val = indices[off + k]; /* khop1.cu:65-67 */
+        }
       }
     }
     states[tid] = st;
@@ -640,6 +644,29 @@ void orc_sample_weighted_khop(const orc_id_t *indptr, const orc_id_t *indices,
   }
   *num_out = w;
   free(kv);
+}
+
+void orc_sample_weighted_khop(const orc_id_t *indptr, const orc_id_t *indices,
+                              const float *prob_table,
+                              const orc_id_t *alias_table,
+                              const orc_id_t *input, size_t num_input,
+                              size_t fanout, orc_xorwow_t *states,
+                              size_t num_states, orc_id_t *out_src,
+                              orc_id_t *out_dst, size_t *num_out) {
+  assert(prob_table && alias_table);
+  sample_with_replacement(indptr, indices, prob_table, alias_table, input, num_input, fanout, states, num_states,
+                          out_src, out_dst, num_out);
+}
+
+/* cuda_sampling_khop1.cu:42-72 (one curand % len per task, with replacement; grid-stride over
+ * <= kKHop1MaxThreads = 512 K stored states), SortPairs by src :160-176, count_edge/compact_edge
+ * :74-127 (an entry equal to its successor is dropped) -- the weighted sampler minus the alias draw. */
+void orc_sample_khop1(const orc_id_t *indptr, const orc_id_t *indices,
+                      const orc_id_t *input, size_t num_input, size_t fanout,
+                      orc_xorwow_t *states, size_t num_states,
+                      orc_id_t *out_src, orc_id_t *out_dst, size_t *num_out) {
+  sample_with_replacement(indptr, indices, NULL, NULL, input, num_input, fanout, states, num_states, out_src, out_dst,
+                          num_out);
 }
 
 /* cuda_sampling_random_walk.cu:43-112; launch geometry :137-141 */
@@ -868,6 +895,9 @@ orc_sample_result_t *orc_do_sample_ex(int sample_type, const orc_id_t *indptr,
         break;
       case ORC_KHOP3:
         orc_sample_khop3(indptr, indices, cur, num_cur, fanout, states, num_states, out_src, out_dst, &num_out);
+        break;
+      case ORC_KHOP1:
+        orc_sample_khop1(indptr, indices, cur, num_cur, fanout, states, num_states, out_src, out_dst, &num_out);
         break;
       case ORC_KHOP2:
         orc_sample_khop2(indptr, (orc_id_t *)indices, cur, num_cur, fanout, states, num_states, out_src, out_dst,

@@ -69,7 +69,7 @@ def _oracle_batches(d, worker_id, num_worker, batch_size, num_epoch, fanouts, se
     nstates = max(oracle.predict_num_nodes(max_seeds, fanouts, len(fanouts) - 1),
                   (oracle.predict_num_nodes(max_seeds, fanouts, len(fanouts) - 1) + 127) // 128 * 8,
                   (oracle.predict_num_nodes(max_seeds, fanouts, len(fanouts) - 1) + 1023) // 1024 * 256)
-    if sample_type == "weighted_khop":
+    if sample_type in ("weighted_khop", "khop1"):
         nstates = min(oracle.predict_num_nodes(max_seeds, fanouts, len(fanouts)), 512 * 1024)
     if sample_type == "random_walk":
         nstates = (oracle.predict_num_nodes(max_seeds, fanouts, len(fanouts) - 1) + 63) // 64 * 256
@@ -86,7 +86,7 @@ def _oracle_batches(d, worker_id, num_worker, batch_size, num_epoch, fanouts, se
             if arch6 and ep == 0 and st == 0:
                 size = min(int(size * 1.25), n_local - off)
             seeds = local[off:off + size]
-            code = {"khop3": oracle.KHOP3, "khop0": oracle.KHOP0, "khop2": oracle.KHOP2, "weighted_khop": oracle.WEIGHTED_KHOP,
+            code = {"khop3": oracle.KHOP3, "khop0": oracle.KHOP0, "khop2": oracle.KHOP2, "khop1": oracle.KHOP1, "weighted_khop": oracle.WEIGHTED_KHOP,
                     "random_walk": oracle.RANDOM_WALK}[sample_type]
             res = oracle.do_sample(code, d["ip"], d["ix"], seeds, fanouts, states, **kw)
             key = ep * n_global + worker_id * n_local_step + st
@@ -116,7 +116,7 @@ def _check(npz, want, num_layers):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("pipelined,sample_type,table", [(0, "khop3", "direct"), (1, "khop3", "hashed"), (0, "khop0", "direct"),
-                                                         (1, "khop2", "direct")])
+                                                         (1, "khop2", "direct"), (0, "khop1", "direct")])
 def test_arch1_end_to_end(tmp_path, pipelined, sample_type, table):
     d = make_dataset(tmp_path / "ds")
     prefix = str(tmp_path / "out")

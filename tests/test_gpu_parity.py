@@ -176,6 +176,30 @@ def test_sample_khop0(ops, graphs, gname, n, fanout):
     np.testing.assert_array_equal(host_u32(dst, m), wdst)
 
 
+@pytest.mark.parametrize("gname,n,fanout", [("small", 1, 5), ("small", 300, 25), ("small", 0, 4), ("mid", 8000, 10),
+                                            ("mid", 30000, 25), ("mid", 5000, 3)])
+def test_sample_khop1(ops, graphs, gname, n, fanout):
+    """With replacement + stable sort by src + adjacent-duplicate drop (khop1.cu:42-127); 30000*25 > 512 K tasks
+    exercises the grid-stride reuse of a stream."""
+    ip, ix, g = graphs[gname]
+    rng = np.random.RandomState(n * 11 + fanout)
+    inp = rng.randint(0, ip.size - 1, n).astype(np.uint32)
+    nstates = max(256, min(n * fanout, 512 * 1024))
+    st_gpu = ops.random_states(nstates, 0x1001)
+    st_orc = oracle.random_states(nstates, 0x1001)
+    for rep in range(2):
+        src, dst, num = ops.sample_khop1(g, dev(inp) if n else torch.zeros(0, dtype=torch.int32, device="cuda"),
+                                         fanout, st_gpu)
+        wsrc, wdst = oracle.sample_khop1(ip, ix, inp, fanout, st_orc)
+        m = int(num.item())
+        assert m == wsrc.size
+        np.testing.assert_array_equal(host_u32(src, m), wsrc)
+        np.testing.assert_array_equal(host_u32(dst, m), wdst)
+        got_states = states_np(st_gpu)
+        np.testing.assert_array_equal(got_states[:, 0], st_orc["d"])
+        np.testing.assert_array_equal(got_states[:, 1:], st_orc["v"])
+
+
 @pytest.mark.parametrize("gname,n,fanout", [("small", 1, 5), ("small", 300, 25), ("small", 0, 4), ("small", 1025, 3),
                                             ("mid", 8000, 10), ("mid", 20000, 25), ("mid", 4097, 64)])
 def test_sample_khop2(ops, graphs, gname, n, fanout):
@@ -353,7 +377,7 @@ def test_partition_cache_paths(ops, P, dim):
 
 # ------------------------------------------------------- multi-layer batch
 @pytest.mark.parametrize("direct", [True, False])
-@pytest.mark.parametrize("stype", ["khop3", "khop0", "khop2"])
+@pytest.mark.parametrize("stype", ["khop3", "khop0", "khop2", "khop1"])
 @pytest.mark.parametrize("fanouts,nseed", [([25, 10], 1000), ([5, 10, 15], 300), ([3], 129), ([25, 10], 0)])
 def test_sample_batch_vs_oracle(ops, stype, fanouts, nseed, direct):
     """DoGPUSample (dist_loops.cc:62-368): row/col/num_src/num_dst per layer + input nodes."""
@@ -361,8 +385,8 @@ def test_sample_batch_vs_oracle(ops, stype, fanouts, nseed, direct):
     t_ix = dev(ix)
     g = ops.DeviceGraph(dev(ip), t_ix)
     rng = np.random.RandomState(len(fanouts) * 1000 + nseed)
-    code = {"khop3": ops.KHOP3, "khop0": ops.KHOP0, "khop2": ops.KHOP2}[stype]
-    ocode = {"khop3": oracle.KHOP3, "khop0": oracle.KHOP0, "khop2": oracle.KHOP2}[stype]
+    code = {"khop3": ops.KHOP3, "khop0": ops.KHOP0, "khop2": ops.KHOP2, "khop1": ops.KHOP1}[stype]
+    ocode = {"khop3": oracle.KHOP3, "khop0": oracle.KHOP0, "khop2": oracle.KHOP2, "khop1": oracle.KHOP1}[stype]
     bs = ops.BatchSampler(g, fanouts, max(nseed, 1), sample_type=code, seed=77, direct_table=direct)
     orc_states = oracle.random_states(bs.states.shape[0], 77) if stype != "khop0" else None
     ix = ix.copy()  # khop2 permutes the oracle's CSR too

@@ -43,6 +43,7 @@ SYMBOLS = {
     "ggms_sample_workspace_bytes": (_sz, [_i, _sz, _sz]),
     "ggms_sample_khop3": (_i, [C.POINTER(Graph), _vp, _sz, _sz, _vp, _vp, _vp, _vp, _sz, _vp, _sz, _vp]),
     "ggms_sample_khop0": (_i, [C.POINTER(Graph), _vp, _sz, _sz, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "ggms_sample_khop1": (_i, [C.POINTER(Graph), _vp, _sz, _sz, _vp, _vp, _vp, _vp, _sz, _vp, _sz, _vp]),
     "ggms_sample_khop2": (_i, [C.POINTER(Graph), _vp, _sz, _sz, _vp, _vp, _vp, _vp, _sz, _vp, _sz, _vp]),
     "ggms_sample_weighted_workspace_bytes": (_sz, [_sz, _sz]),
     "ggms_sample_weighted_khop": (_i, [C.POINTER(Graph), _vp, _vp, _vp, _sz, _sz, _vp, _vp, _vp, _vp, _sz, _vp, _sz,

@@ -111,10 +111,12 @@ void Engine::Configure(const std::unordered_map<std::string, std::string> &kv_in
   if (kv.count("presample_epoch")) cfg.presample_epoch = std::stoull(kv["presample_epoch"]); // operation.cc:184-189
   if (kv.count("seed")) { cfg.has_seed = true; cfg.seed = std::stoull(kv["seed"]); }
   if (kv.count("hash_table")) cfg.direct_table = kv["hash_table"] != "hashed";
-  SAM_CHECK(cfg.sample_type == GGMS_KHOP3 || cfg.sample_type == GGMS_KHOP0 || cfg.sample_type == GGMS_KHOP2 ||
-                cfg.sample_type == GGMS_WEIGHTED_KHOP || cfg.sample_type == GGMS_RANDOM_WALK,
-            "sample types built: khop0, khop2, khop3, weighted_khop, random_walk (DESIGN.md)");
-  if (cfg.sample_type == GGMS_WEIGHTED_KHOP || cfg.sample_type == GGMS_KHOP2) // dist_loops.cc:171-172,219-220
+  SAM_CHECK(cfg.sample_type == GGMS_KHOP3 || cfg.sample_type == GGMS_KHOP0 || cfg.sample_type == GGMS_KHOP1 ||
+                cfg.sample_type == GGMS_KHOP2 || cfg.sample_type == GGMS_WEIGHTED_KHOP ||
+                cfg.sample_type == GGMS_RANDOM_WALK,
+            "sample types built: khop0, khop1, khop2, khop3, weighted_khop, random_walk (DESIGN.md)");
+  if (cfg.sample_type == GGMS_WEIGHTED_KHOP || cfg.sample_type == GGMS_KHOP2 ||
+      cfg.sample_type == GGMS_KHOP1) // dist_loops.cc:167-168,171-172,219-220
     SAM_CHECK(!cfg.use_dist_graph, "this algorithm not support DistGraph engine");
   cfg.configured = true;
 }

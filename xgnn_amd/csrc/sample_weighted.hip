@@ -1,10 +1,13 @@
-// sample_weighted.hip -- weighted fan-out sampler (alias method, with replacement).
+// sample_weighted.hip -- with-replacement fan-out samplers: weighted (alias method) and uniform (khop1).
 //
 // Reference: GPUSampleWeightedKHop, cuda/cuda_sampling_weighted_khop.cu:132-238:
 //   sample_weighted_khop :41-76   task t -> seed t / fanout; k = curand % deg; r = curand_uniform;
 //                                 dst = r < prob[off+k] ? indices[off+k] : alias[off+k]
 //                                 (grid-stride over <= 512 K threads, one stored XORWOW state per thread)
 //   cub SortPairs(key = src) :172-181, count_edge / compact_edge :78-128 (drop an entry equal to its successor)
+//
+// GPUSampleKHop1, cuda/cuda_sampling_khop1.cu:130-236, is the same pipeline with one draw per task
+// (dst = indices[off + curand % deg], :65-67) and kKHop1MaxThreads = 512 K (constant.h:71): k_weighted_draw<false>.
 //
 // Kept bit-for-bit: task -> thread -> RNG stream assignment (span = ceil(min(tasks, 512K) / 256) * 256),
 // two draws per task, the stable order by src, the adjacent-duplicate rule (dedup is partial by design).
@@ -19,6 +22,7 @@ namespace ggms {
 
 constexpr uint64_t kWeightedMaxThreads = 512 * 1024; // Constant::kWeightedKHopMaxThreads, constant.h:72
 
+template <bool WEIGHTED>
 __global__ __launch_bounds__(kBlock) void k_weighted_draw(const uint32_t *__restrict__ indptr,
                                                           const uint32_t *__restrict__ indices,
                                                           const float *__restrict__ prob,
@@ -40,8 +44,12 @@ __global__ __launch_bounds__(kBlock) void k_weighted_draw(const uint32_t *__rest
     const uint32_t len = indptr[rid + 1] - off;
     if (len != 0) {
       const uint32_t k = st.next() % len;
-      const float r = st.uniform();
-      tmp_dst[task] = (r < prob[off + k]) ? indices[off + k] : alias[off + k];
+      if (WEIGHTED) {
+        const float r = st.uniform();
+        tmp_dst[task] = (r < prob[off + k]) ? indices[off + k] : alias[off + k];
+      } else {
+        tmp_dst[task] = indices[off + k];
+      }
     }
   }
   st.store(states + 6 * tid);
@@ -117,8 +125,12 @@ int sample_weighted_impl(const uint32_t *indptr, const uint32_t *indices, const 
   uint32_t *scan_scr = w;
   const size_t task_max = n_max * fanout;
   const size_t threads = task_max < kWeightedMaxThreads ? task_max : (size_t)kWeightedMaxThreads;
-  hipLaunchKernelGGL(k_weighted_draw, dim3((unsigned)((threads + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, indptr,
-                     indices, prob, alias, input, n, fanout, tmp_dst, states);
+  if (prob)
+    hipLaunchKernelGGL(k_weighted_draw<true>, dim3((unsigned)((threads + kBlock - 1) / kBlock)), dim3(kBlock), 0, s,
+                       indptr, indices, prob, alias, input, n, fanout, tmp_dst, states);
+  else // khop1: uniform with replacement
+    hipLaunchKernelGGL(k_weighted_draw<false>, dim3((unsigned)((threads + kBlock - 1) / kBlock)), dim3(kBlock), 0, s,
+                       indptr, indices, prob, alias, input, n, fanout, tmp_dst, states);
   GGMS_LAUNCH_CHECK();
   hipLaunchKernelGGL(k_weighted_keys, dim3(grid_for(n_max, kBlock)), dim3(kBlock), 0, s, indptr, input, n, k0, v0);
   GGMS_LAUNCH_CHECK();
@@ -162,6 +174,28 @@ int ggms_sample_weighted_khop(const ggms_graph_t *graph, const float *prob_table
   GGMS_CHECK_ARG((span < tasks ? span : tasks) <= num_states); // assert(thread_id < num_random_states), :52
   return sample_weighted_impl(graph->indptr, graph->indices, prob_table, alias_table, input, num_input,
                               count_of(num_input), (uint32_t)fanout, out_src, out_dst, num_out_dev, (uint32_t *)states,
+                              (uint32_t *)workspace, nullptr, 0, s);
+}
+
+int ggms_sample_khop1(const ggms_graph_t *graph, const ggms_id_t *input, size_t num_input, size_t fanout,
+                      ggms_id_t *out_src, ggms_id_t *out_dst, uint64_t *num_out_dev, void *states,
+                      size_t num_states, void *workspace, size_t workspace_bytes, ggms_stream_t stream) {
+  GGMS_CHECK_ARG(graph && num_out_dev && fanout > 0);
+  GGMS_CHECK_ARG(graph->num_part == 0); // "this algorithm not support DistGraph engine", dist_loops.cc:167-168
+  hipStream_t s = to_stream(stream);
+  if (num_input == 0) {
+    GGMS_HIP(hipMemsetAsync(num_out_dev, 0, sizeof(uint64_t), s));
+    return GGMS_OK;
+  }
+  GGMS_CHECK_ARG(input && out_src && out_dst && states && workspace);
+  GGMS_CHECK_ARG((uint64_t)num_input * fanout < (1ull << 32));
+  GGMS_CHECK_ARG(workspace_bytes >= ggms_sample_weighted_workspace_bytes(num_input, fanout));
+  const uint64_t tasks = (uint64_t)num_input * fanout;
+  const uint64_t threads = tasks < kWeightedMaxThreads ? tasks : kWeightedMaxThreads;
+  const uint64_t span = (threads + 255) / 256 * 256;
+  GGMS_CHECK_ARG((span < tasks ? span : tasks) <= num_states); // assert(thread_id < num_random_states), khop1.cu:51
+  return sample_weighted_impl(graph->indptr, graph->indices, nullptr, nullptr, input, num_input, count_of(num_input),
+                              (uint32_t)fanout, out_src, out_dst, num_out_dev, (uint32_t *)states,
                               (uint32_t *)workspace, nullptr, 0, s);
 }
 
