@@ -38,6 +38,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline: keep sampling mini-batches this long")
     ap.add_argument("--host-profile", action="store_true", help="print host enqueue time per section to stderr")
+    ap.add_argument("--pipelines", type=int, default=3,
+                    help="sampling batches in flight (each on its own stream with its own dedup table)")
     ap.add_argument("--no-overlap", action="store_true",
                     help="one stream: extract of batch k and sampling of batch k+1 run back to back "
                          "(default: two streams, the HBM-bound gather overlaps the latency-bound sampler)")
@@ -186,15 +188,18 @@ def main():
         feat_rows(torch.arange(N, dtype=torch.int64), host_feat)
 
     code = {"khop3": ops.KHOP3, "khop0": ops.KHOP0, "khop2": ops.KHOP2, "khop1": ops.KHOP1}[args.sample_type]
-    NSLOT = 2  # batch slots, as in the engine: outputs of batch k stay valid while batch k+1 is sampled
+    # batches in flight: K sampling pipelines (own stream, dedup table, workspace; RNG pool consumed in batch
+    # order) + the extract stream; outputs live in batch slots, as in the engine
+    K = 1 if args.no_overlap else max(1, args.pipelines)
+    NSLOT = K + 1
     sampler = ops.BatchSampler(g, fanouts, args.batch, sample_type=code, seed=0x5EED + rank, device=dev,
-                               num_slots=NSLOT)
+                               num_slots=NSLOT, num_pipelines=K)
     out = [torch.empty((sampler.max_unique, dim), dtype=torch.float32, device=dev) for _ in range(NSLOT)]
     out_label = [torch.empty(sampler.max_seeds, dtype=torch.int64, device=dev) for _ in range(NSLOT)]
     nmiss = torch.zeros(1, dtype=torch.int64, device=dev)
     L = len(fanouts)
-    s_sample = torch.cuda.Stream(device=dev)
-    s_extract = s_sample if args.no_overlap else torch.cuda.Stream(device=dev)
+    s_samples = [torch.cuda.Stream(device=dev) for _ in range(K)]
+    s_extract = s_samples[0] if args.no_overlap else torch.cuda.Stream(device=dev)
     slot_free = [None] * NSLOT  # event: the slot's previous extract has finished
 
     # DistAlignedShuffler semantics (dist_shuffler_aligned.cc:37-146): pad to a multiple of world,
@@ -223,6 +228,7 @@ def main():
     def run_step(step, timed_idx=None):
         seeds = all_seeds[step]
         slot = step % NSLOT
+        s_sample = s_samples[step % K]
         h0 = time.perf_counter()
         with torch.cuda.stream(s_sample):
             if slot_free[slot] is not None:
@@ -336,11 +342,12 @@ def main():
                             f"seeds DP over {world} GPU(s)",
                 "global_batch": args.batch * world,
                 "parallelism": f"dp{world}",
-                "streams": "1 (serial)" if args.no_overlap else "2 (extract of batch k overlaps sampling of batch k+1)",
+                "streams": "1 (serial)" if args.no_overlap else
+                           f"{K} sampling pipelines (batches in flight, RNG pool consumed in batch order) + 1 extract stream",
             },
             "feature_extract_GBps": feat_rate_all,  # sum over ranks of rows*dim*4 / (time inside the gather kernel)
             "per_gpu": {
-                "sample_ms_per_step": t_sample_ms / args.steps,
+                "sample_ms_per_step": t_sample_ms / args.steps,  # latency of one batch on its pipeline (they overlap)
                 "extract_ms_per_step": t_extract_ms / args.steps,
                 "sample_only_edges_per_s": edges / (t_sample_ms / 1e3),
                 "edges_per_step": edges / args.steps,

@@ -30,6 +30,7 @@ extern "C" {
 
 typedef uint32_t ggms_id_t;
 typedef void *ggms_stream_t;
+typedef void *ggms_event_t;   /* hipEvent_t */
 #define GGMS_EMPTY_KEY 0xffffffffu
 
 enum ggms_status {
@@ -234,7 +235,18 @@ typedef struct {
   size_t num_random_walk;
   ggms_id_t *const *data;         /* random_walk: HOST array of L device pointers, visit counts
                                      (TrainGraph::data, dist_loops.cc:314-319)                */
+  /* Several batches in flight (one stream, table and workspace each) must still consume the
+   * shared RNG pool -- and, for khop2, permute the CSR -- in batch order, as the reference's
+   * one-batch-at-a-time loop does.  The sampler kernels of this batch wait for `rng_wait` and
+   * `rng_done` is recorded right after the last of them; everything else of the batch (table
+   * fills, scans, id mapping) is free to overlap with the neighbouring batches.  NULL = none. */
+  ggms_event_t rng_wait;
+  ggms_event_t rng_done;
 } ggms_sample_extra_t;
+
+/* events for the ordering above (thin hipEvent_t handles, timing disabled) */
+int ggms_event_create(ggms_event_t *event);
+int ggms_event_destroy(ggms_event_t event);
 
 int ggms_sample_batch_capacity(size_t num_seeds, const size_t *fanouts,
                                uint32_t num_layer, size_t *max_input,

@@ -407,6 +407,40 @@ def test_sample_batch_vs_oracle(ops, stype, fanouts, nseed, direct):
     np.testing.assert_array_equal(host_u32(t_ix), ix)  # untouched, or permuted identically (khop2)
 
 
+@pytest.mark.parametrize("stype", ["khop3", "khop2", "khop1", "khop0"])
+def test_batches_in_flight_keep_batch_order(ops, stype):
+    """Three batches in flight on three streams (own table + workspace each) must give exactly what the
+    one-at-a-time loop gives: the RNG pool / khop2's CSR are consumed in batch order (rng_wait / rng_done)."""
+    ip, ix = powerlaw_csr(20_000, mean_deg=30, seed=4)
+    t_ix = dev(ix)
+    g = ops.DeviceGraph(dev(ip), t_ix)
+    fanouts, nseed, K, NB = [10, 5], 1500, 3, 7
+    code = {"khop3": ops.KHOP3, "khop0": ops.KHOP0, "khop2": ops.KHOP2, "khop1": ops.KHOP1}[stype]
+    ocode = {"khop3": oracle.KHOP3, "khop0": oracle.KHOP0, "khop2": oracle.KHOP2, "khop1": oracle.KHOP1}[stype]
+    bs = ops.BatchSampler(g, fanouts, nseed, sample_type=code, seed=5, num_slots=NB, num_pipelines=K)
+    orc_states = oracle.random_states(bs.states.shape[0], 5) if stype != "khop0" else None
+    rng = np.random.RandomState(8)
+    seeds = [rng.permutation(20_000)[:nseed].astype(np.uint32) for _ in range(NB)]
+    t_seeds = [dev(x) for x in seeds]
+    streams = [torch.cuda.Stream() for _ in range(K)]
+    torch.cuda.synchronize()
+    for b in range(NB):
+        with torch.cuda.stream(streams[b % K]):
+            bs.sample(t_seeds[b], slot=b, copy_input_nodes=True)
+    torch.cuda.synchronize()
+    ix = ix.copy()
+    for b in range(NB):
+        want = oracle.do_sample(ocode, ip, ix, seeds[b], fanouts, orc_states)
+        c = bs.counts_slots[b].cpu().tolist()
+        np.testing.assert_array_equal(host_u32(bs.input_nodes[b], c[3 * len(fanouts)]), want["input_nodes"])
+        for i in range(len(fanouts)):
+            wl = want["layers"][i]
+            assert (c[3 * i], c[3 * i + 1], c[3 * i + 2]) == (wl["row"].size, wl["num_src"], wl["num_dst"]), (b, i)
+            np.testing.assert_array_equal(host_u32(bs.rows[b][i], c[3 * i]), wl["row"], err_msg=f"row {b}/{i}")
+            np.testing.assert_array_equal(host_u32(bs.cols[b][i], c[3 * i]), wl["col"], err_msg=f"col {b}/{i}")
+    np.testing.assert_array_equal(host_u32(t_ix), ix)
+
+
 @pytest.mark.parametrize("stype", ["weighted", "random_walk"])
 def test_sample_batch_weighted_and_random_walk(ops, stype):
     """DoGPUSample with the weighted (alias) sampler and with PinSAGE random walks (row/col/data)."""

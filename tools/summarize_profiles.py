@@ -1,0 +1,107 @@
+"""Turn the raw rocprofv3 output of tools/collect_profiles.sh into the summaries kept under profiles/.
+
+    python tools/summarize_profiles.py gpurun_out/profiles_<tag> profiles/<round>   [steps+warmup, default 23]
+
+writes
+    <round>_kernel_stats.csv        rocprofv3's own --stats table, ggms kernels + copies only
+    <round>_kernel_timeline.csv     per kernel: launches per step, avg/min/max us, and per HSA queue the
+                                    busy / idle time between the first and the last ggms launch
+    <round>_pmc_hbm_traffic.csv     FETCH_SIZE / WRITE_SIZE per kernel (raw KB, separate passes)
+    <round>_extract_traffic.json    the gather kernel's HBM bytes per launch, corrected as
+                                    /opt/skills/guides/MI355X_MICROARCH.md (HBM section) prescribes;
+                                    bench.py reads it for roofline.traffic
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+
+def one(pattern):
+    f = glob.glob(pattern)
+    if not f:
+        raise SystemExit(f"missing {pattern}")
+    return f[0]
+
+
+def main():
+    src, dst = sys.argv[1], sys.argv[2]
+    launches = int(sys.argv[3]) if len(sys.argv) > 3 else 23
+    os.makedirs(os.path.dirname(dst) or ".", exist_ok=True)
+
+    # ---- rocprofv3 --stats table, filtered
+    rows = list(csv.reader(open(one(f"{src}/trace/*/*_kernel_stats.csv"))))
+    with open(f"{dst}_kernel_stats.csv", "w", newline="") as f:
+        w = csv.writer(f, quoting=csv.QUOTE_NONNUMERIC)
+        w.writerow(rows[0])
+        for r in rows[1:]:
+            if "ggms" in r[0] or "Copy" in r[0] or "copy" in r[0]:
+                w.writerow(r)
+
+    # ---- timeline: per-kernel durations + queue gaps over the region that holds the ggms launches
+    tr = list(csv.DictReader(open(one(f"{src}/trace/*/*_kernel_trace.csv"))))
+    per = collections.OrderedDict()
+    queues = collections.defaultdict(list)
+    for r in tr:
+        if "ggms" not in r["Kernel_Name"]:
+            continue
+        s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
+        per.setdefault(r["Kernel_Name"], []).append((e - s) / 1e3)
+        queues[r["Queue_Id"]].append((s, e))
+    with open(f"{dst}_kernel_timeline.csv", "w", newline="") as f:
+        w = csv.writer(f, quoting=csv.QUOTE_NONNUMERIC)
+        w.writerow(["kernel", "launches", "launches_per_step", "avg_us", "min_us", "max_us", "us_per_step"])
+        for k, v in sorted(per.items(), key=lambda kv: -sum(kv[1])):
+            w.writerow([k, len(v), round(len(v) / launches, 2), round(sum(v) / len(v), 2), round(min(v), 2),
+                        round(max(v), 2), round(sum(v) / launches, 2)])
+        w.writerow([])
+        w.writerow(["queue", "ggms_launches", "span_us", "busy_us", "idle_us", "idle_per_launch_us"])
+        for q, iv in sorted(queues.items()):
+            iv.sort()
+            # drop the warm-up / one-off launches: keep the densest tail (last 80 % of launches)
+            iv = iv[len(iv) // 5:]
+            span = (iv[-1][1] - iv[0][0]) / 1e3
+            busy = sum(e - s for s, e in iv) / 1e3
+            w.writerow([q, len(iv), round(span, 1), round(busy, 1), round(span - busy, 1),
+                        round((span - busy) / max(1, len(iv) - 1), 2)])
+
+    # ---- PMC passes
+    pmc = collections.OrderedDict()
+    for sub in ("pmc_fetch", "pmc_write"):
+        for r in csv.DictReader(open(one(f"{src}/{sub}/*/*_counter_collection.csv"))):
+            if "ggms" not in r["Kernel_Name"]:
+                continue
+            pmc.setdefault((r["Kernel_Name"], r["Counter_Name"]), []).append(float(r["Counter_Value"]))
+    with open(f"{dst}_pmc_hbm_traffic.csv", "w", newline="") as f:
+        w = csv.writer(f, quoting=csv.QUOTE_NONNUMERIC)
+        w.writerow(["kernel", "counter", "dispatches", "avg_value_KB", "max_value_KB"])
+        for (k, c), v in sorted(pmc.items(), key=lambda kv: -sum(kv[1])):
+            w.writerow([k, c, len(v), sum(v) / len(v), max(v)])
+
+    # ---- the gather kernel of the bench (CachedRows): bytes per launch
+    bench = json.loads(open(f"{src}/bench_trace.json").read().strip().splitlines()[-1])
+    rows_per_launch = bench["per_gpu"]["rows_per_step"]
+    row_bytes = bench["roofline"]["algorithmic_bytes_per_row"]
+    gk = [k for (k, c) in pmc if "k_gather_rows" in k and "CachedRows" in k and c == "FETCH_SIZE"]
+    out = {"kernel": gk[0] if gk else None,
+           "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE -- python bench.py --steps 20 --warmup 3 --no-cpu-baseline",
+           "rows_per_launch": rows_per_launch}
+    if gk:
+        fetch = pmc[(gk[0], "FETCH_SIZE")]
+        write = pmc[(gk[0], "WRITE_SIZE")]
+        out["FETCH_SIZE_KB_raw"] = sum(fetch) / len(fetch)
+        out["WRITE_SIZE_KB"] = sum(write) / len(write)
+        out["fetch_correction"] = ("x2 (MI355X_MICROARCH.md HBM section: gfx950 FETCH_SIZE tallies 128-B requests at "
+                                   "64 B for 16-B/lane loads)")
+        out["hbm_bytes_per_launch"] = (2 * out["FETCH_SIZE_KB_raw"] + out["WRITE_SIZE_KB"]) * 1024
+        out["algorithmic_bytes_per_launch"] = rows_per_launch * row_bytes
+    with open(f"{dst}_extract_traffic.json", "w") as f:
+        json.dump(out, f, indent=1)
+    print(json.dumps(out, indent=1))
+    print(open(f"{dst}_kernel_timeline.csv").read())
+
+
+if __name__ == "__main__":
+    main()

@@ -22,7 +22,8 @@ class Graph(C.Structure):
 class SampleExtra(C.Structure):
     """ggms_sample_extra_t"""
     _fields_ = [("prob_table", C.c_void_p), ("alias_table", C.c_void_p), ("random_walk_length", C.c_size_t),
-                ("random_walk_restart_prob", C.c_double), ("num_random_walk", C.c_size_t), ("data", C.c_void_p)]
+                ("random_walk_restart_prob", C.c_double), ("num_random_walk", C.c_size_t), ("data", C.c_void_p),
+                ("rng_wait", C.c_void_p), ("rng_done", C.c_void_p)]
 
 
 class HashTable(C.Structure):
@@ -52,6 +53,8 @@ SYMBOLS = {
     "ggms_random_walk_num_states": (_sz, [_sz, _sz]),
     "ggms_sample_random_walk": (_i, [C.POINTER(Graph), _vp, _sz, _sz, C.c_double, _sz, _sz, _vp, _vp, _vp, _vp, _vp,
                                      _sz, _vp, _sz, _vp]),
+    "ggms_event_create": (_i, [C.POINTER(C.c_void_p)]),
+    "ggms_event_destroy": (_i, [_vp]),
     "ggms_sample_batch_capacity": (_i, [_sz, C.POINTER(_sz), _u32, C.POINTER(_sz), C.POINTER(_sz), C.POINTER(_sz)]),
     "ggms_sample_batch_workspace_bytes": (_sz, [_i, _sz, C.POINTER(_sz), _u32, C.POINTER(SampleExtra)]),
     "ggms_sample_batch": (_i, [_i, C.POINTER(Graph), _vp, _sz, C.POINTER(_sz), _u32, C.POINTER(HashTable), _vp, _sz,

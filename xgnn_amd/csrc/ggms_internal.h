@@ -33,12 +33,19 @@ int sample_random_walk_impl(GraphView g, const uint32_t *input, size_t n_max, Co
 
 // hashtable.hip
 size_t ht_ws_words(size_t num_input);
+// What the first kernel of a batch (the insert of the seeds) does on the side: clear the shared scan area's
+// control words + single-pass descriptors, reset the table's item count, record |seeds|.
+struct BatchPrologue {
+  uint32_t *zero_words;
+  uint32_t num_zero;
+  uint32_t *num_items;
+  uint64_t *record_n;
+};
 // insert + ordered local-id assignment; item_pos[i] = bucket of input[i] (hashed layout only).
-// mirror_a/b (optional): 64-bit device slots that also receive the new item count
+// mirror_a/b (optional): 64-bit device slots that also receive the new item count.
+// mapped (optional): mapped[i] = local id of input[i] (the dst half of GPUMapEdges, fused).
 int ht_fill_impl(const ggms_hashtable_t *ht, const uint32_t *input, size_t n_max, Count n, uint32_t *item_pos,
-                 ScanArea scan, uint64_t *mirror_a, uint64_t *mirror_b, hipStream_t s);
-// out[i] = local id of the i-th inserted item (hashed: through item_pos; direct: through keys)
-int ht_map_by_pos(const ggms_hashtable_t *ht, const uint32_t *item_pos, const uint32_t *keys, size_t n_max, Count n,
-                  uint32_t *out, hipStream_t s);
+                 ScanArea scan, uint64_t *mirror_a, uint64_t *mirror_b, hipStream_t s, uint32_t *mapped = nullptr,
+                 const BatchPrologue *prologue = nullptr);
 
 } // namespace ggms

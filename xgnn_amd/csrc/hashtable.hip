@@ -91,10 +91,18 @@ struct Table {
 };
 
 // generate_hashmap_duplicates (cuda_hashtable.cu:151-168) + ownership by atomicMin
+// pro: the batch prologue rides on the first kernel of a batch (three 5-us launches less)
 template <bool DIRECT>
 __global__ __launch_bounds__(kBlock) void k_ht_insert(Table t, const uint32_t *__restrict__ items, Count n_arg,
-                                                      uint32_t *__restrict__ item_pos) {
+                                                      uint32_t *__restrict__ item_pos, BatchPrologue pro) {
   const uint64_t n = n_arg.get();
+  if (blockIdx.x == 0) {
+    for (uint32_t z = threadIdx.x; z < pro.num_zero; z += kBlock) pro.zero_words[z] = 0u;
+    if (threadIdx.x == 0) {
+      if (pro.num_items) *pro.num_items = 0u;
+      if (pro.record_n) *pro.record_n = n;
+    }
+  }
   for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (uint64_t)gridDim.x * kBlock) {
     const uint32_t key = items[i];
     uint32_t pos = key;
@@ -116,16 +124,20 @@ struct OwnerFlag {
     return *t.w1<DIRECT>(item_pos[i]) == make_w1(t.version, 1u, (uint32_t)i) ? 1u : 0u;
   }
 };
+// mapped (optional): local id of instance i -- known right here for the owners; the others get kEmptyKey and
+// are looked up by k_map_rest once every owner has written its word
 template <bool DIRECT>
 struct AssignLocal {
   Table t;
   const uint32_t *items;
   const uint32_t *item_pos;
+  uint32_t *mapped;
   __device__ __forceinline__ void operator()(uint64_t i, uint32_t flag, uint32_t local) const {
     if (flag) {
       *t.w1<DIRECT>(item_pos[i]) = make_w1(t.version, 0u, local);
       t.n2o[local] = items[i];
     }
+    if (mapped) mapped[i] = flag ? local : kEmptyKey;
   }
 };
 
@@ -159,42 +171,51 @@ static inline Table table_of(const ggms_hashtable_t *ht) {
   return Table{(unsigned long long *)ht->o2n, ht->n2o, (uint32_t)(ht->o2n_size - 1), ht->version};
 }
 
+// the instances that do not own their key (AssignLocal left kEmptyKey): read the owner's local id
 template <bool DIRECT>
-__global__ __launch_bounds__(kBlock) void k_map_by_pos(Table t, const uint32_t *__restrict__ item_pos, Count n_arg,
-                                                       uint32_t *__restrict__ out) {
+__global__ __launch_bounds__(kBlock) void k_map_rest(Table t, const uint32_t *__restrict__ item_pos, Count n_arg,
+                                                     uint32_t *__restrict__ out) {
   const uint64_t n = n_arg.get();
   for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (uint64_t)gridDim.x * kBlock)
-    out[i] = (uint32_t)*t.w1<DIRECT>(item_pos[i]);
+    if (out[i] == kEmptyKey) out[i] = (uint32_t)*t.w1<DIRECT>(item_pos[i]);
 }
 
 size_t ht_ws_words(size_t num_input) { return num_input + tile_scan_words(num_input) + 16; }
 
+// mapped != NULL: also produce the local id of every input instance (FillWithDuplicates + the dst half of
+// GPUMapEdges in one go): owners write theirs while assigning, k_map_rest looks up the rest.
+// clear_area: this is the first kernel of a batch -- it also zeroes the shared scan area's control words.
 int ht_fill_impl(const ggms_hashtable_t *ht, const uint32_t *input, size_t n_max, Count n, uint32_t *item_pos,
-                 ScanArea scratch, uint64_t *mirror_a, uint64_t *mirror_b, hipStream_t s) {
-  if (n_max == 0) return GGMS_OK;
+                 ScanArea scratch, uint64_t *mirror_a, uint64_t *mirror_b, hipStream_t s, uint32_t *mapped,
+                 const BatchPrologue *prologue) {
+  BatchPrologue pro{nullptr, 0, nullptr, nullptr};
+  if (prologue) pro = *prologue;
+  if (n_max == 0) { // no kernel to ride on
+    if (pro.num_zero) GGMS_HIP(hipMemsetAsync(pro.zero_words, 0, pro.num_zero * sizeof(uint32_t), s));
+    if (pro.num_items) GGMS_HIP(hipMemsetAsync(pro.num_items, 0, sizeof(uint32_t), s));
+    if (pro.record_n) GGMS_HIP(hipMemsetAsync(pro.record_n, 0, sizeof(uint64_t), s));
+    return GGMS_OK;
+  }
   Table t = table_of(ht);
   const int grid = grid_for(n_max, kBlock);
+  int rc;
   if (ht->direct) {
-    hipLaunchKernelGGL(k_ht_insert<true>, dim3(grid), dim3(kBlock), 0, s, t, input, n, item_pos);
+    hipLaunchKernelGGL(k_ht_insert<true>, dim3(grid), dim3(kBlock), 0, s, t, input, n, item_pos, pro);
     GGMS_LAUNCH_CHECK();
     scratch.stash = item_pos; // the direct layout does not use item_pos: it holds the owner flags between passes
-    return tile_scan(OwnerFlag<true>{t, input}, AssignLocal<true>{t, input, input}, n_max, n, scratch,
-                     ht->num_items_dev, ht->num_items_dev, nullptr, s, mirror_a, mirror_b);
-  }
-  hipLaunchKernelGGL(k_ht_insert<false>, dim3(grid), dim3(kBlock), 0, s, t, input, n, item_pos);
-  GGMS_LAUNCH_CHECK();
-  return tile_scan(OwnerFlag<false>{t, item_pos}, AssignLocal<false>{t, input, item_pos}, n_max, n, scratch,
+    rc = tile_scan(OwnerFlag<true>{t, input}, AssignLocal<true>{t, input, input, mapped}, n_max, n, scratch,
                    ht->num_items_dev, ht->num_items_dev, nullptr, s, mirror_a, mirror_b);
-}
-
-int ht_map_by_pos(const ggms_hashtable_t *ht, const uint32_t *item_pos, const uint32_t *keys, size_t n_max, Count n,
-                  uint32_t *out, hipStream_t s) {
-  if (n_max == 0) return GGMS_OK;
-  const int grid = grid_for(n_max, kBlock);
+  } else {
+    hipLaunchKernelGGL(k_ht_insert<false>, dim3(grid), dim3(kBlock), 0, s, t, input, n, item_pos, pro);
+    GGMS_LAUNCH_CHECK();
+    rc = tile_scan(OwnerFlag<false>{t, item_pos}, AssignLocal<false>{t, input, item_pos, mapped}, n_max, n, scratch,
+                   ht->num_items_dev, ht->num_items_dev, nullptr, s, mirror_a, mirror_b);
+  }
+  if (rc != GGMS_OK || !mapped) return rc;
   if (ht->direct)
-    hipLaunchKernelGGL(k_map_by_pos<true>, dim3(grid), dim3(kBlock), 0, s, table_of(ht), keys, n, out);
+    hipLaunchKernelGGL(k_map_rest<true>, dim3(grid), dim3(kBlock), 0, s, t, input, n, mapped);
   else
-    hipLaunchKernelGGL(k_map_by_pos<false>, dim3(grid), dim3(kBlock), 0, s, table_of(ht), item_pos, n, out);
+    hipLaunchKernelGGL(k_map_rest<false>, dim3(grid), dim3(kBlock), 0, s, t, item_pos, n, mapped);
   GGMS_LAUNCH_CHECK();
   return GGMS_OK;
 }
@@ -253,7 +274,7 @@ int ggms_hashtable_fill_with_duplicates(ggms_hashtable_t *ht, const ggms_id_t *i
     GGMS_CHECK_ARG(num_input < (1ull << 32));
     uint32_t *item_pos = (uint32_t *)workspace;
     int rc = ht_fill_impl(ht, input, num_input, count_of(num_input), item_pos,
-                          ScanArea{item_pos + num_input, false}, nullptr, nullptr, s);
+                          ScanArea{item_pos + num_input, false}, nullptr, nullptr, s, nullptr, nullptr);
     if (rc != GGMS_OK) return rc;
   }
   if (unique_out) {

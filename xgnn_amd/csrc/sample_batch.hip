@@ -57,6 +57,19 @@ using namespace ggms;
 
 extern "C" {
 
+int ggms_event_create(ggms_event_t *event) {
+  GGMS_CHECK_ARG(event);
+  hipEvent_t e;
+  GGMS_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  *event = (ggms_event_t)e;
+  return GGMS_OK;
+}
+
+int ggms_event_destroy(ggms_event_t event) {
+  if (event) GGMS_HIP(hipEventDestroy((hipEvent_t)event));
+  return GGMS_OK;
+}
+
 int ggms_sample_batch_capacity(size_t num_seeds, const size_t *fanouts, uint32_t num_layer, size_t *max_input,
                                size_t *max_edges, size_t *max_unique) {
   GGMS_CHECK_ARG(fanouts && num_layer >= 1 && num_layer <= 16);
@@ -133,23 +146,26 @@ int ggms_sample_batch(int sample_type, const ggms_graph_t *graph, const ggms_id_
   // cleared once here: descriptors are epoch-tagged, the control words re-arm themselves
   ScanArea scan{w, true};
   const size_t scan_items = std::max(c.max_e_all, c.max_in_all);
-  if (!scan_three_pass()) { // only the single-pass form keeps control words in the area
+  if (scan_mode() == 1) { // every scan single-pass: the whole descriptor region, by memset
     int rc0 = clear_scan_area(scan.words, scan_items, s);
     if (rc0 != GGMS_OK) return rc0;
   }
 
   const GraphView g = view_of(graph);
-  int rc = ggms_hashtable_reset(ht, stream); // hash_table->Reset, dist_loops.cc:105
+  // hash_table->Reset (dist_loops.cc:105): a new version stamp; the item count is zeroed by the prologue below
+  if (ht->version >= 0x7ffffff0u) {
+    int rc0 = ggms_hashtable_init(ht, stream);
+    if (rc0 != GGMS_OK) return rc0;
+  }
+  ht->version += 1;
+  // FillWithDupRevised(seeds), dist_loops.cc:110-111, + the local ids of the raw seeds (they may repeat): the
+  // first layer's `col`.  Its insert kernel is the first kernel of the batch and carries the prologue:
+  // scan-area clear, item count reset, num_dst of the first layer = |seeds| (dist_loops.cc:305).
+  const BatchPrologue pro{scan_align(scan.words), (uint32_t)scan_clear_words(scan_items), ht->num_items_dev,
+                          counts_dev + 3 * (num_layer - 1) + 2};
+  int rc = ht_fill_impl(ht, seeds, num_seeds, count_of(num_seeds), item_pos, scan, nullptr, nullptr, s, seed_local,
+                        &pro);
   if (rc != GGMS_OK) return rc;
-  // FillWithDupRevised(seeds), dist_loops.cc:110-111 (item_pos doubles as scratch here)
-  rc = ht_fill_impl(ht, seeds, num_seeds, count_of(num_seeds), item_pos, scan, nullptr, nullptr, s);
-  if (rc != GGMS_OK) return rc;
-  // local ids of the raw seeds (they may repeat): first-layer `col`
-  rc = ht_map_by_pos(ht, item_pos, seeds, num_seeds, count_of(num_seeds), seed_local, s);
-  if (rc != GGMS_OK) return rc;
-  // num_dst of the first layer = |seeds| (dist_loops.cc:305); later layers get theirs from the fill
-  hipLaunchKernelGGL(k_record, dim3(1), dim3(64), 0, s, counts_dev + 3 * (num_layer - 1) + 2, count_of(num_seeds));
-  GGMS_LAUNCH_CHECK();
 
   for (int i = (int)num_layer - 1; i >= 0; --i) {
     const bool first = (i == (int)num_layer - 1);
@@ -160,6 +176,8 @@ int ggms_sample_batch(int sample_type, const ggms_graph_t *graph, const ggms_id_
     uint64_t *num_src = counts_dev + 3 * i + 1;                       // unique nodes after this layer (:304)
     uint64_t *next_dst = i > 0 ? counts_dev + 3 * (i - 1) + 2         // = next layer's frontier size (:305)
                                : counts_dev + 3 * num_layer;          // = number of input nodes
+    // batch order on the shared RNG pool (and on khop2's CSR): only the sampler kernels are ordered
+    if (first && extra && extra->rng_wait) GGMS_HIP(hipStreamWaitEvent(s, (hipEvent_t)extra->rng_wait, 0));
     if (n_max == 0) {
       GGMS_HIP(hipMemsetAsync(num_edge, 0, sizeof(uint64_t), s));
     } else if (sample_type == GGMS_KHOP3) {
@@ -187,6 +205,7 @@ int ggms_sample_batch(int sample_type, const ggms_graph_t *graph, const ggms_id_
                                    samp_ws, first ? seed_local : nullptr, 1, s);
     }
     if (rc != GGMS_OK) return rc;
+    if (i == 0 && extra && extra->rng_done) GGMS_HIP(hipEventRecord((hipEvent_t)extra->rng_done, s));
     const Count ne = count_of(e_max, num_edge);
     if (e_max == 0) { // nothing can be sampled: the counts are the current table size
       hipLaunchKernelGGL(k_record, dim3(1), dim3(64), 0, s, num_src, count_of32(0, ht->num_items_dev));
@@ -194,9 +213,8 @@ int ggms_sample_batch(int sample_type, const ggms_graph_t *graph, const ggms_id_
       GGMS_LAUNCH_CHECK();
       continue;
     }
-    rc = ht_fill_impl(ht, tmp_dst, e_max, ne, item_pos, scan, num_src, next_dst, s); // FillWithDuplicates, :279
-    if (rc != GGMS_OK) return rc;
-    rc = ht_map_by_pos(ht, item_pos, tmp_dst, e_max, ne, row[i], s);    // GPUMapEdges dst half, :296
+    // FillWithDuplicates (:279) + the dst half of GPUMapEdges (:296): row[i] = local id of every sampled neighbour
+    rc = ht_fill_impl(ht, tmp_dst, e_max, ne, item_pos, scan, num_src, next_dst, s, row[i]);
     if (rc != GGMS_OK) return rc;
   }
   return GGMS_OK;

@@ -75,157 +75,170 @@ __device__ __forceinline__ uint32_t row_shr(uint32_t v, uint32_t fill) {
   return (uint32_t)__builtin_amdgcn_update_dpp((int)fill, (int)v, 0x110 + S, 0xf, 0xf, false);
 }
 
-__global__ __launch_bounds__(128) void k_khop3_positions(GraphView g, const uint32_t *__restrict__ input,
-                                                         Count n_arg, uint32_t fanout,
-                                                         const uint32_t *__restrict__ offset,
-                                                         uint32_t *__restrict__ out_src,
-                                                         uint32_t *__restrict__ out_dst,
-                                                         uint32_t *__restrict__ states, SrcMode sm,
-                                                         uint32_t set_mask) {
+//
+// Only seeds with more neighbours than `fanout` enter the serial loop; the "take them all" seeds
+// consume no draws and are filled in by k_gather_neighbours.  GPW = groups per wave64: 4 packs the
+// lanes (large frontiers: the loop is issue-bound), 1 gives every group a wave of its own (small
+// frontiers: the chip has idle SIMDs and a group no longer waits for its three neighbours).
+template <int GPW>
+__global__ __launch_bounds__(128 * (4 / GPW)) void k_khop3_positions(GraphView g, const uint32_t *__restrict__ input,
+                                                                     Count n_arg, uint32_t fanout,
+                                                                     const uint32_t *__restrict__ offset,
+                                                                     uint32_t *__restrict__ out_dst,
+                                                                     uint32_t *__restrict__ states,
+                                                                     uint32_t set_mask) {
   constexpr uint32_t HASH_EMPTY = 0xffffffffu;
   __shared__ uint32_t set_tab[8][128]; // one open-addressing set per group; set_mask + 1 slots in use
+  const uint32_t lane = threadIdx.x & 63u;
+  if (GPW < 4 && lane >= 16u * GPW) return; // the unused lanes of a sparse wave
   const uint64_t n = n_arg.get();
-  const uint32_t y = threadIdx.x >> 4, lig = threadIdx.x & 15;
-  const uint32_t grp_shift = (threadIdx.x & 63u) & ~15u; // first lane of my group inside the wave
+  const uint32_t y = (threadIdx.x >> 6) * GPW + (lane >> 4), lig = lane & 15u;
+  const uint32_t grp_shift = lane & ~15u; // first lane of my group inside the wave
   uint32_t *const tab = set_tab[y];
   const uint64_t num_blocks = (n + 127) / 128;
 
   for (uint32_t s = lig; s <= set_mask; s += 16) tab[s] = HASH_EMPTY;
+  bool dirty = false; // group-uniform: the set holds entries
 
   for (uint64_t b = blockIdx.x; b < num_blocks; b += gridDim.x) {
     const uint64_t stream = 8 * b + y;
+    // lane lig fetches seed k = lig of the group: id -> (degree, output offset, 2^32/deg)
+    const uint64_t my_index = 128 * b + y + 8 * (uint64_t)lig;
+    uint32_t my_len = 0, my_off = 0, my_magic = 0;
+    if (my_index < n) {
+      g.neighbours(input[my_index], my_len);
+      my_off = offset[my_index];
+      if (my_len > fanout) my_magic = (uint32_t)(4294967296.0 / (double)my_len); // floor(2^32 / len), exact
+    }
+    // seeds of the group that draw, in order k = 0..15
+    uint32_t todo = (uint32_t)(__ballot(my_len > fanout) >> grp_shift) & 0xffffu;
+    if (__builtin_expect(todo == 0, 0)) continue; // the stream is not touched (khop3.cu:111-116 draws nothing)
     Xorwow st;
     st.load(states + 6 * stream);
-    // lane lig fetches seed k = lig of the group: id -> (degree, output offset, src value, 2^32/deg)
-    const uint64_t my_index = 128 * b + y + 8 * (uint64_t)lig;
-    const bool my_valid = my_index < n;
-    uint32_t my_len = 0, my_off = 0, my_sv = 0, my_magic = 0;
-    if (my_valid) {
-      const uint32_t rid = input[my_index];
-      g.neighbours(rid, my_len);
-      my_off = offset[my_index];
-      my_sv = sm.value(rid, my_index);
-      if (my_len > 1) my_magic = (uint32_t)(4294967296.0 / (double)my_len); // floor(2^32 / len), exact
-    }
 
-    int k = -1;
-    bool seed_done = true, alive = true;
-    uint32_t len = 0, o = 0, sv = 0, magic = 0, count = 0;
-    while (__any(alive)) {
-      if (alive) {
-        if (seed_done) {
-          ++k;
-          const int src_lane = (int)grp_shift + (k < 16 ? k : 15);
-          const bool valid_k = (k < 16) && (__shfl((int)my_valid, src_lane, 64) != 0);
-          len = __shfl(my_len, src_lane, 64);
-          o = __shfl(my_off, src_lane, 64);
-          sv = __shfl(my_sv, src_lane, 64);
-          magic = __shfl(my_magic, src_lane, 64);
-          count = 0;
-          seed_done = false;
-          if (!valid_k) alive = false;
-        }
-        if (alive) {
-          if (len <= fanout) {
-            // every neighbour, in list order (khop3.cu:111-116)
-            for (uint32_t j = lig; j < len; j += 16) {
-              out_src[o + j] = sv;
-              out_dst[o + j] = j;
-            }
-            seed_done = true;
-          } else {
-            // ---- one round: 16 consecutive draws of the stream
-            const Xorwow st0 = st;
-            uint32_t x = 0;
+    bool fetch = true;
+    uint32_t len = 0, o = 0, magic = 0, count = 0;
+    while (todo != 0) {
+      if (fetch) {
+        const int src_lane = (int)(grp_shift + (uint32_t)__ffs(todo) - 1u);
+        len = __shfl(my_len, src_lane, 64);
+        o = __shfl(my_off, src_lane, 64);
+        magic = __shfl(my_magic, src_lane, 64);
+        count = 0;
+        fetch = false;
+      }
+      // ---- one round: 16 consecutive draws of the stream; lane lig keeps draw lig.
+      // w = the raw xorshift word of my draw: the generator's v-array is a sliding window over the
+      // sequence (old v0..v4, w of draw 0, w of draw 1, ...), which is what the rewind below reads.
+      const Xorwow st0 = st;
+      uint32_t x = 0, w = 0;
 #pragma unroll
-            for (uint32_t i = 0; i < 16; ++i) {
-              const uint32_t xi = st.next();
-              x = (lig == i) ? xi : x;
-            }
-            // r = x mod len: q' = mulhi(x, floor(2^32/len)) is q or q - 1 (two fix-ups for safety)
-            uint32_t r = x - __umulhi(x, magic) * len;
-            r = min(r, r - len);
-            r = min(r, r - len);
-            // already chosen for this seed?
-            bool in_set = false;
-            {
-              uint32_t pos = r & set_mask;
-              for (;;) {
-                const uint32_t cur = tab[pos];
-                if (cur == HASH_EMPTY) break;
-                if (cur == r) { in_set = true; break; }
-                pos = (pos + 1) & set_mask;
-              }
-            }
-            // equal to an EARLIER candidate of this round?
-            bool dup = false;
-            dup |= row_shr<1>(r, HASH_EMPTY) == r;
-            dup |= row_shr<2>(r, HASH_EMPTY) == r;
-            dup |= row_shr<3>(r, HASH_EMPTY) == r;
-            dup |= row_shr<4>(r, HASH_EMPTY) == r;
-            dup |= row_shr<5>(r, HASH_EMPTY) == r;
-            dup |= row_shr<6>(r, HASH_EMPTY) == r;
-            dup |= row_shr<7>(r, HASH_EMPTY) == r;
-            dup |= row_shr<8>(r, HASH_EMPTY) == r;
-            dup |= row_shr<9>(r, HASH_EMPTY) == r;
-            dup |= row_shr<10>(r, HASH_EMPTY) == r;
-            dup |= row_shr<11>(r, HASH_EMPTY) == r;
-            dup |= row_shr<12>(r, HASH_EMPTY) == r;
-            dup |= row_shr<13>(r, HASH_EMPTY) == r;
-            dup |= row_shr<14>(r, HASH_EMPTY) == r;
-            dup |= row_shr<15>(r, HASH_EMPTY) == r;
-            const bool is_new = !in_set && !dup;
-            const uint32_t new_mask = (uint32_t)(__ballot(is_new) >> grp_shift) & 0xffffu;
-            const uint32_t rank = __popc(new_mask & ((1u << lig) - 1u));
-            const uint32_t total_new = __popc(new_mask);
-            const uint32_t need = fanout - count;
-            const bool completes = total_new >= need;
-            const bool accept = is_new && rank < need;
-            if (accept) {
-              // insertion order == output order (items[] of khop3.cu:64)
-              out_src[o + count + rank] = sv;
-              out_dst[o + count + rank] = r;
-            }
-            if (completes) {
-              // rewind the generator to just after the draw that completed the set
-              const uint32_t last_mask = (uint32_t)(__ballot(accept && rank == need - 1) >> grp_shift) & 0xffffu;
-              const uint32_t tstar = __ffs(last_mask) - 1;
-              st = st0;
-              for (uint32_t i = 0; i <= tstar; ++i) st.next();
-              __builtin_amdgcn_wave_barrier();
-              for (uint32_t s = lig; s <= set_mask; s += 16) tab[s] = HASH_EMPTY; // next seed starts empty
-              __builtin_amdgcn_wave_barrier();
-              seed_done = true;
-            } else {
-              __builtin_amdgcn_wave_barrier();
-              if (accept) {
-                uint32_t pos = r & set_mask;
-                while (atomicCAS(&tab[pos], HASH_EMPTY, r) != HASH_EMPTY) pos = (pos + 1) & set_mask;
-              }
-              __builtin_amdgcn_wave_barrier();
-              count += total_new;
-            }
-          }
+      for (uint32_t i = 0; i < 16; ++i) {
+        const uint32_t xi = st.next();
+        x = (lig == i) ? xi : x;
+        w = (lig == i) ? st.v4 : w;
+      }
+      // r = x mod len: q' = mulhi(x, floor(2^32/len)) is q or q - 1 (two fix-ups for safety)
+      uint32_t r = x - __umulhi(x, magic) * len;
+      r = min(r, r - len);
+      r = min(r, r - len);
+      // already chosen for this seed?  (nothing is, in a seed's first round)
+      bool in_set = false;
+      if (count != 0) {
+        uint32_t pos = r & set_mask;
+        for (;;) {
+          const uint32_t cur = tab[pos];
+          if (cur == HASH_EMPTY) break;
+          if (cur == r) { in_set = true; break; }
+          pos = (pos + 1) & set_mask;
         }
+      }
+      // equal to an EARLIER candidate of this round?
+      bool dup = false;
+      dup |= row_shr<1>(r, HASH_EMPTY) == r;
+      dup |= row_shr<2>(r, HASH_EMPTY) == r;
+      dup |= row_shr<3>(r, HASH_EMPTY) == r;
+      dup |= row_shr<4>(r, HASH_EMPTY) == r;
+      dup |= row_shr<5>(r, HASH_EMPTY) == r;
+      dup |= row_shr<6>(r, HASH_EMPTY) == r;
+      dup |= row_shr<7>(r, HASH_EMPTY) == r;
+      dup |= row_shr<8>(r, HASH_EMPTY) == r;
+      dup |= row_shr<9>(r, HASH_EMPTY) == r;
+      dup |= row_shr<10>(r, HASH_EMPTY) == r;
+      dup |= row_shr<11>(r, HASH_EMPTY) == r;
+      dup |= row_shr<12>(r, HASH_EMPTY) == r;
+      dup |= row_shr<13>(r, HASH_EMPTY) == r;
+      dup |= row_shr<14>(r, HASH_EMPTY) == r;
+      dup |= row_shr<15>(r, HASH_EMPTY) == r;
+      const bool is_new = !in_set && !dup;
+      const uint32_t new_mask = (uint32_t)(__ballot(is_new) >> grp_shift) & 0xffffu;
+      const uint32_t rank = __popc(new_mask & ((1u << lig) - 1u));
+      const uint32_t total_new = __popc(new_mask);
+      const uint32_t need = fanout - count;
+      const bool accept = is_new && rank < need;
+      if (accept) out_dst[o + count + rank] = r; // insertion order == output order (items[] of khop3.cu:64)
+      if (total_new >= need) {
+        // The set completed at draw t* = the lane of the need-th new candidate.  State after m = t* + 1
+        // draws: v_j = element m + j of the window, d = d0 + m * 362437 -- five lane reads, no replay.
+        const uint32_t last_mask = (uint32_t)(__ballot(accept && rank == need - 1) >> grp_shift) & 0xffffu;
+        const uint32_t m = (uint32_t)__ffs(last_mask); // t* + 1, in 1..16
+        uint32_t v[5];
+#pragma unroll
+        for (uint32_t j = 0; j < 5; ++j) {
+          const uint32_t e = m + j; // window element: 0..4 = old v0..v4, 5 + i = w of draw i
+          const uint32_t from_draw = __shfl(w, (int)(grp_shift + (e >= 5 ? e - 5 : 0)), 64);
+          uint32_t from_old = st0.v4;
+          from_old = (e == 3) ? st0.v3 : from_old;
+          from_old = (e == 2) ? st0.v2 : from_old;
+          from_old = (e == 1) ? st0.v1 : from_old;
+          v[j] = (e >= 5) ? from_draw : from_old; // e >= 1 always
+        }
+        st.v0 = v[0]; st.v1 = v[1]; st.v2 = v[2]; st.v3 = v[3]; st.v4 = v[4];
+        st.d = st0.d + m * 362437u;
+        if (dirty) { // next seed starts from an empty set
+          __builtin_amdgcn_wave_barrier();
+          for (uint32_t s = lig; s <= set_mask; s += 16) tab[s] = HASH_EMPTY;
+          __builtin_amdgcn_wave_barrier();
+          dirty = false;
+        }
+        todo &= todo - 1;
+        fetch = true;
+      } else {
+        __builtin_amdgcn_wave_barrier();
+        if (accept) {
+          uint32_t pos = r & set_mask;
+          while (atomicCAS(&tab[pos], HASH_EMPTY, r) != HASH_EMPTY) pos = (pos + 1) & set_mask;
+        }
+        __builtin_amdgcn_wave_barrier();
+        count += total_new;
+        dirty = true;
       }
     }
     if (lig == 0) st.store(states + 6 * stream);
   }
 }
 
-// out_dst[e] holds a position inside the seed's neighbour list; replace it by the neighbour id.
-// The seed comes from out_src[e]: its global id (leaf API) or, in local mode, n2o[out_src[e]].
-__global__ __launch_bounds__(kBlock) void k_gather_neighbours(GraphView g, const uint32_t *__restrict__ out_src,
-                                                              uint32_t *__restrict__ out_dst,
-                                                              const uint64_t *__restrict__ num_out,
-                                                              const uint32_t *__restrict__ local_to_global) {
-  const uint64_t n = *num_out;
-  for (uint64_t e = (uint64_t)blockIdx.x * kBlock + threadIdx.x; e < n; e += (uint64_t)gridDim.x * kBlock) {
-    const uint32_t sv = out_src[e];
-    const uint32_t rid = local_to_global ? local_to_global[sv] : sv;
+// Slot j of seed i -> the edge at offset[i] + j: its position inside the seed's neighbour list is j for
+// a "take them all" seed and the sampler's pick otherwise; written out as (src value, neighbour id).
+__global__ __launch_bounds__(kBlock) void k_gather_neighbours(GraphView g, const uint32_t *__restrict__ input,
+                                                              Count n_arg, uint32_t fanout, uint32_t fanout_magic,
+                                                              const uint32_t *__restrict__ offset,
+                                                              uint32_t *__restrict__ out_src,
+                                                              uint32_t *__restrict__ out_dst, SrcMode sm) {
+  const uint64_t total = n_arg.get() * fanout;
+  for (uint64_t t = (uint64_t)blockIdx.x * kBlock + threadIdx.x; t < total; t += (uint64_t)gridDim.x * kBlock) {
+    // i = t / fanout for t < 2^32 (host checks n_max * fanout < 2^32): mulhi by ceil(2^32 / fanout), one fix-up
+    uint32_t i = fanout == 1 ? (uint32_t)t : __umulhi((uint32_t)t, fanout_magic);
+    if ((uint64_t)i * fanout > t) --i;
+    const uint32_t j = (uint32_t)t - i * fanout;
+    const uint32_t rid = input[i];
     uint32_t len;
     const uint32_t *edges = g.neighbours(rid, len);
-    out_dst[e] = edges[out_dst[e]];
+    if (j >= min(len, fanout)) continue;
+    const uint32_t e = offset[i] + j;
+    const uint32_t pos = len <= fanout ? j : out_dst[e];
+    out_src[e] = sm.value(rid, i);
+    out_dst[e] = edges[pos];
   }
 }
 
@@ -332,6 +345,19 @@ __global__ __launch_bounds__(kBlock) void k_sample_khop2(const uint32_t *__restr
   }
 }
 
+// groups per wave of the khop3 kernel: sparse waves while the frontier leaves SIMDs idle (1024 SIMDs; a block
+// is 8 groups).  GGMS_KHOP3_GPW=1|2|4 pins it (measurement hook).
+static int khop3_groups_per_wave(size_t blocks) {
+  static const int pinned = [] {
+    const char *e = getenv("GGMS_KHOP3_GPW");
+    return e ? atoi(e) : 0;
+  }();
+  if (pinned == 1 || pinned == 2 || pinned == 4) return pinned;
+  if (blocks * 8 <= 2048) return 1;
+  if (blocks * 4 <= 2048) return 2;
+  return 4;
+}
+
 size_t sample_ws_words(size_t num_input) { return num_input + tile_scan_words(num_input) + 16; }
 
 // offsets by exclusive scan of min(deg, fanout), then the sampler proper
@@ -344,15 +370,26 @@ int sample_khop3_impl(GraphView g, const uint32_t *input, size_t n_max, Count n,
   int rc = tile_scan(SeedCount{g, input, fanout}, StoreOffset{offset}, n_max, n, sa, nullptr, nullptr,
                      num_out_dev, s);
   if (rc != GGMS_OK) return rc;
-  const int grid = grid_for((n_max + 127) / 128, 1);
   const SrcMode sm{seed_local, src_local};
   // 64 slots up to fanout 31 (load < 0.5), else the reference's 128 (HASHTABLE_SIZE, khop3.cu:43)
   const uint32_t set_mask = fanout < 32 ? 63u : 127u;
-  hipLaunchKernelGGL(k_khop3_positions, dim3(grid), dim3(128), 0, s, g, input, n, fanout, offset, out_src, out_dst,
-                     states, sm, set_mask);
+  const size_t blocks = (n_max + 127) / 128;
+  const int gpw = khop3_groups_per_wave(blocks);
+  const int grid = grid_for(blocks, 1);
+  if (gpw == 1)
+    hipLaunchKernelGGL(k_khop3_positions<1>, dim3(grid), dim3(512), 0, s, g, input, n, fanout, offset, out_dst, states,
+                       set_mask);
+  else if (gpw == 2)
+    hipLaunchKernelGGL(k_khop3_positions<2>, dim3(grid), dim3(256), 0, s, g, input, n, fanout, offset, out_dst, states,
+                       set_mask);
+  else
+    hipLaunchKernelGGL(k_khop3_positions<4>, dim3(grid), dim3(128), 0, s, g, input, n, fanout, offset, out_dst, states,
+                       set_mask);
   GGMS_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_gather_neighbours, dim3(grid_for(n_max * fanout, kBlock)), dim3(kBlock), 0, s, g, out_src,
-                     out_dst, num_out_dev, src_local ? local_to_global : nullptr);
+  (void)local_to_global;
+  const uint32_t fanout_magic = (uint32_t)((0x100000000ull + fanout - 1) / fanout); // ceil(2^32 / fanout)
+  hipLaunchKernelGGL(k_gather_neighbours, dim3(grid_for(n_max * fanout, kBlock)), dim3(kBlock), 0, s, g, input, n,
+                     fanout, fanout_magic, offset, out_src, out_dst, sm);
   GGMS_LAUNCH_CHECK();
   return GGMS_OK;
 }

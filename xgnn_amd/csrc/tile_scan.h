@@ -3,8 +3,9 @@
 // Replaces the reference's {count kernel, cub::DeviceScan::ExclusiveSum over grid+1 entries, compact
 // kernel with cub::BlockScan} triple (e.g. cuda_sampling_khop3.cu:148-230,286-295; cuda_hashtable.cu:
 // 197-232,406-458; cuda_cache_manager_device.cu:40-169) and its intermediate host syncs.
-// Two interchangeable forms (same results, same scratch): three launches (default, see scan_three_pass)
-// and one launch with decoupled look-back.
+// Two interchangeable forms (same results, same scratch): one launch with decoupled look-back for inputs of up
+// to kSinglePassTiles tiles (every block is resident, the look-back is a handful of descriptor reads and two
+// launch latencies are saved), three launches beyond that (see scan_three_pass).
 //
 // Single pass, decoupled look-back:
 //   * tiles of 1024 items (4 rounds of 256 threads, item = tile*1024 + round*256 + thread -- the
@@ -30,8 +31,16 @@ namespace ggms {
 constexpr uint32_t kTile = 1024;
 
 inline size_t num_tiles_for(size_t n) { return (n + kTile - 1) / kTile; }
-// scratch in uint32 words: 4 control words + one 64-bit descriptor per tile
-inline size_t tile_scan_words(size_t n) { return 12 + 2 * (num_tiles_for(n) + 1); }
+// scratch in uint32 words: 8 control words, one 64-bit descriptor per tile (single pass), tile sums + prefixes
+// (three launches); the two forms keep their words apart so that scans of both kinds can share one area
+inline size_t tile_scan_words(size_t n) { return 12 + 4 * (num_tiles_for(n) + 1); }
+// inputs of at most this many tiles take the single-pass kernel
+constexpr size_t kSinglePassTiles = 256;
+// words (from the aligned start of an area) that must be zero before the first single-pass scan of a batch
+inline size_t scan_clear_words(size_t n_max) {
+  const size_t nt = num_tiles_for(n_max);
+  return 8 + 2 * ((nt < kSinglePassTiles ? nt : kSinglePassTiles) + 1);
+}
 
 // where a scan keeps its control words + descriptors; `cleared` = the caller zeroed it already (one
 // memset per batch instead of one per scan; descriptors are epoch-tagged, so scans may share an area)
@@ -272,13 +281,20 @@ __global__ __launch_bounds__(kBlock) void k_tile_prefix_t(const uint32_t *tile_s
 }
 
 
-// Default: three launches.  A/B on MI355X (bench.py, same box): 0.403 ms vs 0.414 ms of sampling per batch for
-// the single-pass kernel -- the look-back saves a launch and one predicate evaluation but its 1-tile-per-block
-// latency chain costs as much -- and the three-launch form has no inter-workgroup wait at all.
-// GGMS_SCAN=1 selects the single-pass kernel.
-inline bool scan_three_pass() {
-  static const bool v = [] { const char *e = getenv("GGMS_SCAN"); return !(e && e[0] == '1'); }();
+// Large inputs: three launches.  A/B on MI355X (bench.py, same box): 0.403 ms vs 0.414 ms of sampling per batch
+// with the single-pass kernel everywhere -- at ~900 tiles its 1-tile-per-block latency chain costs what the two
+// extra launches cost -- and the three-launch form has no inter-workgroup wait at all.  Small inputs are the
+// opposite case: every launch sits on the ~5 us floor, so one launch beats three.
+// GGMS_SCAN=1 forces the single-pass kernel everywhere, GGMS_SCAN=3 the three launches everywhere.
+inline int scan_mode() {
+  static const int v = [] { const char *e = getenv("GGMS_SCAN"); return e ? atoi(e) : 0; }();
   return v;
+}
+inline bool scan_three_pass() { return scan_mode() != 1; }
+inline bool scan_single_pass(size_t n_max) {
+  if (scan_mode() == 1) return true;
+  if (scan_mode() == 3) return false;
+  return num_tiles_for(n_max) <= kSinglePassTiles;
 }
 
 // Host helper.  scratch: tile_scan_words(n_max) uint32, 8-byte aligned; its control words must be zero
@@ -286,7 +302,8 @@ inline bool scan_three_pass() {
 inline uint32_t *scan_align(uint32_t *p) { return (uint32_t *)(((uintptr_t)p + 7) & ~(uintptr_t)7); }
 
 inline int clear_scan_area(uint32_t *words, size_t n_max, hipStream_t stream) {
-  GGMS_HIP(hipMemsetAsync(scan_align(words), 0, (tile_scan_words(n_max) - 2) * sizeof(uint32_t), stream));
+  const size_t w = scan_mode() == 1 ? 8 + 2 * (num_tiles_for(n_max) + 1) : scan_clear_words(n_max);
+  GGMS_HIP(hipMemsetAsync(scan_align(words), 0, w * sizeof(uint32_t), stream));
   return GGMS_OK;
 }
 
@@ -303,13 +320,14 @@ inline int tile_scan(ValueF value, EmitF emit, size_t n_max, Count n, ScanArea a
   const size_t nt = num_tiles_for(n_max);
   uint32_t *ctl = scan_align(area.words); // 64-bit descriptors need 8-byte alignment
   unsigned long long *desc = reinterpret_cast<unsigned long long *>(ctl + 8);
-  if (!area.cleared && !scan_three_pass()) { // only the single-pass kernel needs zeroed control words
+  const bool single = scan_single_pass(n_max);
+  if (!area.cleared && single) { // only the single-pass kernel needs zeroed control words
     int rc = clear_scan_area(area.words, n_max, stream);
     if (rc != GGMS_OK) return rc;
   }
   const int grid = grid_for(nt, 1);
-  if (scan_three_pass()) { // tile_sums / tile_prefix live in the descriptor words (same footprint)
-    uint32_t *tile_sums = ctl + 8;
+  if (!single) {
+    uint32_t *tile_sums = ctl + 8 + 2 * (nt + 1); // behind the descriptors
     uint32_t *tile_prefix = tile_sums + nt + 1;
     hipLaunchKernelGGL((k_tile_reduce<ValueF>), dim3(grid), dim3(kBlock), 0, stream, value, n, tile_sums, area.stash);
     hipLaunchKernelGGL((k_tile_prefix_t<0>), dim3(1), dim3(kBlock), 0, stream, tile_sums, n, tile_prefix, base_in,

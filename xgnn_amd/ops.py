@@ -282,11 +282,17 @@ def extract_cached(out, nodes, table, parts_table, num_part, host_feat, num=None
 
 
 class BatchSampler:
-    """DoGPUSample (dist_loops.cc:62-368) as one enqueue: buffers sized once, reused every batch."""
+    """DoGPUSample (dist_loops.cc:62-368) as one enqueue: buffers sized once, reused every batch.
+
+    num_slots      output slots (the engine's batch slots): a batch's COO / counts / input-node copy stay valid
+                   while later batches are being sampled.
+    num_pipelines  batches that may be in flight at once, each with its own dedup table and workspace.  Call
+                   sample() for consecutive batches from different streams; the shared RNG pool (and khop2's CSR)
+                   is still consumed in call order (ggms_sample_extra_t.rng_wait / rng_done)."""
 
     def __init__(self, graph, fanouts, batch_size, sample_type=KHOP3, seed=0, device="cuda", direct_table=True,
                  prob_table=None, alias_table=None, random_walk_length=0, random_walk_restart_prob=0.0,
-                 num_random_walk=0, num_slots=1):
+                 num_random_walk=0, num_slots=1, num_pipelines=1):
         self.graph, self.fanouts, self.sample_type = graph, [int(f) for f in fanouts], sample_type
         L = len(self.fanouts)
         self.L = L
@@ -296,14 +302,15 @@ class BatchSampler:
         self.max_seeds = int(batch_size * 1.25) + 1
         check(lib().ggms_sample_batch_capacity(self.max_seeds, self._f, L, mi, me, C.byref(mu)), "capacity")
         self.max_input, self.max_edges, self.max_unique = list(mi), list(me), mu.value
-        self.ht = OrderedHashTable(self.max_unique, device, num_node=graph.c.num_node if direct_table else None)
+        self.num_pipelines = num_pipelines
+        self.hts = [OrderedHashTable(self.max_unique, device, num_node=graph.c.num_node if direct_table else None)
+                    for _ in range(num_pipelines)]
+        self.ht = self.hts[0]
         nstates = lib().ggms_random_states_count(sample_type, self._f, L, self.max_seeds, num_random_walk)
         nstates = max(nstates, (max(self.max_input) + 127) // 128 * 8, (max(self.max_input) + 1023) // 1024 * 256)
         if sample_type == RANDOM_WALK:
             nstates = max(nstates, lib().ggms_random_walk_num_states(max(self.max_input), num_random_walk))
         self.states = random_states(nstates, seed, device) if sample_type != KHOP0 else None
-        # output slots (the engine's batch slots): a batch's COO / counts / input-node copy stay valid while the
-        # next batch is being sampled
         self.num_slots = num_slots
         self.rows = [[torch.empty(max(1, e), dtype=torch.int32, device=device) for e in self.max_edges]
                      for _ in range(num_slots)]
@@ -314,37 +321,68 @@ class BatchSampler:
         self.counts_slots = [torch.zeros(3 * L + 1, dtype=torch.int64, device=device) for _ in range(num_slots)]
         self.input_nodes = [torch.empty(self.max_unique, dtype=torch.int32, device=device) for _ in range(num_slots)]
         self.row, self.col, self.counts = self.rows[0], self.cols[0], self.counts_slots[0]
-        self._row, self._col = self._rows[0], self._cols[0]
-        self.extra = None
         self.data = None
+        self.datas = None
         self._keep = (prob_table, alias_table)
-        if sample_type in (WEIGHTED_KHOP, RANDOM_WALK):
-            self.extra = _lib.SampleExtra()
-            self.extra.prob_table = prob_table.data_ptr() if prob_table is not None else None
-            self.extra.alias_table = alias_table.data_ptr() if alias_table is not None else None
-            self.extra.random_walk_length = random_walk_length
-            self.extra.random_walk_restart_prob = random_walk_restart_prob
-            self.extra.num_random_walk = num_random_walk
-            if sample_type == RANDOM_WALK:
-                self.data = [torch.empty(max(1, e), dtype=torch.int32, device=device) for e in self.max_edges]
-                self._data = (C.c_void_p * L)(*[t.data_ptr() for t in self.data])
-                self.extra.data = C.cast(self._data, C.c_void_p)
-        self._extra_ref = C.byref(self.extra) if self.extra is not None else None
-        self.ws = _workspace(lib().ggms_sample_batch_workspace_bytes(sample_type, self.max_seeds, self._f, L,
-                                                                     self._extra_ref), device)
+        if sample_type == RANDOM_WALK:
+            self.datas = [[torch.empty(max(1, e), dtype=torch.int32, device=device) for e in self.max_edges]
+                          for _ in range(num_slots)]
+            self._datas = [(C.c_void_p * L)(*[t.data_ptr() for t in d]) for d in self.datas]
+            self.data = self.datas[0]
+        # one extras struct per (pipeline, slot) use: filled in sample()
+        self._extra = _lib.SampleExtra()
+        self._extra.prob_table = prob_table.data_ptr() if prob_table is not None else None
+        self._extra.alias_table = alias_table.data_ptr() if alias_table is not None else None
+        self._extra.random_walk_length = random_walk_length
+        self._extra.random_walk_restart_prob = random_walk_restart_prob
+        self._extra.num_random_walk = num_random_walk
+        if self.datas is not None:
+            self._extra.data = C.cast(self._datas[0], C.c_void_p)
+        wsb = lib().ggms_sample_batch_workspace_bytes(sample_type, self.max_seeds, self._f, L, C.byref(self._extra))
+        self.wss = [_workspace(wsb, device) for _ in range(num_pipelines)]
+        self.ws = self.wss[0]
+        # batch-order events on the RNG pool; only needed when batches overlap
+        self._events = []
+        if num_pipelines > 1 and sample_type != KHOP0:
+            for _ in range(num_pipelines):
+                e = C.c_void_p()
+                check(lib().ggms_event_create(C.byref(e)), "ggms_event_create")
+                self._events.append(e)
+        self._batch_no = 0
+
+    def __del__(self):
+        try:
+            for e in self._events:
+                lib().ggms_event_destroy(e)
+        except Exception:
+            pass
 
     def sample(self, seeds, slot=0, copy_input_nodes=False):
         """Enqueue one batch into output slot `slot`; read counts / row / col / ht.n2o after a sync.
-        copy_input_nodes: also copy the unique list (ht.n2o, reused by the next batch) into the slot."""
+        copy_input_nodes: also copy the unique list (ht.n2o, reused by a later batch) into the slot.
+        Batch b runs on pipeline b % num_pipelines (its table is `self.ht` until the next call)."""
         _i32(seeds)
         n = seeds.numel()
         assert n <= self.max_seeds
+        b, K = self._batch_no, self.num_pipelines
+        self._batch_no += 1
+        pipe = b % K
+        self.ht = self.hts[pipe]
         counts = self.counts_slots[slot]
+        self.row, self.col, self.counts = self.rows[slot], self.cols[slot], counts
+        ex = self._extra
+        if self.datas is not None:
+            ex.data = C.cast(self._datas[slot], C.c_void_p)
+            self.data = self.datas[slot]
+        if self._events:
+            ex.rng_wait = self._events[(b - 1) % K] if b > 0 else None
+            ex.rng_done = self._events[pipe]
+        ws = self.wss[pipe]
         check(lib().ggms_sample_batch(self.sample_type, C.byref(self.graph.c), _ptr(seeds), n, self._f, self.L,
                                       C.byref(self.ht.c), _ptr(self.states),
                                       self.states.shape[0] if self.states is not None else 0, self._rows[slot],
-                                      self._cols[slot], _ptr(counts), self._extra_ref, _ptr(self.ws),
-                                      self.ws.numel() * 4, _stream()),
+                                      self._cols[slot], _ptr(counts), C.byref(ex), _ptr(ws), ws.numel() * 4,
+                                      _stream()),
               "ggms_sample_batch")
         if copy_input_nodes:
             gather_scatter(self.input_nodes[slot], self.ht.n2o, None, None, num=self.max_unique,
