@@ -38,7 +38,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline: keep sampling mini-batches this long")
     ap.add_argument("--host-profile", action="store_true", help="print host enqueue time per section to stderr")
-    ap.add_argument("--pipelines", type=int, default=3,
+    ap.add_argument("--pipelines", type=int, default=1,
                     help="sampling batches in flight (each on its own stream with its own dedup table)")
     ap.add_argument("--no-overlap", action="store_true",
                     help="one stream: extract of batch k and sampling of batch k+1 run back to back "
