@@ -320,6 +320,47 @@ int ggms_extract_cached(void *out, const ggms_id_t *nodes, size_t num_nodes,
                         const void *host_feat, size_t dim, int dtype,
                         uint64_t *num_miss_dev, ggms_stream_t stream);
 
+
+/* ---------------------------------------------------------------------------
+ * GGMS shards across processes (one process per GPU).
+ *
+ * Publishing a shard: DistGraph::_Barrier/IPC exchange, cuda/dist_graph.cu:228-272
+ * (cudaIpcGetMemHandle / cudaIpcOpenMemHandle).  A shard is an allocation of its
+ * own (ggms_device_alloc), so the handle maps exactly the shard.  `handle` is a
+ * GGMS_IPC_HANDLE_BYTES buffer that may travel through any byte channel
+ * (shared memory, torch.distributed.all_gather_object, ...).
+ * ------------------------------------------------------------------------- */
+#define GGMS_IPC_HANDLE_BYTES 64
+int ggms_device_alloc(void **ptr, size_t bytes);
+int ggms_device_free(void *ptr);
+int ggms_ipc_export(const void *ptr, void *handle);
+int ggms_ipc_import(const void *handle, void **ptr);   /* peer HBM, read in-kernel over xGMI */
+int ggms_ipc_release(void *ptr);
+
+/* The exchange form of the remote gather: instead of dereferencing
+ * peer pointers inside the gather kernel (ggms_extract_cached with num_part > 0),
+ * a batch's rows are requested from their owners with one all-to-all of row ids
+ * and returned with one all-to-all of rows.  These two leaves split the batch by
+ * owner: slot s = table[node] lives on shard s % num_part at row s / num_part
+ * (cuda_cache_manager_host.cc:187-221); an uncached node (slot kEmptyKey) goes to
+ * bucket num_part and keeps its node id (host tier).
+ *   ggms_owner_histogram  slots_out[i] = table[nodes[i]]; counts_dev[p] += |bucket p|
+ *                         (counts_dev: num_part + 1 zeroed uint64)
+ *   ggms_owner_bucket     cursor_dev[p] = start of bucket p on entry (exclusive
+ *                         prefix of the counts), its end on return;
+ *                         bucket_row[k] = row id to ask the owner for (node id in
+ *                         the host bucket), bucket_pos[k] = row of the batch output
+ *                         it fills.  Order inside a bucket is unspecified. */
+int ggms_owner_histogram(const ggms_id_t *table, const ggms_id_t *nodes,
+                         size_t num_nodes, const uint64_t *num_nodes_dev,
+                         uint32_t num_part, ggms_id_t *slots_out,
+                         uint64_t *counts_dev, ggms_stream_t stream);
+int ggms_owner_bucket(const ggms_id_t *slots, const ggms_id_t *nodes,
+                      size_t num_nodes, const uint64_t *num_nodes_dev,
+                      uint32_t num_part, uint64_t *cursor_dev,
+                      ggms_id_t *bucket_row, ggms_id_t *bucket_pos,
+                      ggms_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,82 @@
+"""GGMS feature shards across two processes sharing the box's one GPU: peer (hipIpc, in-kernel loads) and
+exchange (all-to-all; gloo through host memory here, RCCL on a real node) must both reproduce extract()."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, mode, q):
+    import oracle
+    from xgnn_amd import ggms_store, ops
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    N, dim, num_cached = 20_000, 100, 13_001
+    rng = np.random.RandomState(5)
+    feat = rng.standard_normal((N, dim)).astype(np.float32)
+    rank_list = rng.permutation(N).astype(np.int64)
+    table = np.full(N, -1, np.int32)
+    table[rank_list[:num_cached]] = np.arange(num_cached, dtype=np.int32)
+    t_table = torch.from_numpy(table).to(dev)
+    host_feat = torch.from_numpy(feat).pin_memory()
+    t_rank = torch.from_numpy(rank_list)
+
+    def rows_of(node_ids, out):
+        out.copy_(torch.from_numpy(feat[node_ids.numpy()]))
+
+    shard, holder = ggms_store.shard_rows(rows_of, t_rank, num_cached, world, rank, dim, torch.float32, dev,
+                                          shared=(mode == "peer"))
+    store = ggms_store.FeatureShards(shard, t_table, world, rank, mode=mode, dist=dist, host_feat=host_feat)
+    if mode == "peer":
+        store.connect_peers(holder)
+    ok = True
+    for b in range(3):
+        n = 5000 + 333 * rank + b
+        nodes = np.random.RandomState(100 * b + rank).randint(0, N, n).astype(np.uint32)
+        t_nodes = torch.from_numpy(nodes.view(np.int32)).to(dev)
+        out = torch.zeros((n + 3, dim), dtype=torch.float32, device=dev)
+        store.extract(t_nodes, n, out)
+        torch.cuda.synchronize()
+        got = out.cpu().numpy()
+        ok = ok and got[:n].tobytes() == oracle.extract(feat, nodes).tobytes() and not got[n:].any()
+    dist.barrier()  # nobody unmaps a shard a peer may still be reading
+    q.put((rank, ok))
+    dist.barrier()
+    if holder is not None:
+        holder.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode", ["peer", "a2a"])
+def test_two_processes_one_gpu(mode):
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, mode, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in range(world))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert res == [(0, True), (1, True)]

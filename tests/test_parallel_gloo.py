@@ -56,3 +56,71 @@ def test_two_rank_seed_partition_and_reduction():
     assert not np.array_equal(out[0], out[1])  # reshuffled per epoch
     assert mx == [2.0, 20.0, 3.0] and sm == [3.0, 30.0, 6.0]
     assert parallel.steps_per_epoch(101, 2, 16) == 4
+
+
+# ---- GGMS feature shards, exchange form: host logic on two CPU ranks --------------------------------------
+class _NumpyLeaf:
+    """Test stand-in for the HIP leaf operators (checker side: plain numpy on CPU tensors)."""
+
+    def split_by_owner(self, table, nodes, num, num_part):
+        slots = table[nodes[:num].long()]
+        owner = torch.where(slots < 0, torch.full_like(slots, num_part), slots % num_part)
+        order = torch.argsort(owner, stable=True)
+        counts = torch.bincount(owner, minlength=num_part + 1).to(torch.int64)
+        row = torch.where(slots < 0, nodes[:num], slots // num_part)[order].to(torch.int32)
+        return row, order.to(torch.int32), counts
+
+    def gather(self, src, index):
+        return src[index.long()]
+
+    def gather_scatter(self, out, src, src_index, dst_index):
+        rows = src if src_index is None else src[src_index.long()]
+        if dst_index is None:
+            out[:rows.shape[0]] = rows
+        else:
+            out[dst_index.long()] = rows
+
+
+def _shard_worker(rank, world, port, q):
+    from xgnn_amd.ggms_store import FeatureShards
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    N, dim, num_cached = 500, 7, 320
+    g = torch.Generator().manual_seed(3)
+    feat = torch.randn(N, dim, generator=g)
+    rank_list = torch.randperm(N, generator=g)
+    table = torch.full((N,), -1, dtype=torch.int32)
+    table[rank_list[:num_cached]] = torch.arange(num_cached, dtype=torch.int32)
+    shard = feat[rank_list[rank:num_cached:world]].contiguous()  # slot s -> rank s % P, row s // P
+    store = FeatureShards(shard, table, world, rank, mode="a2a", dist=dist, leaf=_NumpyLeaf(), host_feat=feat)
+    ok = True
+    for b in range(3):
+        nodes = torch.randint(0, N, (90 + 17 * rank + b,), generator=torch.Generator().manual_seed(10 * b + rank),
+                              dtype=torch.int32)
+        out = torch.zeros(nodes.numel() + 5, dim)
+        store.extract(nodes, nodes.numel(), out)
+        ok = ok and torch.equal(out[:nodes.numel()], feat[nodes.long()]) and bool((out[nodes.numel():] == 0).all())
+    # a batch whose rows all live on ONE owner (empty buckets elsewhere), and an empty batch
+    only0 = rank_list[0:num_cached:world][:40].to(torch.int32)
+    out = torch.zeros(40, dim)
+    store.extract(only0, 40, out)
+    ok = ok and torch.equal(out, feat[only0.long()])
+    store.extract(only0[:0], 0, torch.zeros(1, dim))
+    dist.barrier()
+    q.put((rank, ok))
+    dist.destroy_process_group()
+
+
+def test_two_rank_feature_shards_all_to_all():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_shard_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res == [(0, True), (1, True)]

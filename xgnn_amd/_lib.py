@@ -53,6 +53,13 @@ SYMBOLS = {
     "ggms_random_walk_num_states": (_sz, [_sz, _sz]),
     "ggms_sample_random_walk": (_i, [C.POINTER(Graph), _vp, _sz, _sz, C.c_double, _sz, _sz, _vp, _vp, _vp, _vp, _vp,
                                      _sz, _vp, _sz, _vp]),
+    "ggms_device_alloc": (_i, [C.POINTER(C.c_void_p), _sz]),
+    "ggms_device_free": (_i, [_vp]),
+    "ggms_ipc_export": (_i, [_vp, _vp]),
+    "ggms_ipc_import": (_i, [_vp, C.POINTER(C.c_void_p)]),
+    "ggms_ipc_release": (_i, [_vp]),
+    "ggms_owner_histogram": (_i, [_vp, _vp, _sz, _vp, _u32, _vp, _vp, _vp]),
+    "ggms_owner_bucket": (_i, [_vp, _vp, _sz, _vp, _u32, _vp, _vp, _vp, _vp]),
     "ggms_event_create": (_i, [C.POINTER(C.c_void_p)]),
     "ggms_event_destroy": (_i, [_vp]),
     "ggms_sample_batch_capacity": (_i, [_sz, C.POINTER(_sz), _u32, C.POINTER(_sz), C.POINTER(_sz), C.POINTER(_sz)]),

@@ -6,6 +6,8 @@
 // Here: ONE stable scan of the miss flags.  A hit's position in the hit list is
 // i - (number of misses before i), so both lists come out of the same pass, in
 // input order, and both totals stay on the device.
+#include <cstring>
+
 #include "tile_scan.h"
 
 namespace ggms {
@@ -49,6 +51,62 @@ __global__ __launch_bounds__(kBlock) void k_count_nodes(uint32_t *__restrict__ f
     atomicAdd(&freq[nodes[i]], 1u);
 }
 
+// ---- exchange form of the remote gather: split a batch by owning shard ----------------------------
+__device__ __forceinline__ uint32_t owner_of(uint32_t slot, uint32_t num_part) {
+  return slot == kEmptyKey ? num_part : slot % num_part;
+}
+
+__global__ __launch_bounds__(kBlock) void k_owner_histogram(const uint32_t *__restrict__ table,
+                                                            const uint32_t *__restrict__ nodes, Count n_arg,
+                                                            uint32_t num_part, uint32_t *__restrict__ slots_out,
+                                                            unsigned long long *counts) {
+  const uint64_t n = n_arg.get();
+  const uint64_t rounded = (n + kWave - 1) / kWave * kWave; // whole waves stay together for the ballots
+  for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < rounded; i += (uint64_t)gridDim.x * kBlock) {
+    const bool valid = i < n;
+    uint32_t owner = 0xffffffffu;
+    if (valid) {
+      const uint32_t slot = table[nodes[i]];
+      slots_out[i] = slot;
+      owner = owner_of(slot, num_part);
+    }
+    for (uint32_t p = 0; p <= num_part; ++p) { // one atomic per (wave, bucket)
+      const uint64_t m = __ballot(owner == p);
+      if (m && lane_id() == (uint32_t)__builtin_ctzll(m)) atomicAdd(&counts[p], (unsigned long long)__popcll(m));
+    }
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void k_owner_bucket(const uint32_t *__restrict__ slots,
+                                                         const uint32_t *__restrict__ nodes, Count n_arg,
+                                                         uint32_t num_part, unsigned long long *cursor,
+                                                         uint32_t *__restrict__ bucket_row,
+                                                         uint32_t *__restrict__ bucket_pos) {
+  const uint64_t n = n_arg.get();
+  const uint64_t rounded = (n + kWave - 1) / kWave * kWave;
+  for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < rounded; i += (uint64_t)gridDim.x * kBlock) {
+    const bool valid = i < n;
+    uint32_t owner = 0xffffffffu, slot = 0;
+    if (valid) {
+      slot = slots[i];
+      owner = owner_of(slot, num_part);
+    }
+    for (uint32_t p = 0; p <= num_part; ++p) {
+      const uint64_t m = __ballot(owner == p);
+      if (!m) continue;
+      const uint32_t leader = (uint32_t)__builtin_ctzll(m);
+      unsigned long long base = 0;
+      if (lane_id() == leader) base = atomicAdd(&cursor[p], (unsigned long long)__popcll(m));
+      base = __shfl(base, (int)leader, 64);
+      if (owner == p) {
+        const uint64_t at = base + __popcll(m & ((1ull << lane_id()) - 1ull));
+        bucket_row[at] = (p == num_part) ? nodes[i] : slot / num_part;
+        bucket_pos[at] = (uint32_t)i;
+      }
+    }
+  }
+}
+
 } // namespace ggms
 
 using namespace ggms;
@@ -86,6 +144,66 @@ int ggms_get_miss_cache_index(const ggms_id_t *table, const ggms_id_t *nodes, si
                    SplitEmit{table, nodes, miss_src_index, miss_dst_index, cache_src_index, cache_dst_index,
                              num_miss_dev, num_cache_dev, n},
                    num_nodes, n, ScanArea{(uint32_t *)workspace, false}, nullptr, nullptr, nullptr, s);
+}
+
+int ggms_owner_histogram(const ggms_id_t *table, const ggms_id_t *nodes, size_t num_nodes,
+                         const uint64_t *num_nodes_dev, uint32_t num_part, ggms_id_t *slots_out, uint64_t *counts_dev,
+                         ggms_stream_t stream) {
+  GGMS_CHECK_ARG(num_part >= 1 && num_part <= 64 && counts_dev);
+  if (num_nodes == 0) return GGMS_OK;
+  GGMS_CHECK_ARG(table && nodes && slots_out && num_nodes < (1ull << 32));
+  hipLaunchKernelGGL(k_owner_histogram, dim3(grid_for(num_nodes, kBlock)), dim3(kBlock), 0, to_stream(stream), table,
+                     nodes, count_of(num_nodes, num_nodes_dev), num_part, slots_out, (unsigned long long *)counts_dev);
+  GGMS_LAUNCH_CHECK();
+  return GGMS_OK;
+}
+
+int ggms_owner_bucket(const ggms_id_t *slots, const ggms_id_t *nodes, size_t num_nodes, const uint64_t *num_nodes_dev,
+                      uint32_t num_part, uint64_t *cursor_dev, ggms_id_t *bucket_row, ggms_id_t *bucket_pos,
+                      ggms_stream_t stream) {
+  GGMS_CHECK_ARG(num_part >= 1 && num_part <= 64 && cursor_dev);
+  if (num_nodes == 0) return GGMS_OK;
+  GGMS_CHECK_ARG(slots && nodes && bucket_row && bucket_pos && num_nodes < (1ull << 32));
+  hipLaunchKernelGGL(k_owner_bucket, dim3(grid_for(num_nodes, kBlock)), dim3(kBlock), 0, to_stream(stream), slots, nodes,
+                     count_of(num_nodes, num_nodes_dev), num_part, (unsigned long long *)cursor_dev, bucket_row,
+                     bucket_pos);
+  GGMS_LAUNCH_CHECK();
+  return GGMS_OK;
+}
+
+// ---- shards across processes: cuda/dist_graph.cu:228-272 ----
+int ggms_device_alloc(void **ptr, size_t bytes) {
+  GGMS_CHECK_ARG(ptr && bytes > 0);
+  GGMS_HIP(hipMalloc(ptr, bytes));
+  return GGMS_OK;
+}
+
+int ggms_device_free(void *ptr) {
+  if (ptr) GGMS_HIP(hipFree(ptr));
+  return GGMS_OK;
+}
+
+int ggms_ipc_export(const void *ptr, void *handle) {
+  GGMS_CHECK_ARG(ptr && handle);
+  static_assert(sizeof(hipIpcMemHandle_t) <= GGMS_IPC_HANDLE_BYTES, "handle buffer too small");
+  hipIpcMemHandle_t h;
+  GGMS_HIP(hipIpcGetMemHandle(&h, const_cast<void *>(ptr)));
+  memset(handle, 0, GGMS_IPC_HANDLE_BYTES);
+  memcpy(handle, &h, sizeof(h));
+  return GGMS_OK;
+}
+
+int ggms_ipc_import(const void *handle, void **ptr) {
+  GGMS_CHECK_ARG(ptr && handle);
+  hipIpcMemHandle_t h;
+  memcpy(&h, handle, sizeof(h));
+  GGMS_HIP(hipIpcOpenMemHandle(ptr, h, hipIpcMemLazyEnablePeerAccess));
+  return GGMS_OK;
+}
+
+int ggms_ipc_release(void *ptr) {
+  if (ptr) GGMS_HIP(hipIpcCloseMemHandle(ptr));
+  return GGMS_OK;
 }
 
 } // extern "C"

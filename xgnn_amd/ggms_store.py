@@ -1,0 +1,151 @@
+"""GGMS feature shards across the GPUs of one node, one process per GPU.
+
+Cache slot s (position in the cache rank list, s < num_cached) lives on rank s % P at row s // P -- the
+reference's partition cache (GPUCacheManager ctor, cuda/cuda_cache_manager_host.cc:133-254); nodes that are
+not cached stay in host memory.  Two interchangeable ways to bring a batch's rows together:
+
+  mode "peer"  every rank maps its peers' shards (hipIpc) and ONE gather kernel dereferences the owner's HBM
+               directly over xGMI -- what the reference does over NVLink (combine_cache_data_for_partition,
+               cuda_cache_manager_device.cu:277-299).  No exchange step, no staging.
+  mode "a2a"   one exchange: bucket the batch by owner -> all-to-all of row ids -> every owner gathers the
+               rows asked of it from its own HBM -> all-to-all of rows -> scatter into the batch.  Fewer,
+               larger xGMI transfers through RCCL; one host sync per batch for the split sizes.
+
+Both produce the bytes `extract(full_table, nodes)` would.  The device work goes through `leaf` (default:
+the HIP operators of xgnn_amd.ops); tests exercise the host logic on CPU ranks by passing their own leaf.
+"""
+import numpy as np
+import torch
+
+
+class HipLeaf:
+    """The device operators the store needs, on HIP (xgnn_amd.ops)."""
+
+    def __init__(self):
+        from . import ops
+        self.ops = ops
+
+    def split_by_owner(self, table, nodes, num, num_part, num_dev=None):
+        """-> (bucket_row, bucket_pos, counts[num_part + 1] on the host).  One host sync.
+        num is an upper bound when the batch size lives on the device (num_dev)."""
+        ops, dev = self.ops, nodes.device
+        counts = torch.zeros(num_part + 1, dtype=torch.int64, device=dev)
+        slots = torch.empty(max(1, num), dtype=torch.int32, device=dev)
+        ops.owner_histogram(table, nodes, num_part, slots, counts, num=num, num_dev=num_dev)
+        counts_h = counts.cpu()
+        cursor = (torch.cumsum(counts_h, 0) - counts_h).to(dev)
+        row = torch.empty(max(1, num), dtype=torch.int32, device=dev)
+        pos = torch.empty(max(1, num), dtype=torch.int32, device=dev)
+        ops.owner_bucket(slots, nodes, num_part, cursor, row, pos, num=num, num_dev=num_dev)
+        return row, pos, counts_h
+
+    def gather(self, src, index):
+        return self.ops.extract(src, index)
+
+    def gather_scatter(self, out, src, src_index, dst_index):
+        n = (src_index if src_index is not None else dst_index).numel()
+        if n:
+            self.ops.gather_scatter(out, src, src_index, dst_index, num=n)
+
+    def gather_peer(self, out, nodes, num, table, parts_table, num_part, host_feat, num_dev=None, num_miss=None):
+        self.ops.extract_cached(out, nodes, table, parts_table, num_part, host_feat, num=num, num_dev=num_dev,
+                                num_miss=num_miss)
+
+
+def _all_to_all(dist, out, inp, out_splits, in_splits, group=None):
+    """all_to_all_single on the tensors' own device with RCCL; through host memory with any other backend
+    (gloo on a one-GPU test box)."""
+    if dist.get_backend(group) == "nccl" or not inp.is_cuda:
+        dist.all_to_all_single(out, inp, output_split_sizes=out_splits, input_split_sizes=in_splits, group=group)
+        return
+    o, i = out.cpu(), inp.cpu()
+    dist.all_to_all_single(o, i, output_split_sizes=out_splits, input_split_sizes=in_splits, group=group)
+    out.copy_(o)
+
+
+class FeatureShards:
+    """This rank's view of the partitioned feature cache."""
+
+    def __init__(self, shard, table, world, rank, mode="peer", dist=None, leaf=None, host_feat=None, group=None):
+        """shard: [ceil((num_cached - rank) / world), dim] rows of this rank (a SharedShard's tensor in peer mode);
+        table: int32[N] node -> slot or -1; host_feat: full table in (device-mapped) host memory for misses."""
+        assert mode in ("peer", "a2a")
+        self.shard, self.table, self.world, self.rank, self.mode = shard, table, world, rank, mode
+        self.dist, self.group, self.host_feat = dist, group, host_feat
+        self.leaf = leaf if leaf is not None else HipLeaf()
+        self.parts_table = None
+        self._shared = None
+
+    # ---- mode "peer": publish / map the shards ------------------------------------------------------
+    def connect_peers(self, shared_shard):
+        """Exchange hipIpc handles (all_gather of 64-byte blobs) and build the device pointer table."""
+        assert self.mode == "peer"
+        self._shared = shared_shard
+        mine = shared_shard.export_handle()
+        if self.world == 1:
+            handles = [mine]
+        else:
+            handles = [None] * self.world
+            self.dist.all_gather_object(handles, mine, group=self.group)
+        ptrs = [shared_shard.ptr if r == self.rank else shared_shard.import_peer(handles[r]) for r in range(self.world)]
+        self.parts_table = torch.tensor(ptrs, dtype=torch.int64, device=self.shard.device)
+        return self
+
+    # ---- one batch ----------------------------------------------------------------------------------
+    def extract(self, nodes, num, out, num_dev=None, num_miss=None):
+        """out[i, :] = feature row of nodes[i], i < num; with num_dev (device int64[1]) num is an upper bound."""
+        if self.mode == "peer":
+            self.leaf.gather_peer(out, nodes, num, self.table, self.parts_table, self.world, self.host_feat,
+                                  **({"num_dev": num_dev, "num_miss": num_miss} if num_dev is not None else {}))
+            return out
+        return self._extract_a2a(nodes, num, out, num_dev)
+
+    def _extract_a2a(self, nodes, num, out, num_dev=None):
+        P, me, leaf, dist = self.world, self.rank, self.leaf, self.dist
+        row, pos, counts = leaf.split_by_owner(self.table, nodes, num, P, **({"num_dev": num_dev} if num_dev is not None else {}))
+        counts = [int(c) for c in counts.tolist()]
+        start = np.concatenate([[0], np.cumsum(counts)]).tolist()
+        # my own bucket and the host bucket never leave the GPU
+        leaf.gather_scatter(out, self.shard, row[start[me]:start[me + 1]], pos[start[me]:start[me + 1]])
+        if counts[P]:
+            assert self.host_feat is not None, "batch has uncached nodes but no host tier was given"
+            leaf.gather_scatter(out, self.host_feat, row[start[P]:start[P + 1]], pos[start[P]:start[P + 1]])
+        if P == 1:
+            return out
+        send = [0 if p == me else counts[p] for p in range(P)]  # ids I ask of each owner
+        recv = self._exchange_counts(send)  # ids each requester asks of me
+        # request ids, grouped by owner (my own bucket cut out)
+        ids_out = torch.cat([row[start[p]:start[p + 1]] for p in range(P) if p != me]) if sum(send) else row[:0]
+        pos_out = torch.cat([pos[start[p]:start[p + 1]] for p in range(P) if p != me]) if sum(send) else pos[:0]
+        ids_in = torch.empty(sum(recv), dtype=row.dtype, device=row.device)
+        _all_to_all(dist, ids_in, ids_out.contiguous(), recv, send, self.group)
+        rows_out = leaf.gather(self.shard, ids_in) if sum(recv) else self.shard[:0]
+        rows_in = torch.empty((sum(send),) + tuple(self.shard.shape[1:]), dtype=self.shard.dtype, device=row.device)
+        _all_to_all(dist, rows_in, rows_out.contiguous(), send, recv, self.group)
+        leaf.gather_scatter(out, rows_in, None, pos_out.contiguous())
+        return out
+
+    def _exchange_counts(self, send):
+        on_dev = self.dist.get_backend(self.group) == "nccl"
+        s = torch.tensor(send, dtype=torch.int64, device=self.shard.device if on_dev else "cpu")
+        r = torch.zeros_like(s)
+        self.dist.all_to_all_single(r, s, group=self.group)
+        return [int(x) for x in r.tolist()]
+
+
+def shard_rows(feat_rows_fn, rank_list, num_cached, world, rank, dim, dtype, device, shared=False):
+    """Build this rank's shard: row k = feature of node rank_list[rank + k * world] (partition_feature).
+    feat_rows_fn(node_ids, out) fills `out` with the rows of `node_ids`.  shared=True allocates an
+    IPC-exportable shard (returns (tensor, SharedShard)), else a plain tensor (returns (tensor, None))."""
+    mine = rank_list[rank:num_cached:world]
+    n = int(mine.numel() if hasattr(mine, "numel") else len(mine))
+    holder = None
+    if shared:
+        from . import ops
+        holder = ops.SharedShard((max(n, 1), dim), dtype, device)
+        t = holder.tensor
+    else:
+        t = torch.empty((max(n, 1), dim), dtype=dtype, device=device)
+    if n:
+        feat_rows_fn(mine, t[:n])
+    return t, holder

@@ -7,6 +7,8 @@ samgraph/torch/adapter.cc:103,117) and are bit-identical to uint32.
 """
 import ctypes as C
 
+import numpy as np
+
 import torch
 
 from . import _lib
@@ -279,6 +281,69 @@ def extract_cached(out, nodes, table, parts_table, num_part, host_feat, num=None
                                     num_part, _ptr(host_feat), _dim_of(out), DTYPE_CODE[out.dtype], _ptr(num_miss),
                                     _stream()), "ggms_extract_cached")
     return out
+
+
+def owner_histogram(table, nodes, num_part, slots_out, counts, num=None, num_dev=None):
+    """slots_out[i] = table[nodes[i]]; counts[p] += rows of the batch owned by shard p (p = num_part: host tier)."""
+    _require_gpu(nodes)
+    n = nodes.numel() if num is None else num
+    check(lib().ggms_owner_histogram(_ptr(table), _ptr(nodes), n, _ptr(num_dev), num_part, _ptr(slots_out),
+                                     _ptr(counts), _stream()), "ggms_owner_histogram")
+
+
+def owner_bucket(slots, nodes, num_part, cursor, bucket_row, bucket_pos, num=None, num_dev=None):
+    """Group the batch by owning shard: bucket p starts at cursor[p] (exclusive prefix of the histogram)."""
+    _require_gpu(nodes)
+    n = nodes.numel() if num is None else num
+    check(lib().ggms_owner_bucket(_ptr(slots), _ptr(nodes), n, _ptr(num_dev), num_part, _ptr(cursor),
+                                  _ptr(bucket_row), _ptr(bucket_pos), _stream()), "ggms_owner_bucket")
+
+
+class _RawDevice:
+    def __init__(self, ptr, shape, typestr):
+        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr, "data": (int(ptr), False),
+                                         "version": 2, "strides": None}
+
+
+_TYPESTR = {torch.float32: "<f4", torch.float64: "<f8", torch.float16: "<f2", torch.uint8: "|u1",
+            torch.int32: "<i4", torch.int8: "|i1", torch.int64: "<i8"}
+
+
+class SharedShard:
+    """A GGMS shard that other processes can map: an allocation of its own (hipMalloc), published with
+    hipIpcGetMemHandle and opened by peers with hipIpcOpenMemHandle (cuda/dist_graph.cu:228-272)."""
+
+    def __init__(self, shape, dtype, device):
+        self.shape, self.dtype, self.device = tuple(int(x) for x in shape), dtype, torch.device(device)
+        nbytes = max(1, int(np.prod(self.shape))) * torch.empty(0, dtype=dtype).element_size()
+        p = C.c_void_p()
+        with torch.cuda.device(self.device):
+            check(lib().ggms_device_alloc(C.byref(p), nbytes), "ggms_device_alloc")
+        self.ptr = p.value
+        self.tensor = torch.as_tensor(_RawDevice(self.ptr, self.shape, _TYPESTR[dtype]), device=self.device)
+        self._imported = []
+
+    def export_handle(self):
+        buf = C.create_string_buffer(64)
+        check(lib().ggms_ipc_export(C.c_void_p(self.ptr), buf), "ggms_ipc_export")
+        return bytes(buf.raw)
+
+    def import_peer(self, handle):
+        """Map a peer's shard; returns its device address in this process."""
+        p = C.c_void_p()
+        with torch.cuda.device(self.device):
+            check(lib().ggms_ipc_import(C.c_char_p(handle), C.byref(p)), "ggms_ipc_import")
+        self._imported.append(p.value)
+        return p.value
+
+    def close(self):
+        for p in self._imported:
+            lib().ggms_ipc_release(C.c_void_p(p))
+        self._imported = []
+        if self.ptr:
+            self.tensor = None
+            lib().ggms_device_free(C.c_void_p(self.ptr))
+            self.ptr = None
 
 
 class BatchSampler:
