@@ -43,6 +43,10 @@ def parse():
     ap.add_argument("--no-overlap", action="store_true",
                     help="one stream: extract of batch k and sampling of batch k+1 run back to back "
                          "(default: two streams, the HBM-bound gather overlaps the latency-bound sampler)")
+    ap.add_argument("--store", default="replica", choices=["replica", "peer", "a2a"],
+                    help="N > 1: 'replica' = every GPU holds the cached features (DP over seeds only); 'peer' = GGMS "
+                         "feature shards (slot %% N), rows read from the owner's HBM inside the gather kernel over xGMI "
+                         "(hipIpc); 'a2a' = same shards, rows exchanged with RCCL all-to-all")
     ap.add_argument("--cache-ratio", type=float, default=1.0,
                     help="fraction of feature rows (by degree rank) resident in HBM; the rest is gathered from "
                          "pinned host memory by the same kernel (GGMS host tier). 1.0 = BASELINE configs[1]")
@@ -177,8 +181,14 @@ def main():
     rank_list = datagen.degree_rank(graph["indptr"])
     t_rank = to_dev(rank_list)
     num_cached = int(N * args.cache_ratio)
-    cache = torch.empty((max(num_cached, 1), dim), dtype=torch.float32, device=dev)
-    feat_rows(t_rank[:num_cached], cache)
+    store = None
+    if args.store == "replica" or world == 1:
+        cache = torch.empty((max(num_cached, 1), dim), dtype=torch.float32, device=dev)
+        feat_rows(t_rank[:num_cached], cache)
+    else:  # GGMS: cache slot s lives on rank s % world at row s // world
+        from xgnn_amd import ggms_store
+        cache, holder = ggms_store.shard_rows(feat_rows, t_rank, num_cached, world, rank, dim, torch.float32, dev,
+                                              shared=(args.store == "peer"))
     table = torch.full((N,), -1, dtype=torch.int32, device=dev)  # 0xffffffff
     table[t_rank[:num_cached].long()] = torch.arange(num_cached, dtype=torch.int32, device=dev)
     ptab = ops.part_pointer_table([cache], dev)
@@ -186,6 +196,10 @@ def main():
     if num_cached < N:  # host tier: the full table in pinned host memory, read zero-copy by the gather kernel
         host_feat = torch.empty((N, dim), dtype=torch.float32, pin_memory=True)
         feat_rows(torch.arange(N, dtype=torch.int64), host_feat)
+    if args.store != "replica" and world > 1:
+        store = ggms_store.FeatureShards(cache, table, world, rank, mode=args.store, dist=dist, host_feat=host_feat)
+        if args.store == "peer":
+            store.connect_peers(holder)
 
     code = {"khop3": ops.KHOP3, "khop0": ops.KHOP0, "khop2": ops.KHOP2, "khop1": ops.KHOP1}[args.sample_type]
     # batches in flight: K sampling pipelines (own stream, dedup table, workspace; RNG pool consumed in batch
@@ -248,8 +262,12 @@ def main():
             counts = sampler.counts_slots[slot]
             if timed_idx is not None:
                 ev[timed_idx][2].record(s_extract)
-            ops.extract_cached(out[slot], sampler.input_nodes[slot], table, ptab, 0, host_feat,
-                               num=sampler.max_unique, num_dev=counts[3 * L:3 * L + 1], num_miss=nmiss)
+            if store is None:
+                ops.extract_cached(out[slot], sampler.input_nodes[slot], table, ptab, 0, host_feat,
+                                   num=sampler.max_unique, num_dev=counts[3 * L:3 * L + 1], num_miss=nmiss)
+            else:  # sharded store: peer loads inside the same kernel, or the all-to-all exchange
+                store.extract(sampler.input_nodes[slot], sampler.max_unique, out[slot],
+                              num_dev=counts[3 * L:3 * L + 1], num_miss=nmiss)
             if timed_idx is not None:
                 ev[timed_idx][3].record(s_extract)
             h4 = time.perf_counter()
@@ -285,7 +303,7 @@ def main():
               file=sys.stderr)
     # the same gather with nothing beside it (one stream), for reference next to the in-pipeline figure
     serial_us = None
-    if not args.no_overlap:
+    if not args.no_overlap and store is None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         reps = 10
         counts = sampler.counts_slots[(args.warmup + args.steps - 1) % NSLOT]
@@ -298,6 +316,16 @@ def main():
         torch.cuda.synchronize()
         serial_us = e0.elapsed_time(e1) / reps * 1e3
         serial_rows = int(counts[3 * L].item())
+    # self-check outside the timed region: the last batch's rows against the generator's closed form
+    last_slot = (args.warmup + args.steps - 1) % NSLOT
+    n_last = int(sampler.counts_slots[last_slot][3 * L].item())
+    ids = sampler.input_nodes[last_slot][:n_last].to(torch.int64)
+    sample_ids = ids[:: max(1, n_last // 4096)]
+    want = torch.empty((sample_ids.numel(), dim), dtype=torch.float32, device=dev)
+    feat_rows(sample_ids, want)
+    rows_ok = bool(torch.equal(out[last_slot][:n_last][:: max(1, n_last // 4096)], want))
+    if not rows_ok:
+        raise SystemExit("bench self-check failed: gathered rows differ from the feature generator")
     c = acc.cpu().tolist()
     edges = sum(c[3 * i] for i in range(L))
     rows = c[3 * L]
@@ -335,11 +363,12 @@ def main():
             "vs_baseline": None,
             "dtype": "u32 ids / f32 rows (bit copy)",
             "data": "synthetic",
+            "rows_verified": rows_ok,
             "config": {
                 "workload": f"{args.preset}-shaped power-law CSR N={N} E={meta['num_edge']} f32 dim {dim}, "
                             f"GraphSAGE fanout {fanouts} {args.sample_type}, batch {args.batch}, "
                             f"graph in HBM, feature cache_ratio {args.cache_ratio} (rest in pinned host DRAM), "
-                            f"seeds DP over {world} GPU(s)",
+                            f"seeds DP over {world} GPU(s), feature store: {args.store if world > 1 else 'local'}",
                 "global_batch": args.batch * world,
                 "parallelism": f"dp{world}",
                 "streams": "1 (serial)" if args.no_overlap else

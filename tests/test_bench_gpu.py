@@ -1,0 +1,41 @@
+"""bench.py contract on the GPU box: one JSON line with the required keys; the N = 2 launch (two ranks pinned to
+the box's one GPU through the bench's test hooks, gloo for the timing barrier) for every feature-store mode."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+KEYS = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+        "vs_baseline", "dtype", "data", "config", "roofline"}
+
+
+def _last_json(stdout):
+    return json.loads([l for l in stdout.strip().splitlines() if l.startswith("{")][-1])
+
+
+def test_single_gpu_line():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--preset", "tiny", "--steps", "4", "--warmup", "1",
+                        "--batch", "512", "--cpu-seconds", "1"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = _last_json(r.stdout)
+    assert KEYS <= set(d) and "cpu_baseline" in d
+    assert d["n_gpus"] == 1 and d["value"] > 0 and d["roofline"]["bound"] == "hbm" and d["config"]["workload"]
+
+
+@pytest.mark.parametrize("store", ["replica", "peer", "a2a"])
+def test_two_ranks_one_gpu(store):
+    env = dict(os.environ, GGMS_BENCH_DEVICE="0", GGMS_BENCH_BACKEND="gloo")
+    port = 29600 + {"replica": 1, "peer": 2, "a2a": 3}[store]
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
+                        "--gpus", "2", "--preset", "tiny", "--steps", "4", "--warmup", "1", "--batch", "512",
+                        "--store", store, "--cache-ratio", "0.6"],
+                       capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = _last_json(r.stdout)
+    assert KEYS <= set(d) and d["n_gpus"] == 2 and d["value"] > 0
+    assert store in d["config"]["workload"]
