@@ -1,5 +1,6 @@
 // ggms_device.h -- shared device-side building blocks (gfx950, wave64).
 #pragma once
+#include <cstdlib>
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -34,10 +35,22 @@ void set_error(const char *fmt, ...);
 
 inline hipStream_t to_stream(ggms_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 
+// Grid for a grid-stride kernel over n items.  The cap decides how a kernel shares the chip with the other
+// stream: 2048 blocks x 256 threads is every wave slot of the device (256 CUs x 32 waves) held for the whole
+// kernel, so a kernel arriving on the other stream waits it out; a grid of many short-lived blocks frees
+// slots all the time and the dispatcher interleaves the two queues.  GGMS_GRID_CAP overrides (measurement hook).
+inline size_t grid_cap() {
+  static const size_t cap = [] {
+    const char *e = getenv("GGMS_GRID_CAP");
+    const long v = e ? atol(e) : 0;
+    return v > 0 ? (size_t)v : (size_t)kMaxGridBlocks;
+  }();
+  return cap;
+}
 inline int grid_for(size_t n, size_t per_block) {
   size_t g = (n + per_block - 1) / per_block;
   if (g < 1) g = 1;
-  if (g > (size_t)kMaxGridBlocks) g = kMaxGridBlocks;
+  if (g > grid_cap()) g = grid_cap();
   return (int)g;
 }
 
