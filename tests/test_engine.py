@@ -197,8 +197,7 @@ def test_arch6_two_workers_one_gpu(tmp_path, opts):
 def test_cpp_driver_over_the_c_abi(tmp_path):
     """A pure C++ caller (tools/samgraph_no_train.cc, the role of samgraph/main.cc) drives the same ABI."""
     exe = os.path.join(ROOT, "build", "samgraph_no_train")
-    if not os.path.exists(exe):
-        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "xgnn_amd", "csrc"), "driver"])
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "xgnn_amd", "csrc"), "driver"])
     d = make_dataset(tmp_path / "ds")
     r = subprocess.run([exe, "--dataset-path", d["path"], "--batch-size", "64", "--num-epoch", "2", "--fanout", "5 4",
                         "--seed", "3"], capture_output=True, text=True, timeout=600)
@@ -208,10 +207,9 @@ def test_cpp_driver_over_the_c_abi(tmp_path):
     # same seed => same number of sampled edges as the oracle replay
     want = _oracle_batches(d, 0, 1, 64, 2, [5, 4], 3, arch6=False)
     for ep, line in enumerate(lines):
-        ts = float(line.split("sample ")[1].split(" s")[0])
-        seps = float(line.split("-> ")[1].split(" M SEPS")[0])
+        got_edges = int(line.split("| ")[1].split(" edges")[0])
         edges = sum(sum(l["row"].size for l in w["res"]["layers"]) for k, w in want.items() if k // 8 == ep)
-        assert abs(seps * 1e6 * ts - edges) <= max(2e-3 * edges, 600)  # printed with 4/3 digits
+        assert got_edges == edges
 
 
 @pytest.mark.gpu

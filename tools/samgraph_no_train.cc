@@ -45,8 +45,8 @@ int main(int argc, char **argv) {
     // item codes: kLogEpochSampleTime = 0, kLogEpochCopyTime = 8, kLogEpochFeatureBytes = 12, kLogEpochNumSample = 15
     const double ts = samgraph_get_log_epoch_value(e, 0), tc = samgraph_get_log_epoch_value(e, 8);
     const double fb = samgraph_get_log_epoch_value(e, 12), ns = samgraph_get_log_epoch_value(e, 15);
-    std::printf("[epoch %zu] %zu steps, wall %.4f s | sample %.4f s -> %.3f M SEPS | extract %.4f s -> %.2f GB/s\n", e, steps,
-                wall, ts, ns / ts / 1e6, tc, fb / tc / 1e9);
+    std::printf("[epoch %zu] %zu steps, wall %.4f s | %.0f edges, sample %.6f s -> %.3f M SEPS | extract %.6f s -> %.2f GB/s\n",
+                e, steps, wall, ns, ts, ns / ts / 1e6, tc, fb / tc / 1e9);
   }
   samgraph_report_init();
   samgraph_shutdown();

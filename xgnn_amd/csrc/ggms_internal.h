@@ -8,7 +8,7 @@ namespace ggms {
 size_t sample_ws_words(size_t num_input);
 int sample_khop3_impl(GraphView g, const uint32_t *input, size_t n_max, Count n, uint32_t fanout, uint32_t *out_src,
                       uint32_t *out_dst, uint64_t *num_out_dev, uint32_t *states, uint32_t *workspace,
-                      const uint32_t *seed_local, int src_local, const uint32_t *local_to_global, hipStream_t s,
+                      const uint32_t *seed_local, int src_local, const ggms_hashtable_t *insert_into, hipStream_t s,
                       ScanArea *shared_scan = nullptr);
 int sample_khop0_impl(GraphView g, const uint32_t *input, size_t n_max, Count n, uint32_t fanout, uint32_t *out_src,
                       uint32_t *out_dst, uint64_t *num_out_dev, uint32_t *workspace, const uint32_t *seed_local,
@@ -44,8 +44,9 @@ struct BatchPrologue {
 // insert + ordered local-id assignment; item_pos[i] = bucket of input[i] (hashed layout only).
 // mirror_a/b (optional): 64-bit device slots that also receive the new item count.
 // mapped (optional): mapped[i] = local id of input[i] (the dst half of GPUMapEdges, fused).
+// inserted = true: the producer of `input` already entered every item (k_gather_neighbours<true>).
 int ht_fill_impl(const ggms_hashtable_t *ht, const uint32_t *input, size_t n_max, Count n, uint32_t *item_pos,
                  ScanArea scan, uint64_t *mirror_a, uint64_t *mirror_b, hipStream_t s, uint32_t *mapped = nullptr,
-                 const BatchPrologue *prologue = nullptr);
+                 const BatchPrologue *prologue = nullptr, bool inserted = false);
 
 } // namespace ggms

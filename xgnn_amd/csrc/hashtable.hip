@@ -187,7 +187,7 @@ size_t ht_ws_words(size_t num_input) { return num_input + tile_scan_words(num_in
 // clear_area: this is the first kernel of a batch -- it also zeroes the shared scan area's control words.
 int ht_fill_impl(const ggms_hashtable_t *ht, const uint32_t *input, size_t n_max, Count n, uint32_t *item_pos,
                  ScanArea scratch, uint64_t *mirror_a, uint64_t *mirror_b, hipStream_t s, uint32_t *mapped,
-                 const BatchPrologue *prologue) {
+                 const BatchPrologue *prologue, bool inserted) {
   BatchPrologue pro{nullptr, 0, nullptr, nullptr};
   if (prologue) pro = *prologue;
   if (n_max == 0) { // no kernel to ride on
@@ -200,8 +200,10 @@ int ht_fill_impl(const ggms_hashtable_t *ht, const uint32_t *input, size_t n_max
   const int grid = grid_for(n_max, kBlock);
   int rc;
   if (ht->direct) {
-    hipLaunchKernelGGL(k_ht_insert<true>, dim3(grid), dim3(kBlock), 0, s, t, input, n, item_pos, pro);
-    GGMS_LAUNCH_CHECK();
+    if (!inserted) {
+      hipLaunchKernelGGL(k_ht_insert<true>, dim3(grid), dim3(kBlock), 0, s, t, input, n, item_pos, pro);
+      GGMS_LAUNCH_CHECK();
+    }
     scratch.stash = item_pos; // the direct layout does not use item_pos: it holds the owner flags between passes
     rc = tile_scan(OwnerFlag<true>{t, input}, AssignLocal<true>{t, input, input, mapped}, n_max, n, scratch,
                    ht->num_items_dev, ht->num_items_dev, nullptr, s, mirror_a, mirror_b);

@@ -178,11 +178,13 @@ int ggms_sample_batch(int sample_type, const ggms_graph_t *graph, const ggms_id_
                                : counts_dev + 3 * num_layer;          // = number of input nodes
     // batch order on the shared RNG pool (and on khop2's CSR): only the sampler kernels are ordered
     if (first && extra && extra->rng_wait) GGMS_HIP(hipStreamWaitEvent(s, (hipEvent_t)extra->rng_wait, 0));
+    bool inserted = false; // the sampler entered its output into the table itself
     if (n_max == 0) {
       GGMS_HIP(hipMemsetAsync(num_edge, 0, sizeof(uint64_t), s));
     } else if (sample_type == GGMS_KHOP3) {
       rc = sample_khop3_impl(g, input, n_max, n, (uint32_t)fanouts[i], col[i], tmp_dst, num_edge, (uint32_t *)states,
-                             samp_ws, first ? seed_local : nullptr, 1, ht->n2o, s, &scan);
+                             samp_ws, first ? seed_local : nullptr, 1, ht, s, &scan);
+      inserted = ht->direct != 0;
     } else if (sample_type == GGMS_KHOP0) {
       rc = sample_khop0_impl(g, input, n_max, n, (uint32_t)fanouts[i], col[i], tmp_dst, num_edge, samp_ws,
                              first ? seed_local : nullptr, 1, s, &scan);
@@ -214,7 +216,7 @@ int ggms_sample_batch(int sample_type, const ggms_graph_t *graph, const ggms_id_
       continue;
     }
     // FillWithDuplicates (:279) + the dst half of GPUMapEdges (:296): row[i] = local id of every sampled neighbour
-    rc = ht_fill_impl(ht, tmp_dst, e_max, ne, item_pos, scan, num_src, next_dst, s, row[i]);
+    rc = ht_fill_impl(ht, tmp_dst, e_max, ne, item_pos, scan, num_src, next_dst, s, row[i], nullptr, inserted);
     if (rc != GGMS_OK) return rc;
   }
   return GGMS_OK;

@@ -220,11 +220,15 @@ __global__ __launch_bounds__(128 * (4 / GPW)) void k_khop3_positions(GraphView g
 
 // Slot j of seed i -> the edge at offset[i] + j: its position inside the seed's neighbour list is j for
 // a "take them all" seed and the sampler's pick otherwise; written out as (src value, neighbour id).
+// INSERT: the batch loop's dedup table is direct-indexed, so the neighbour is also entered right here
+// (one fire-and-forget atomicMin, what k_ht_insert<true> would do in a pass of its own).
+template <bool INSERT>
 __global__ __launch_bounds__(kBlock) void k_gather_neighbours(GraphView g, const uint32_t *__restrict__ input,
                                                               Count n_arg, uint32_t fanout, uint32_t fanout_magic,
                                                               const uint32_t *__restrict__ offset,
                                                               uint32_t *__restrict__ out_src,
-                                                              uint32_t *__restrict__ out_dst, SrcMode sm) {
+                                                              uint32_t *__restrict__ out_dst, SrcMode sm,
+                                                              unsigned long long *table_w, uint32_t table_version) {
   const uint64_t total = n_arg.get() * fanout;
   for (uint64_t t = (uint64_t)blockIdx.x * kBlock + threadIdx.x; t < total; t += (uint64_t)gridDim.x * kBlock) {
     // i = t / fanout for t < 2^32 (host checks n_max * fanout < 2^32): mulhi by ceil(2^32 / fanout), one fix-up
@@ -237,8 +241,11 @@ __global__ __launch_bounds__(kBlock) void k_gather_neighbours(GraphView g, const
     if (j >= min(len, fanout)) continue;
     const uint32_t e = offset[i] + j;
     const uint32_t pos = len <= fanout ? j : out_dst[e];
+    const uint32_t nbr = edges[pos];
     out_src[e] = sm.value(rid, i);
-    out_dst[e] = edges[pos];
+    out_dst[e] = nbr;
+    if (INSERT) // w1 = {0x7fffffff - version : 31 | pending = 1 | first index : 32}, hashtable.hip
+      atomicMin(table_w + nbr, ((((unsigned long long)(0x7fffffffu - table_version)) << 1 | 1ull) << 32) | e);
   }
 }
 
@@ -363,7 +370,7 @@ size_t sample_ws_words(size_t num_input) { return num_input + tile_scan_words(nu
 // offsets by exclusive scan of min(deg, fanout), then the sampler proper
 int sample_khop3_impl(GraphView g, const uint32_t *input, size_t n_max, Count n, uint32_t fanout, uint32_t *out_src,
                       uint32_t *out_dst, uint64_t *num_out_dev, uint32_t *states, uint32_t *workspace,
-                      const uint32_t *seed_local, int src_local, const uint32_t *local_to_global, hipStream_t s,
+                      const uint32_t *seed_local, int src_local, const ggms_hashtable_t *insert_into, hipStream_t s,
                       ScanArea *shared_scan) {
   uint32_t *offset = workspace;
   const ScanArea sa = shared_scan ? *shared_scan : ScanArea{offset + n_max, false};
@@ -386,10 +393,14 @@ int sample_khop3_impl(GraphView g, const uint32_t *input, size_t n_max, Count n,
     hipLaunchKernelGGL(k_khop3_positions<4>, dim3(grid), dim3(128), 0, s, g, input, n, fanout, offset, out_dst, states,
                        set_mask);
   GGMS_LAUNCH_CHECK();
-  (void)local_to_global;
   const uint32_t fanout_magic = (uint32_t)((0x100000000ull + fanout - 1) / fanout); // ceil(2^32 / fanout)
-  hipLaunchKernelGGL(k_gather_neighbours, dim3(grid_for(n_max * fanout, kBlock)), dim3(kBlock), 0, s, g, input, n,
-                     fanout, fanout_magic, offset, out_src, out_dst, sm);
+  if (insert_into && insert_into->direct)
+    hipLaunchKernelGGL(k_gather_neighbours<true>, dim3(grid_for(n_max * fanout, kBlock)), dim3(kBlock), 0, s, g, input,
+                       n, fanout, fanout_magic, offset, out_src, out_dst, sm, (unsigned long long *)insert_into->o2n,
+                       insert_into->version);
+  else
+    hipLaunchKernelGGL(k_gather_neighbours<false>, dim3(grid_for(n_max * fanout, kBlock)), dim3(kBlock), 0, s, g, input,
+                       n, fanout, fanout_magic, offset, out_src, out_dst, sm, nullptr, 0u);
   GGMS_LAUNCH_CHECK();
   return GGMS_OK;
 }
