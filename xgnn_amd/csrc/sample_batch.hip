@@ -19,8 +19,17 @@
 //     local id is its position in the frontier (n2o), so the E hash lookups of
 //     GPUMapEdges' src half (cuda_mapping.cu:57-60) reduce to none (n lookups
 //     for the first layer, whose input is the raw seed list);
-//   * `row` comes from the bucket position remembered at insert time
-//     (item_pos), so the dst half needs no probing either.
+//   * `row` (local id of the sampled neighbour) is produced by the table fill itself:
+//     the instance that owns a key writes its id while assigning it, the other ~30 %
+//     are looked up afterwards (k_map_rest) -- the dst half of GPUMapEdges without a
+//     pass over all E edges;
+//   * with the direct table layout khop3's neighbour gather also enters the neighbour
+//     into the table (one atomicMin), so FillWithDuplicates starts at the owner scan;
+//   * the batch prologue (scan-area clear, item-count reset, |seeds| record) rides on
+//     the first kernel of the batch instead of three tiny launches.
+// Several batches may be in flight on different streams (own table + workspace each):
+// ggms_sample_extra_t.rng_wait / rng_done chain only the sampler kernels, which share
+// the RNG pool, in batch order.
 #include <algorithm>
 
 #include "ggms_internal.h"

@@ -13,10 +13,12 @@
 //     (khop3.cu:148-230,272-302) and their four host syncs disappear;
 //   * khop3: the reference spends 16 lanes of a warp on one seed although its
 //     rejection loop is serial by construction (one shared XORWOW state, one
-//     insert per draw, khop3.cu:125-131).  Here ONE lane owns one RNG stream
-//     ("group"), i.e. 64 independent streams per wave64, each with a private
-//     open-addressing set in LDS laid out lane-interleaved (bank = lane % 32,
-//     conflict-free for ds_read_b32/ds_write_b32);
+//     insert per draw, khop3.cu:125-131).  Here the 16 lanes of a group take 16
+//     consecutive draws of the stream per round and resolve them together (set
+//     lookup, in-round first-occurrence dedup, ranking); seeds that take all their
+//     neighbours never enter the loop; see k_khop3_positions below;
+//   * khop2: one lane per stream as the assignment demands, compact COO written
+//     directly at the seed's scanned offset;
 //   * khop0: one lane per logical reservoir lane (32 per seed, as the RNG stream
 //     assignment demands); the racy atomicExch (khop0.cu:144-148) becomes an LDS
 //     atomicMax on the candidate position, i.e. highest-j-wins, deterministic.
