@@ -34,7 +34,10 @@ def parse():
     ap.add_argument("--preset", default="products")
     ap.add_argument("--batch", type=int, default=8000)
     ap.add_argument("--fanout", default="25,10")
-    ap.add_argument("--sample-type", default="khop3", choices=["khop3", "khop0", "khop2", "khop1"])
+    ap.add_argument("--sample-type", default="khop3",
+                    choices=["khop3", "khop0", "khop2", "khop1", "weighted_khop", "random_walk"],
+                    help="random_walk: PinSAGE defaults (walk length 3, restart 0.5, 4 walks); --fanout gives the "
+                         "top-K per layer, e.g. 5,5,5.  weighted_khop: synthetic alias tables")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline: keep sampling mini-batches this long")
     ap.add_argument("--host-profile", action="store_true", help="print host enqueue time per section to stderr")
@@ -201,13 +204,22 @@ def main():
         if args.store == "peer":
             store.connect_peers(holder)
 
-    code = {"khop3": ops.KHOP3, "khop0": ops.KHOP0, "khop2": ops.KHOP2, "khop1": ops.KHOP1}[args.sample_type]
+    code = {"khop3": ops.KHOP3, "khop0": ops.KHOP0, "khop2": ops.KHOP2, "khop1": ops.KHOP1,
+            "weighted_khop": ops.WEIGHTED_KHOP, "random_walk": ops.RANDOM_WALK}[args.sample_type]
+    extra_kw = {}
+    if args.sample_type == "weighted_khop":  # per-edge acceptance probability + alias neighbour (engine.cc:372-384)
+        gen = torch.Generator(device=dev).manual_seed(7)
+        E = indices.numel()
+        extra_kw = dict(prob_table=torch.rand(E, generator=gen, device=dev, dtype=torch.float32),
+                        alias_table=torch.randint(0, N, (E,), generator=gen, device=dev, dtype=torch.int32))
+    if args.sample_type == "random_walk":  # common_config.py PinSAGE defaults
+        extra_kw = dict(random_walk_length=3, random_walk_restart_prob=0.5, num_random_walk=4)
     # batches in flight: K sampling pipelines (own stream, dedup table, workspace; RNG pool consumed in batch
     # order) + the extract stream; outputs live in batch slots, as in the engine
     K = 1 if args.no_overlap else max(1, args.pipelines)
     NSLOT = K + 1
     sampler = ops.BatchSampler(g, fanouts, args.batch, sample_type=code, seed=0x5EED + rank, device=dev,
-                               num_slots=NSLOT, num_pipelines=K)
+                               num_slots=NSLOT, num_pipelines=K, **extra_kw)
     out = [torch.empty((sampler.max_unique, dim), dtype=torch.float32, device=dev) for _ in range(NSLOT)]
     out_label = [torch.empty(sampler.max_seeds, dtype=torch.int64, device=dev) for _ in range(NSLOT)]
     nmiss = torch.zeros(1, dtype=torch.int64, device=dev)
