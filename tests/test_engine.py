@@ -120,8 +120,10 @@ def _check(npz, want, num_layers):
 def test_arch1_end_to_end(tmp_path, pipelined, sample_type, table):
     d = make_dataset(tmp_path / "ds")
     prefix = str(tmp_path / "out")
+    # sample_once() enqueues one batch ahead by default; the hashed-table case runs without that
     r = subprocess.run([sys.executable, DRIVER, d["path"], prefix, "arch1", "1", f"pipelined={pipelined}",
-                        f"sample_type={sample_type}", f"hash_table={table}", "seed=99", "batch_size=64", "fanout=5 4"],
+                        f"sample_type={sample_type}", f"hash_table={table}", "seed=99", "batch_size=64", "fanout=5 4",
+                        f"lookahead={0 if table == 'hashed' else 1}"],
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     want = _oracle_batches(d, 0, 1, 64, 2, [5, 4], 99, arch6=False, sample_type=sample_type)

@@ -111,6 +111,7 @@ void Engine::Configure(const std::unordered_map<std::string, std::string> &kv_in
   if (kv.count("presample_epoch")) cfg.presample_epoch = std::stoull(kv["presample_epoch"]); // operation.cc:184-189
   if (kv.count("seed")) { cfg.has_seed = true; cfg.seed = std::stoull(kv["seed"]); }
   if (kv.count("hash_table")) cfg.direct_table = kv["hash_table"] != "hashed";
+  if (kv.count("lookahead")) cfg.lookahead = std::stoull(kv["lookahead"]);
   SAM_CHECK(cfg.sample_type == GGMS_KHOP3 || cfg.sample_type == GGMS_KHOP0 || cfg.sample_type == GGMS_KHOP1 ||
                 cfg.sample_type == GGMS_KHOP2 || cfg.sample_type == GGMS_WEIGHTED_KHOP ||
                 cfg.sample_type == GGMS_RANDOM_WALK,
@@ -552,6 +553,7 @@ void Engine::TrainInit(int worker_id, const std::string &ctx) {
   const size_t row_bytes = ds.feat_dim * ggms_dtype_bytes(ds.feat_dtype);
   size_t nslots = 2;
   if (cfg.raw.count("max_copying_jobs")) nslots = std::max<size_t>(2, std::min<size_t>(4, std::stoull(cfg.raw["max_copying_jobs"]) + 1));
+  nslots = std::max(nslots, 2 + cfg.lookahead); // the trainer's batch + the one asked for + the ones enqueued ahead
   for (size_t s = 0; s < nslots; ++s) {
     auto b = std::make_unique<Batch>();
     b->slot = (int)s;
@@ -611,17 +613,30 @@ Batch *Engine::AcquireSlot() {
   }
 }
 
-// RunArch1LoopsOnce (cuda/cuda_loops_arch1.cc:43-86) / RunArch6LoopsOnce (dist/dist_loops_arch6.cc:236-243):
-// shuffle -> sample -> extract, all enqueued on one stream with no host round trip
+// samgraph_sample_once: the batches come out in shuffler order whoever asks, so the foreground call keeps
+// `lookahead` more of them enqueued than it was asked for -- batch k+1 samples while batch k's rows are gathered and
+// while the caller trains on batch k.  The pool hands them out in the same order (GetNextBatch).
 void Engine::RunSampleOnce() {
+  if (bg_.joinable() && std::this_thread::get_id() == bg_.get_id()) { // background loop: one per iteration
+    (void)EnqueueOne();
+    return;
+  }
+  ++fg_calls_;
+  while (fg_enqueued_ < fg_calls_ + cfg.lookahead && EnqueueOne()) ++fg_enqueued_;
+  // a call that found the pool full (cuda_loops_arch1.cc:45-48) stays owed: a later call catches up
+}
+
+// RunArch1LoopsOnce (cuda/cuda_loops_arch1.cc:43-86) / RunArch6LoopsOnce (dist/dist_loops_arch6.cc:236-243):
+// shuffle -> sample -> extract, all enqueued with no host round trip.  false: no free slot, or training finished.
+bool Engine::EnqueueOne() {
   SAM_CHECK(train_ready_, "engine not initialised");
   SAM_HIP(hipSetDevice(device_));
   Batch *b = AcquireSlot();
-  if (!b) return;
+  if (!b) return false;
   if (!ShufflerNext(b)) { // training finished
     std::lock_guard<std::mutex> lk(pool_mu_);
     b->in_use = false;
-    return;
+    return false;
   }
   const uint32_t L = (uint32_t)cfg.fanout.size();
   SAM_HIP(hipEventRecord(b->ev_start, stream_));
@@ -659,6 +674,7 @@ void Engine::RunSampleOnce() {
     pool_.push_back(b); // graph_pool->Submit
   }
   pool_cv_.notify_all();
+  return true;
 }
 
 // block until the batch is complete, publish sizes, log the items the scripts read

@@ -69,6 +69,7 @@ struct RunConfig {
   bool has_seed = false;
   uint64_t seed = 0;
   bool direct_table = true;
+  size_t lookahead = 1; // batches sample_once() keeps enqueued beyond the one it was asked for (config key `lookahead`)
   size_t presample_epoch = 0;
   bool UsePresample() const { return UseGPUCache() && (cache_policy == 2 /*kCacheByPreSample*/); }
   bool UseGPUCache() const { return cache_percentage > 0 && arch != kArch1; } // run_config.h:124-126
@@ -150,6 +151,7 @@ class Engine {
   void Start();
   void Shutdown();
   void RunSampleOnce();
+  bool EnqueueOne();
   uint64_t GetNextBatch();
   void ExtractStart(int count);
   Batch *Current(uint64_t key);
@@ -220,6 +222,7 @@ class Engine {
   std::condition_variable pool_cv_;
   Batch *current_ = nullptr;
   std::thread bg_;
+  size_t fg_calls_ = 0, fg_enqueued_ = 0; // foreground sample_once() calls / batches enqueued for them
   std::atomic<bool> bg_stop_{false};
   // shared (arch6): control block inherited through fork
   struct Shared;
