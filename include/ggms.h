@@ -121,6 +121,36 @@ int ggms_sample_khop0(const ggms_graph_t *graph, const ggms_id_t *input,
                       void *workspace, size_t workspace_bytes,
                       ggms_stream_t stream);
 
+/* GPUSampleWeightedKHopPrefix, cuda/cuda_sampling_weighted_khop_prefix.cu:145-246:
+ * prob_prefix_table = per-list inclusive prefix sums of the edge weights; one
+ * curand_uniform per task, binary search, then the weighted_khop sort/compaction.
+ * Workspace and num_states as ggms_sample_weighted_khop. */
+int ggms_sample_weighted_khop_prefix(const ggms_graph_t *graph,
+                                     const float *prob_prefix_table,
+                                     const ggms_id_t *input, size_t num_input,
+                                     size_t fanout, ggms_id_t *out_src,
+                                     ggms_id_t *out_dst, uint64_t *num_out_dev,
+                                     void *states, size_t num_states,
+                                     void *workspace, size_t workspace_bytes,
+                                     ggms_stream_t stream);
+/* GPUSampleWeightedKHopHashDedup, cuda/cuda_sampling_weighted_khop_hash_dedup.cu:
+ * 196-283: alias-method candidates until `fanout` (< 50) distinct ids per seed;
+ * stream map of khop2 (num_states >= ceil(num_input/1024)*256).  Two bounds the
+ * reference lacks (it would not terminate): a seed that has drawn 65536
+ * candidates takes every further one, and a table probe gives up after 64 steps
+ * (full table) and takes the candidate.
+ * Workspace: ggms_sample_workspace_bytes. */
+int ggms_sample_weighted_khop_hash_dedup(const ggms_graph_t *graph,
+                                         const float *prob_table,
+                                         const ggms_id_t *alias_table,
+                                         const ggms_id_t *input,
+                                         size_t num_input, size_t fanout,
+                                         ggms_id_t *out_src, ggms_id_t *out_dst,
+                                         uint64_t *num_out_dev, void *states,
+                                         size_t num_states, void *workspace,
+                                         size_t workspace_bytes,
+                                         ggms_stream_t stream);
+
 /* GPUSampleKHop1, cuda/cuda_sampling_khop1.cu:130-236: uniform WITH replacement,
  * stable order by src id, an edge equal to its successor dropped.  Unsharded graphs
  * only (dist_loops.cc:167-168).  Workspace: ggms_sample_weighted_workspace_bytes.
@@ -228,7 +258,8 @@ int ggms_map_edges(const ggms_hashtable_t *ht, const ggms_id_t *global_src,
  * ------------------------------------------------------------------------- */
 /* per-sample-type extras of ggms_sample_batch (NULL for khop0/khop3) */
 typedef struct {
-  const float *prob_table;        /* weighted_khop: dataset->prob_table  (engine.cc:372-384) */
+  const float *prob_table;        /* weighted_khop[_hash_dedup]: dataset->prob_table (engine.cc:372-384);
+                                     weighted_khop_prefix: dataset->prob_prefix_table, alias_table NULL */
   const ggms_id_t *alias_table;   /*                dataset->alias_table                      */
   size_t random_walk_length;      /* random_walk: RunConfig::random_walk_length ...           */
   double random_walk_restart_prob;

@@ -20,6 +20,7 @@ _REF = None
 
 EMPTY_KEY = 0xFFFFFFFF
 KHOP0, KHOP1, WEIGHTED_KHOP, RANDOM_WALK, KHOP2, KHOP3, CPU_KHOP0 = 0, 1, 2, 3, 5, 7, 100
+WEIGHTED_KHOP_PREFIX, WEIGHTED_KHOP_HASH_DEDUP = 4, 6
 
 u32p = C.POINTER(C.c_uint32)
 XORWOW_DTYPE = np.dtype([("d", "<u4"), ("v", "<u4", (5,))])
@@ -146,6 +147,26 @@ def sample_khop3(indptr, indices, inp, fanout, states):
     n = C.c_size_t(0)
     lib().orc_sample_khop3(_p(indptr), _p(indices), _p(inp), _sz(inp.size), _sz(fanout),
                            _p(states), _sz(states.size), _p(src), _p(dst), C.byref(n))
+    return src[: n.value].copy(), dst[: n.value].copy()
+
+
+def sample_weighted_khop_prefix(indptr, indices, prob_prefix, inp, fanout, states):
+    indptr, indices, inp = _u32(indptr), _u32(indices), _u32(inp)
+    prob_prefix = np.ascontiguousarray(prob_prefix, np.float32)
+    src, dst = _alloc_out(inp.size, fanout)
+    n = C.c_size_t(0)
+    lib().orc_sample_weighted_khop_prefix(_p(indptr), _p(indices), _p(prob_prefix), _p(inp), _sz(inp.size),
+                                          _sz(fanout), _p(states), _sz(states.size), _p(src), _p(dst), C.byref(n))
+    return src[: n.value].copy(), dst[: n.value].copy()
+
+
+def sample_weighted_khop_hash_dedup(indptr, indices, prob, alias, inp, fanout, states):
+    indptr, indices, inp, alias = _u32(indptr), _u32(indices), _u32(inp), _u32(alias)
+    prob = np.ascontiguousarray(prob, np.float32)
+    src, dst = _alloc_out(inp.size, fanout)
+    n = C.c_size_t(0)
+    lib().orc_sample_weighted_khop_hash_dedup(_p(indptr), _p(indices), _p(prob), _p(alias), _p(inp), _sz(inp.size),
+                                              _sz(fanout), _p(states), _sz(states.size), _p(src), _p(dst), C.byref(n))
     return src[: n.value].copy(), dst[: n.value].copy()
 
 
@@ -300,10 +321,12 @@ def do_sample(sample_type, indptr, indices, seeds, fanouts, states=None, prob=No
     if states is None:
         states = np.zeros(1, XORWOW_DTYPE)
     ex = _SampleExtra()
-    if prob is not None:
+    if prob is not None:  # alias method (prob + alias) or prefix sums (prob only)
         prob = np.ascontiguousarray(prob, np.float32)
-        alias = _u32(alias)
-        ex.prob_table, ex.alias_table = prob.ctypes.data, alias.ctypes.data
+        ex.prob_table = prob.ctypes.data
+        if alias is not None:
+            alias = _u32(alias)
+            ex.alias_table = alias.ctypes.data
     ex.walk_length, ex.restart_prob, ex.num_walk = walk_length, restart_prob, num_walk
     h = lib().orc_do_sample_ex(C.c_int(sample_type), _p(indptr), _p(indices), _sz(indptr.size - 1),
                                _p(seeds), _sz(seeds.size), f, _sz(len(fanouts)), _p(states),

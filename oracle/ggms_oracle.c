@@ -595,7 +595,7 @@ static void stable_sort_kv32(kv32_t *a, size_t n) {
  * by src), :78-128 (adjacent-duplicate compaction), launch :156-164. */
 static void sample_with_replacement(const orc_id_t *indptr, const orc_id_t *indices,
                                     const float *prob_table, /* NULL: uniform (khop1) */
-                                    const orc_id_t *alias_table,
+                                    const orc_id_t *alias_table, /* NULL with prob_table: prefix sums */
                                     const orc_id_t *input, size_t num_input,
                                     size_t fanout, orc_xorwow_t *states,
                                     size_t num_states, orc_id_t *out_src,
@@ -621,12 +621,28 @@ static void sample_with_replacement(const orc_id_t *indptr, const orc_id_t *indi
         kv[task].key = ORC_EMPTY_KEY;
       } else {
         kv[task].key = rid;
-        size_t k = orc_xorwow_next(&st) % len;
-        if (prob_table) {
-          float r = orc_xorwow_uniform(&st);
-          kv[task].val = (r < prob_table[off + k]) ? indices[off + k] : alias_table[off + k];
+        if (prob_table && !alias_table) {
+          /* cuda_sampling_weighted_khop_prefix.cu:59-88: inverse-CDF draw over the per-list prefix sums */
+          const float upbound = prob_table[off + len - 1];
+          const float x = orc_xorwow_uniform(&st) * upbound;
+          if (x <= prob_table[off]) {
+            kv[task].val = indices[off];
+          } else {
+            size_t lo = off, hi = off + len - 1;
+            while (hi - lo >= 2) {
+              const size_t mid = (lo + hi) >> 1;
+              if (prob_table[mid] >= x) hi = mid; else lo = mid;
+            }
+            kv[task].val = indices[hi];
+          }
         } else {
-          kv[task].val = indices[off + k]; /* khop1.cu:65-67 */
+          size_t k = orc_xorwow_next(&st) % len;
+          if (prob_table) {
+            float r = orc_xorwow_uniform(&st);
+            kv[task].val = (r < prob_table[off + k]) ? indices[off + k] : alias_table[off + k];
+          } else {
+            kv[task].val = indices[off + k]; /* khop1.cu:65-67 */
+          }
         }
       }
     }
@@ -656,6 +672,85 @@ void orc_sample_weighted_khop(const orc_id_t *indptr, const orc_id_t *indices,
   assert(prob_table && alias_table);
   sample_with_replacement(indptr, indices, prob_table, alias_table, input, num_input, fanout, states, num_states,
                           out_src, out_dst, num_out);
+}
+
+/* cuda_sampling_weighted_khop_prefix.cu:41-91 (one curand_uniform per task, binary search in the list's
+ * prefix-sum table), then the same sort / adjacent-duplicate compaction :93-142,185-246. */
+void orc_sample_weighted_khop_prefix(const orc_id_t *indptr, const orc_id_t *indices,
+                                     const float *prob_prefix_table,
+                                     const orc_id_t *input, size_t num_input, size_t fanout,
+                                     orc_xorwow_t *states, size_t num_states,
+                                     orc_id_t *out_src, orc_id_t *out_dst, size_t *num_out) {
+  assert(prob_prefix_table);
+  sample_with_replacement(indptr, indices, prob_prefix_table, NULL, input, num_input, fanout, states, num_states,
+                          out_src, out_dst, num_out);
+}
+
+/* cuda_sampling_weighted_khop_hash_dedup.cu:41-57,59-117: thread t of block b owns state 256 b + t and seeds
+ * 1024 b + t + 256 r (the khop2 idiom).  A seed with more than `fanout` neighbours draws alias-method
+ * candidates (two draws each) until `fanout` DISTINCT ids are found; the per-thread 50-slot table keys its
+ * entries by round id = the seed's id, so it is never cleared (entries of an earlier seed with the same id
+ * would still count -- kept as is).  Note the strict `r > prob` here against `r < prob` in the plain sampler. */
+void orc_sample_weighted_khop_hash_dedup(const orc_id_t *indptr, const orc_id_t *indices,
+                                         const float *prob_table, const orc_id_t *alias_table,
+                                         const orc_id_t *input, size_t num_input, size_t fanout,
+                                         orc_xorwow_t *states, size_t num_states,
+                                         orc_id_t *out_src, orc_id_t *out_dst, size_t *num_out) {
+  const size_t BLOCK = 256, TILE = 1024, SLOTS = 50;
+  assert(fanout < SLOTS);
+  orc_id_t *tmp_src = (orc_id_t *)malloc(sizeof(orc_id_t) * (num_input * fanout + 1));
+  orc_id_t *tmp_dst = (orc_id_t *)malloc(sizeof(orc_id_t) * (num_input * fanout + 1));
+  const size_t num_blocks = (num_input + TILE - 1) / TILE;
+  for (size_t b = 0; b < num_blocks; ++b) {
+    for (size_t t = 0; t < BLOCK; ++t) {
+      const size_t i = b * BLOCK + t;
+      assert(i < num_states);
+      (void)num_states;
+      orc_xorwow_t st = states[i];
+      orc_id_t val[50], round_of[50];
+      for (size_t z = 0; z < SLOTS; ++z) { val[z] = ORC_EMPTY_KEY; round_of[z] = ORC_EMPTY_KEY; }
+      for (size_t index = TILE * b + t; index < TILE * (b + 1); index += BLOCK) {
+        if (index >= num_input) continue;
+        const orc_id_t rid = input[index];
+        const orc_id_t off = indptr[rid];
+        const orc_id_t len = indptr[rid + 1] - off;
+        orc_id_t *ts = tmp_src + index * fanout, *td = tmp_dst + index * fanout;
+        if (len <= fanout) {
+          size_t j = 0;
+          for (; j < len; ++j) { ts[j] = rid; td[j] = indices[off + j]; }
+          for (; j < fanout; ++j) { ts[j] = ORC_EMPTY_KEY; td[j] = ORC_EMPTY_KEY; }
+          continue;
+        }
+        size_t got = 0, tries = 0;
+        while (got < fanout) {
+          /* the reference spins forever on a list with fewer than `fanout` distinct candidates; after
+           * ORC_HASH_DEDUP_MAX_TRIES draws for one seed every candidate is taken (same rule in the HIP kernel) */
+          const int give_up = ++tries > ORC_HASH_DEDUP_MAX_TRIES;
+          const size_t k = orc_xorwow_next(&st) % len;
+          const float r = orc_xorwow_uniform(&st);
+          orc_id_t cand = indices[off + k];
+          if (r > prob_table[off + k]) cand = alias_table[off + k];
+          /* insert_hash_table, :41-57 */
+          size_t pos = cand % SLOTS, gap = 1;
+          int is_new = 1; /* bounded probing: the reference loops forever once the 50 slots are full */
+          for (size_t probe = 0; probe < ORC_HASH_DEDUP_MAX_PROBES; ++probe) {
+            if (round_of[pos] != rid) { round_of[pos] = rid; val[pos] = cand; break; }
+            if (val[pos] == cand) { is_new = 0; break; }
+            pos = (pos + gap) % SLOTS;
+            ++gap;
+          }
+          if (!is_new && !give_up) continue;
+          ts[got] = rid;
+          td[got] = cand;
+          ++got;
+        }
+      }
+      states[i] = st;
+    }
+  }
+  *num_out = compact_tmp(tmp_src, tmp_dst, num_input, fanout, out_src, out_dst);
+  free(tmp_src);
+  free(tmp_dst);
 }
 
 /* cuda_sampling_khop1.cu:42-72 (one curand % len per task, with replacement; grid-stride over
@@ -887,6 +982,14 @@ orc_sample_result_t *orc_do_sample_ex(int sample_type, const orc_id_t *indptr,
       case ORC_WEIGHTED_KHOP:
         orc_sample_weighted_khop(indptr, indices, extra->prob_table, extra->alias_table, cur, num_cur, fanout, states,
                                  num_states, out_src, out_dst, &num_out);
+        break;
+      case ORC_WEIGHTED_KHOP_PREFIX:
+        orc_sample_weighted_khop_prefix(indptr, indices, extra->prob_table, cur, num_cur, fanout, states, num_states,
+                                        out_src, out_dst, &num_out);
+        break;
+      case ORC_WEIGHTED_KHOP_HASH_DEDUP:
+        orc_sample_weighted_khop_hash_dedup(indptr, indices, extra->prob_table, extra->alias_table, cur, num_cur,
+                                            fanout, states, num_states, out_src, out_dst, &num_out);
         break;
       case ORC_RANDOM_WALK: /* fanout = num_neighbor = K (operation.cc:174) */
         out_data = (orc_id_t *)malloc(sizeof(orc_id_t) * (num_cur * fanout + 1));

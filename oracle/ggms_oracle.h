@@ -105,6 +105,20 @@ void orc_sample_khop3(const orc_id_t *indptr, const orc_id_t *indices,
                       const orc_id_t *input, size_t num_input, size_t fanout,
                       orc_xorwow_t *states, size_t num_states,
                       orc_id_t *out_src, orc_id_t *out_dst, size_t *num_out);
+/* cuda_sampling_weighted_khop_prefix.cu:41-246 (prob_prefix_table: inclusive prefix sums per neighbour list) */
+void orc_sample_weighted_khop_prefix(const orc_id_t *indptr, const orc_id_t *indices,
+                                     const float *prob_prefix_table,
+                                     const orc_id_t *input, size_t num_input, size_t fanout,
+                                     orc_xorwow_t *states, size_t num_states,
+                                     orc_id_t *out_src, orc_id_t *out_dst, size_t *num_out);
+/* cuda_sampling_weighted_khop_hash_dedup.cu:41-283 */
+#define ORC_HASH_DEDUP_MAX_TRIES 65536
+#define ORC_HASH_DEDUP_MAX_PROBES 64
+void orc_sample_weighted_khop_hash_dedup(const orc_id_t *indptr, const orc_id_t *indices,
+                                         const float *prob_table, const orc_id_t *alias_table,
+                                         const orc_id_t *input, size_t num_input, size_t fanout,
+                                         orc_xorwow_t *states, size_t num_states,
+                                         orc_id_t *out_src, orc_id_t *out_dst, size_t *num_out);
 /* cuda_sampling_khop1.cu:42-127,130-236 */
 void orc_sample_khop1(const orc_id_t *indptr, const orc_id_t *indices,
                       const orc_id_t *input, size_t num_input, size_t fanout,
@@ -160,7 +174,8 @@ void orc_ht_map_edges(const orc_hashtable_t *ht, const orc_id_t *src,
                       orc_id_t *new_dst);
 
 /* ---- multi-layer sample loop (dist_loops.cc:62-368, cpu_loops.cc:55-192) */
-enum { ORC_KHOP0 = 0, ORC_KHOP1 = 1, ORC_WEIGHTED_KHOP = 2, ORC_KHOP2 = 5, ORC_RANDOM_WALK = 3, ORC_KHOP3 = 7, ORC_CPU_KHOP0 = 100 };
+enum { ORC_KHOP0 = 0, ORC_KHOP1 = 1, ORC_WEIGHTED_KHOP = 2, ORC_WEIGHTED_KHOP_PREFIX = 4, ORC_KHOP2 = 5,
+       ORC_WEIGHTED_KHOP_HASH_DEDUP = 6, ORC_RANDOM_WALK = 3, ORC_KHOP3 = 7, ORC_CPU_KHOP0 = 100 };
 typedef struct {
   const float *prob_table;
   const orc_id_t *alias_table;

@@ -28,3 +28,14 @@ def exact_features(num_node, dim, dtype=np.float32):
     if np.dtype(dtype) == np.uint8:
         v = v & 0xFF
     return v.astype(dtype)
+
+
+def prefix_sums(indptr, weights):
+    """Per-neighbour-list inclusive prefix sums in float32 (the prob_prefix_table.bin layout)."""
+    import numpy as np
+    out = np.zeros(weights.size, np.float32)
+    for v in range(indptr.size - 1):
+        a, b = int(indptr[v]), int(indptr[v + 1])
+        if b > a:
+            out[a:b] = np.cumsum(weights[a:b], dtype=np.float32)
+    return out

@@ -69,7 +69,7 @@ def _oracle_batches(d, worker_id, num_worker, batch_size, num_epoch, fanouts, se
     nstates = max(oracle.predict_num_nodes(max_seeds, fanouts, len(fanouts) - 1),
                   (oracle.predict_num_nodes(max_seeds, fanouts, len(fanouts) - 1) + 127) // 128 * 8,
                   (oracle.predict_num_nodes(max_seeds, fanouts, len(fanouts) - 1) + 1023) // 1024 * 256)
-    if sample_type in ("weighted_khop", "khop1"):
+    if sample_type in ("weighted_khop", "khop1", "weighted_khop_prefix"):
         nstates = min(oracle.predict_num_nodes(max_seeds, fanouts, len(fanouts)), 512 * 1024)
     if sample_type == "random_walk":
         nstates = (oracle.predict_num_nodes(max_seeds, fanouts, len(fanouts) - 1) + 63) // 64 * 256
@@ -86,7 +86,9 @@ def _oracle_batches(d, worker_id, num_worker, batch_size, num_epoch, fanouts, se
             if arch6 and ep == 0 and st == 0:
                 size = min(int(size * 1.25), n_local - off)
             seeds = local[off:off + size]
-            code = {"khop3": oracle.KHOP3, "khop0": oracle.KHOP0, "khop2": oracle.KHOP2, "khop1": oracle.KHOP1, "weighted_khop": oracle.WEIGHTED_KHOP,
+            code = {"khop3": oracle.KHOP3, "khop0": oracle.KHOP0, "khop2": oracle.KHOP2, "khop1": oracle.KHOP1,
+                    "weighted_khop_prefix": oracle.WEIGHTED_KHOP_PREFIX,
+                    "weighted_khop_hash_dedup": oracle.WEIGHTED_KHOP_HASH_DEDUP, "weighted_khop": oracle.WEIGHTED_KHOP,
                     "random_walk": oracle.RANDOM_WALK}[sample_type]
             res = oracle.do_sample(code, d["ip"], d["ix"], seeds, fanouts, states, **kw)
             key = ep * n_global + worker_id * n_local_step + st
@@ -137,9 +139,14 @@ def test_arch1_weighted_and_random_walk(tmp_path):
     rng = np.random.RandomState(3)
     prob = rng.random_sample(d["ix"].size).astype(np.float32)
     alias = rng.randint(0, d["ip"].size - 1, d["ix"].size).astype(np.uint32)
+    from graphgen import prefix_sums
+    pre = prefix_sums(d["ip"], (rng.random_sample(d["ix"].size) + 0.01).astype(np.float32))
     prob.tofile(os.path.join(d["path"], "prob_table.bin"))
     alias.tofile(os.path.join(d["path"], "alias_table.bin"))
+    pre.tofile(os.path.join(d["path"], "prob_prefix_table.bin"))
     for stype, fan, kw in [("weighted_khop", [5, 4], dict(prob=prob, alias=alias)),
+                           ("weighted_khop_prefix", [5, 4], dict(prob=pre)),
+                           ("weighted_khop_hash_dedup", [5, 4], dict(prob=prob, alias=alias)),
                            ("random_walk", [5, 5, 5], dict(walk_length=3, restart_prob=0.5, num_walk=4))]:
         prefix = str(tmp_path / f"out_{stype}")
         r = subprocess.run([sys.executable, DRIVER, d["path"], prefix, "arch1", "1", f"sample_type={stype}", "seed=21",

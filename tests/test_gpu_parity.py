@@ -270,6 +270,63 @@ def test_sample_weighted_khop(ops, graphs, gname, n, fanout):
         np.testing.assert_array_equal(got_states[:, 1:], st_orc["v"])
 
 
+@pytest.mark.parametrize("gname,n,fanout", [("small", 1, 5), ("small", 300, 25), ("small", 0, 4), ("mid", 8000, 10),
+                                            ("mid", 30000, 25)])
+def test_sample_weighted_khop_prefix(ops, graphs, gname, n, fanout):
+    """Inverse-CDF draw over per-list prefix sums (weighted_khop_prefix.cu:41-91), f32 product + binary search."""
+    from graphgen import prefix_sums
+    ip, ix, g = graphs[gname]
+    N = ip.size - 1
+    rng = np.random.RandomState(n * 5 + fanout)
+    pre = prefix_sums(ip, (rng.random_sample(ix.size) + 0.01).astype(np.float32))
+    inp = rng.randint(0, N, n).astype(np.uint32)
+    nstates = max(256, min(n * fanout, 512 * 1024))
+    st_gpu = ops.random_states(nstates, 77)
+    st_orc = oracle.random_states(nstates, 77)
+    t_pre = dev(pre)
+    for rep in range(2):
+        src, dst, num = ops.sample_weighted_khop_prefix(
+            g, t_pre, dev(inp) if n else torch.zeros(0, dtype=torch.int32, device="cuda"), fanout, st_gpu)
+        wsrc, wdst = oracle.sample_weighted_khop_prefix(ip, ix, pre, inp, fanout, st_orc)
+        m = int(num.item())
+        assert m == wsrc.size
+        np.testing.assert_array_equal(host_u32(src, m), wsrc)
+        np.testing.assert_array_equal(host_u32(dst, m), wdst)
+        got_states = states_np(st_gpu)
+        np.testing.assert_array_equal(got_states[:, 0], st_orc["d"])
+        np.testing.assert_array_equal(got_states[:, 1:], st_orc["v"])
+
+
+@pytest.mark.parametrize("gname,n,fanout", [("small", 1, 5), ("small", 300, 25), ("small", 0, 4), ("small", 1025, 3),
+                                            ("mid", 8000, 10), ("mid", 5000, 49)])
+def test_sample_weighted_khop_hash_dedup(ops, graphs, gname, n, fanout):
+    """Alias-method candidates until `fanout` distinct ids per seed; per-thread 50-slot table keyed by seed id
+    (weighted_khop_hash_dedup.cu:41-117).  Repeated seeds included: a later copy sees the earlier copy's entries."""
+    ip, ix, g = graphs[gname]
+    N = ip.size - 1
+    rng = np.random.RandomState(n * 13 + fanout)
+    prob = rng.random_sample(ix.size).astype(np.float32)
+    alias = rng.randint(0, N, ix.size).astype(np.uint32)
+    inp = rng.randint(0, N, n).astype(np.uint32)
+    if n >= 600:  # one thread meets the same high-degree seed three times: its 50-slot table fills up
+        inp[[0, 256, 512]] = int(np.argmax(ip[1:] - ip[:-1]))
+    nstates = max(256, (n + 1023) // 1024 * 256)
+    st_gpu = ops.random_states(nstates, 99)
+    st_orc = oracle.random_states(nstates, 99)
+    t_prob, t_alias = dev(prob), dev(alias)
+    for rep in range(2):
+        src, dst, num = ops.sample_weighted_khop_hash_dedup(
+            g, t_prob, t_alias, dev(inp) if n else torch.zeros(0, dtype=torch.int32, device="cuda"), fanout, st_gpu)
+        wsrc, wdst = oracle.sample_weighted_khop_hash_dedup(ip, ix, prob, alias, inp, fanout, st_orc)
+        m = int(num.item())
+        assert m == wsrc.size
+        np.testing.assert_array_equal(host_u32(src, m), wsrc)
+        np.testing.assert_array_equal(host_u32(dst, m), wdst)
+        got_states = states_np(st_gpu)
+        np.testing.assert_array_equal(got_states[:, 0], st_orc["d"])
+        np.testing.assert_array_equal(got_states[:, 1:], st_orc["v"])
+
+
 @pytest.mark.parametrize("gname,n,wl,p,nw,K", [("small", 1, 3, 0.5, 4, 5), ("small", 300, 3, 0.5, 4, 5),
                                                ("small", 0, 3, 0.5, 4, 5), ("mid", 8000, 3, 0.5, 4, 5),
                                                ("mid", 5000, 4, 0.2, 5, 3), ("mid", 3000, 10, 0.1, 10, 20),

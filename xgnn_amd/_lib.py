@@ -49,6 +49,10 @@ SYMBOLS = {
     "ggms_sample_weighted_workspace_bytes": (_sz, [_sz, _sz]),
     "ggms_sample_weighted_khop": (_i, [C.POINTER(Graph), _vp, _vp, _vp, _sz, _sz, _vp, _vp, _vp, _vp, _sz, _vp, _sz,
                                        _vp]),
+    "ggms_sample_weighted_khop_prefix": (_i, [C.POINTER(Graph), _vp, _vp, _sz, _sz, _vp, _vp, _vp, _vp, _sz, _vp, _sz,
+                                              _vp]),
+    "ggms_sample_weighted_khop_hash_dedup": (_i, [C.POINTER(Graph), _vp, _vp, _vp, _sz, _sz, _vp, _vp, _vp, _vp, _sz,
+                                                  _vp, _sz, _vp]),
     "ggms_sample_random_walk_workspace_bytes": (_sz, [_sz, _sz, _sz, _sz]),
     "ggms_random_walk_num_states": (_sz, [_sz, _sz]),
     "ggms_sample_random_walk": (_i, [C.POINTER(Graph), _vp, _sz, _sz, C.c_double, _sz, _sz, _vp, _vp, _vp, _vp, _vp,

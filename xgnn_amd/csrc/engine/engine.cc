@@ -112,12 +112,10 @@ void Engine::Configure(const std::unordered_map<std::string, std::string> &kv_in
   if (kv.count("seed")) { cfg.has_seed = true; cfg.seed = std::stoull(kv["seed"]); }
   if (kv.count("hash_table")) cfg.direct_table = kv["hash_table"] != "hashed";
   if (kv.count("lookahead")) cfg.lookahead = std::stoull(kv["lookahead"]);
-  SAM_CHECK(cfg.sample_type == GGMS_KHOP3 || cfg.sample_type == GGMS_KHOP0 || cfg.sample_type == GGMS_KHOP1 ||
-                cfg.sample_type == GGMS_KHOP2 || cfg.sample_type == GGMS_WEIGHTED_KHOP ||
-                cfg.sample_type == GGMS_RANDOM_WALK,
-            "sample types built: khop0, khop1, khop2, khop3, weighted_khop, random_walk (DESIGN.md)");
-  if (cfg.sample_type == GGMS_WEIGHTED_KHOP || cfg.sample_type == GGMS_KHOP2 ||
-      cfg.sample_type == GGMS_KHOP1) // dist_loops.cc:167-168,171-172,219-220
+  SAM_CHECK(cfg.sample_type >= GGMS_KHOP0 && cfg.sample_type <= GGMS_KHOP3, "unknown sample type");
+  if (cfg.sample_type == GGMS_WEIGHTED_KHOP || cfg.sample_type == GGMS_KHOP2 || cfg.sample_type == GGMS_KHOP1 ||
+      cfg.sample_type == GGMS_WEIGHTED_KHOP_PREFIX ||
+      cfg.sample_type == GGMS_WEIGHTED_KHOP_HASH_DEDUP) // dist_loops.cc:167-168,171-172,209-210,219-220,227-228
     SAM_CHECK(!cfg.use_dist_graph, "this algorithm not support DistGraph engine");
   cfg.configured = true;
 }
@@ -201,10 +199,12 @@ void Engine::LoadDataset() {
   ds.train_set = MapFile("train_set.bin", ds.num_train * 4, false);
   ds.test_set = MapFile("test_set.bin", ds.num_test * 4, false);
   ds.valid_set = MapFile("valid_set.bin", ds.num_valid * 4, false);
-  if (cfg.sample_type == GGMS_WEIGHTED_KHOP) { // engine.cc:372-384
+  if (cfg.sample_type == GGMS_WEIGHTED_KHOP || cfg.sample_type == GGMS_WEIGHTED_KHOP_HASH_DEDUP) { // engine.cc:372-384
     ds.prob_table = MapFile("prob_table.bin", ds.num_edge * 4, false);
     ds.alias_table = MapFile("alias_table.bin", ds.num_edge * 4, false);
   }
+  if (cfg.sample_type == GGMS_WEIGHTED_KHOP_PREFIX) // :373-378; the kernels see it through extra_.prob_table
+    ds.prob_table = MapFile("prob_prefix_table.bin", ds.num_edge * 4, false);
   if (cfg.UseGPUCache()) { // engine.cc:395-440
     static const char *rank_files[] = {"cache_by_degree.bin", "cache_by_heuristic.bin", nullptr, "cache_by_degree_hop.bin",
                                        nullptr, "cache_by_fake_optimal.bin", nullptr, "cache_by_random.bin"};
@@ -405,11 +405,15 @@ void Engine::SampleInit(int worker_id, const std::string &ctx) {
   SAM_HIP(hipMalloc((void **)&ht_.num_items_dev, 16));
   SAM_GGMS(ggms_hashtable_init(&ht_, stream_));
   std::memset(&extra_, 0, sizeof(extra_));
-  if (cfg.sample_type == GGMS_WEIGHTED_KHOP) { // dist_engine.cc:210-213
+  if (cfg.sample_type == GGMS_WEIGHTED_KHOP || cfg.sample_type == GGMS_WEIGHTED_KHOP_HASH_DEDUP) { // dist_engine.cc:210-213
     d_prob_ = dev_upload(ds.prob_table.ptr, ds.prob_table.bytes, stream_);
     d_alias_ = dev_upload(ds.alias_table.ptr, ds.alias_table.bytes, stream_);
     extra_.prob_table = (const float *)d_prob_;
     extra_.alias_table = (const ggms_id_t *)d_alias_;
+  }
+  if (cfg.sample_type == GGMS_WEIGHTED_KHOP_PREFIX) {
+    d_prob_ = dev_upload(ds.prob_table.ptr, ds.prob_table.bytes, stream_);
+    extra_.prob_table = (const float *)d_prob_;
   }
   extra_.random_walk_length = cfg.random_walk_length;
   extra_.random_walk_restart_prob = cfg.random_walk_restart_prob;

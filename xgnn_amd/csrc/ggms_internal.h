@@ -4,6 +4,17 @@
 
 namespace ggms {
 
+// What goes into out_src: the seed's global id (leaf API, like the reference) or
+// its local id (fused batch path: the COO `col` is written by the sampler itself).
+struct SrcMode {
+  const uint32_t *seed_local; // local id per seed position; NULL = the position itself
+  int local;
+  __device__ __forceinline__ uint32_t value(uint32_t rid, uint64_t index) const {
+    if (!local) return rid;
+    return seed_local ? seed_local[index] : (uint32_t)index;
+  }
+};
+
 // sample_khop.hip
 size_t sample_ws_words(size_t num_input);
 int sample_khop3_impl(GraphView g, const uint32_t *input, size_t n_max, Count n, uint32_t fanout, uint32_t *out_src,
@@ -30,6 +41,12 @@ int sample_random_walk_impl(GraphView g, const uint32_t *input, size_t n_max, Co
                             double restart_prob, uint32_t num_walk, uint32_t K, uint32_t *out_src, uint32_t *out_dst,
                             uint32_t *out_data, uint64_t *num_out_dev, uint32_t *states, uint32_t *workspace,
                             const uint32_t *seed_local, int src_local, hipStream_t s, ScanArea *shared_scan = nullptr);
+
+int sample_weighted_hash_dedup_impl(const uint32_t *indptr, const uint32_t *indices, const float *prob,
+                                    const uint32_t *alias, const uint32_t *input, size_t n_max, Count n,
+                                    uint32_t fanout, uint32_t *out_src, uint32_t *out_dst, uint64_t *num_out_dev,
+                                    uint32_t *states, uint32_t *workspace, const uint32_t *seed_local, int src_local,
+                                    hipStream_t s, ScanArea *shared_scan = nullptr);
 
 // hashtable.hip
 size_t ht_ws_words(size_t num_input);

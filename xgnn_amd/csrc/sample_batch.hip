@@ -95,7 +95,7 @@ static size_t sampler_ws_words(int sample_type, const BatchCaps &c, const size_t
                                const ggms_sample_extra_t *extra) {
   size_t w = sample_ws_words(c.max_in_all);
   for (uint32_t i = 0; i < L; ++i) {
-    if (sample_type == GGMS_WEIGHTED_KHOP || sample_type == GGMS_KHOP1)
+    if (sample_type == GGMS_WEIGHTED_KHOP || sample_type == GGMS_KHOP1 || sample_type == GGMS_WEIGHTED_KHOP_PREFIX)
       w = std::max(w, weighted_ws_words(c.max_input[i], fanouts[i]));
     if (sample_type == GGMS_RANDOM_WALK && extra)
       w = std::max(w, random_walk_ws_words(c.max_input[i], extra->random_walk_length, extra->num_random_walk, fanouts[i]));
@@ -122,14 +122,20 @@ int ggms_sample_batch(int sample_type, const ggms_graph_t *graph, const ggms_id_
                       ggms_stream_t stream) {
   GGMS_CHECK_ARG(graph && fanouts && ht && row && col && counts_dev);
   GGMS_CHECK_ARG(num_layer >= 1 && num_layer <= 16);
-  GGMS_CHECK_ARG(sample_type == GGMS_KHOP3 || sample_type == GGMS_KHOP0 || sample_type == GGMS_KHOP1 ||
-                 sample_type == GGMS_KHOP2 || sample_type == GGMS_WEIGHTED_KHOP || sample_type == GGMS_RANDOM_WALK);
+  GGMS_CHECK_ARG(sample_type >= GGMS_KHOP0 && sample_type <= GGMS_KHOP3);
   GGMS_CHECK_ARG(num_seeds == 0 || seeds);
   GGMS_CHECK_ARG(workspace && workspace_bytes >= ggms_sample_batch_workspace_bytes(sample_type, num_seeds, fanouts,
                                                                                    num_layer, extra));
   if (sample_type == GGMS_WEIGHTED_KHOP)
     GGMS_CHECK_ARG(extra && extra->prob_table && extra->alias_table && graph->num_part == 0 && states);
   if (sample_type == GGMS_KHOP1) GGMS_CHECK_ARG(graph->num_part == 0 && graph->indptr && graph->indices && states);
+  if (sample_type == GGMS_WEIGHTED_KHOP_PREFIX)
+    GGMS_CHECK_ARG(extra && extra->prob_table && graph->num_part == 0 && states);
+  if (sample_type == GGMS_WEIGHTED_KHOP_HASH_DEDUP) {
+    GGMS_CHECK_ARG(extra && extra->prob_table && extra->alias_table && graph->num_part == 0);
+    GGMS_CHECK_ARG(states != nullptr);
+    for (uint32_t i = 0; i < num_layer; ++i) GGMS_CHECK_ARG(fanouts[i] > 0 && fanouts[i] < 50);
+  }
   if (sample_type == GGMS_RANDOM_WALK)
     GGMS_CHECK_ARG(extra && extra->data && extra->random_walk_length > 0 && extra->num_random_walk > 0 && states &&
                    extra->random_walk_length * extra->num_random_walk <= 128);
@@ -137,6 +143,7 @@ int ggms_sample_batch(int sample_type, const ggms_graph_t *graph, const ggms_id_
   const BatchCaps c = caps_of(num_seeds, fanouts, num_layer);
   GGMS_CHECK_ARG(c.max_input[0] + c.max_edges[0] <= ht->n2o_size);
   GGMS_CHECK_ARG(c.max_input[0] + c.max_edges[0] < (1ull << 32));
+  if (sample_type == GGMS_WEIGHTED_KHOP_HASH_DEDUP) GGMS_CHECK_ARG((c.max_in_all + 1023) / 1024 * 256 <= num_states);
   if (sample_type == GGMS_KHOP2) { // unsharded CSR, mutated in place (dist_loops.cc:217-224)
     GGMS_CHECK_ARG(graph->num_part == 0 && graph->indptr && graph->indices);
     GGMS_CHECK_ARG(states && (c.max_in_all + 1023) / 1024 * 256 <= num_states);
@@ -205,6 +212,14 @@ int ggms_sample_batch(int sample_type, const ggms_graph_t *graph, const ggms_id_
       rc = sample_weighted_impl(graph->indptr, graph->indices, nullptr, nullptr, input, n_max, n,
                                 (uint32_t)fanouts[i], col[i], tmp_dst, num_edge, (uint32_t *)states, samp_ws,
                                 first ? seed_local : nullptr, 1, s);
+    } else if (sample_type == GGMS_WEIGHTED_KHOP_PREFIX) {
+      rc = sample_weighted_impl(graph->indptr, graph->indices, extra->prob_table, nullptr, input, n_max, n,
+                                (uint32_t)fanouts[i], col[i], tmp_dst, num_edge, (uint32_t *)states, samp_ws,
+                                first ? seed_local : nullptr, 1, s);
+    } else if (sample_type == GGMS_WEIGHTED_KHOP_HASH_DEDUP) {
+      rc = sample_weighted_hash_dedup_impl(graph->indptr, graph->indices, extra->prob_table, extra->alias_table, input,
+                                           n_max, n, (uint32_t)fanouts[i], col[i], tmp_dst, num_edge,
+                                           (uint32_t *)states, samp_ws, first ? seed_local : nullptr, 1, s, &scan);
     } else if (sample_type == GGMS_WEIGHTED_KHOP) {
       rc = sample_weighted_impl(graph->indptr, graph->indices, extra->prob_table, extra->alias_table, input, n_max, n,
                                 (uint32_t)fanouts[i], col[i], tmp_dst, num_edge, (uint32_t *)states, samp_ws,

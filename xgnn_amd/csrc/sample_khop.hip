@@ -42,17 +42,6 @@ struct StoreOffset {
   __device__ __forceinline__ void operator()(uint64_t i, uint32_t, uint32_t excl) const { offset[i] = excl; }
 };
 
-// What goes into out_src: the seed's global id (leaf API, like the reference) or
-// its local id (fused batch path: the COO `col` is written by the sampler itself).
-struct SrcMode {
-  const uint32_t *seed_local; // local id per seed position; NULL = the position itself
-  int local;
-  __device__ __forceinline__ uint32_t value(uint32_t rid, uint64_t index) const {
-    if (!local) return rid;
-    return seed_local ? seed_local[index] : (uint32_t)index;
-  }
-};
-
 // ---- khop3 -------------------------------------------------------------------
 // Group (b, y) of the reference grid == stream id i = 8 b + y; it serves seeds
 // 128 b + y + 8 k, k = 0..15, in that order (khop3.cu:86-89,106).

@@ -1,4 +1,5 @@
-// sample_weighted.hip -- with-replacement fan-out samplers: weighted (alias method) and uniform (khop1).
+// sample_weighted.hip -- weighted fan-out samplers (alias method, prefix sums, alias + per-seed dedup)
+// and the uniform with-replacement sampler (khop1).
 //
 // Reference: GPUSampleWeightedKHop, cuda/cuda_sampling_weighted_khop.cu:132-238:
 //   sample_weighted_khop :41-76   task t -> seed t / fanout; k = curand % deg; r = curand_uniform;
@@ -8,6 +9,12 @@
 //
 // GPUSampleKHop1, cuda/cuda_sampling_khop1.cu:130-236, is the same pipeline with one draw per task
 // (dst = indices[off + curand % deg], :65-67) and kKHop1MaxThreads = 512 K (constant.h:71): k_weighted_draw<false>.
+//
+// GPUSampleWeightedKHopPrefix, cuda/cuda_sampling_weighted_khop_prefix.cu:145-246, again the same pipeline; the
+// draw is one curand_uniform scaled by the list's total weight and a binary search in its prefix sums (:59-88):
+// k_weighted_draw<2>.
+// GPUSampleWeightedKHopHashDedup, cuda/cuda_sampling_weighted_khop_hash_dedup.cu:196-283, is a different
+// animal -- the khop2 thread<->stream map, rejection until `fanout` distinct ids: k_weighted_hash_dedup below.
 //
 // Kept bit-for-bit: task -> thread -> RNG stream assignment (span = ceil(min(tasks, 512K) / 256) * 256),
 // two draws per task, the stable order by src, the adjacent-duplicate rule (dedup is partial by design).
@@ -22,7 +29,23 @@ namespace ggms {
 
 constexpr uint64_t kWeightedMaxThreads = 512 * 1024; // Constant::kWeightedKHopMaxThreads, constant.h:72
 
-template <bool WEIGHTED>
+// per-seed edge count min(deg, fanout) and its scanned offset (hash-dedup sampler: compact COO written directly)
+struct MinDegFanout {
+  const uint32_t *indptr, *input;
+  uint32_t fanout;
+  __device__ __forceinline__ uint32_t operator()(uint64_t i) const {
+    const uint32_t rid = input[i];
+    const uint32_t len = indptr[rid + 1] - indptr[rid];
+    return len < fanout ? len : fanout;
+  }
+};
+struct StoreWord {
+  uint32_t *out;
+  __device__ __forceinline__ void operator()(uint64_t i, uint32_t, uint32_t excl) const { out[i] = excl; }
+};
+
+// MODE 0: uniform (khop1), 1: alias method, 2: prefix sums (`prob` = inclusive prefix sums per list)
+template <int MODE>
 __global__ __launch_bounds__(kBlock) void k_weighted_draw(const uint32_t *__restrict__ indptr,
                                                           const uint32_t *__restrict__ indices,
                                                           const float *__restrict__ prob,
@@ -42,9 +65,22 @@ __global__ __launch_bounds__(kBlock) void k_weighted_draw(const uint32_t *__rest
     const uint32_t rid = input[task / fanout];
     const uint32_t off = indptr[rid];
     const uint32_t len = indptr[rid + 1] - off;
-    if (len != 0) {
+    if (len == 0) continue;
+    if (MODE == 2) {
+      const float x = st.uniform() * prob[off + len - 1]; // prefix.cu:59,66
+      if (x <= prob[off]) {
+        tmp_dst[task] = indices[off];
+      } else {
+        uint32_t lo = off, hi = off + len - 1;
+        while (hi - lo >= 2) {
+          const uint32_t mid = (uint32_t)(((uint64_t)lo + hi) >> 1);
+          if (prob[mid] >= x) hi = mid; else lo = mid;
+        }
+        tmp_dst[task] = indices[hi];
+      }
+    } else {
       const uint32_t k = st.next() % len;
-      if (WEIGHTED) {
+      if (MODE == 1) {
         const float r = st.uniform();
         tmp_dst[task] = (r < prob[off + k]) ? indices[off + k] : alias[off + k];
       } else {
@@ -125,12 +161,16 @@ int sample_weighted_impl(const uint32_t *indptr, const uint32_t *indices, const 
   uint32_t *scan_scr = w;
   const size_t task_max = n_max * fanout;
   const size_t threads = task_max < kWeightedMaxThreads ? task_max : (size_t)kWeightedMaxThreads;
-  if (prob)
-    hipLaunchKernelGGL(k_weighted_draw<true>, dim3((unsigned)((threads + kBlock - 1) / kBlock)), dim3(kBlock), 0, s,
-                       indptr, indices, prob, alias, input, n, fanout, tmp_dst, states);
+  const dim3 draw_grid((unsigned)((threads + kBlock - 1) / kBlock));
+  if (prob && alias)
+    hipLaunchKernelGGL(k_weighted_draw<1>, draw_grid, dim3(kBlock), 0, s, indptr, indices, prob, alias, input, n, fanout,
+                       tmp_dst, states);
+  else if (prob) // prefix sums
+    hipLaunchKernelGGL(k_weighted_draw<2>, draw_grid, dim3(kBlock), 0, s, indptr, indices, prob, alias, input, n, fanout,
+                       tmp_dst, states);
   else // khop1: uniform with replacement
-    hipLaunchKernelGGL(k_weighted_draw<false>, dim3((unsigned)((threads + kBlock - 1) / kBlock)), dim3(kBlock), 0, s,
-                       indptr, indices, prob, alias, input, n, fanout, tmp_dst, states);
+    hipLaunchKernelGGL(k_weighted_draw<0>, draw_grid, dim3(kBlock), 0, s, indptr, indices, prob, alias, input, n, fanout,
+                       tmp_dst, states);
   GGMS_LAUNCH_CHECK();
   hipLaunchKernelGGL(k_weighted_keys, dim3(grid_for(n_max, kBlock)), dim3(kBlock), 0, s, indptr, input, n, k0, v0);
   GGMS_LAUNCH_CHECK();
@@ -142,6 +182,91 @@ int sample_weighted_impl(const uint32_t *indptr, const uint32_t *indices, const 
   const ScanArea sa = shared_scan ? *shared_scan : ScanArea{scan_scr, false};
   return tile_scan(KeepFlag{ss}, KeepEmit{ss, out_src, out_dst, seed_local, src_local}, task_max,
                    count_of(task_max), sa, nullptr, nullptr, num_out_dev, s);
+}
+
+// ---- weighted_khop_hash_dedup --------------------------------------------------------------------------
+// Thread t of block b owns stream 256 b + t and seeds 1024 b + t + 256 r (hash_dedup.cu:69-80).  The
+// reference keeps the per-thread 50-slot table {value, round id} in local memory; here it sits in LDS,
+// slot-major ([slot][thread]: a wave's accesses to one slot are 64 consecutive words, conflict-free), and is
+// keyed by round id = the seed's id exactly as there, so it is initialised once per thread.
+constexpr uint32_t kDedupSlots = 50;       // hash_dedup.cu:42
+constexpr uint32_t kDedupMaxTries = 65536; // the reference spins forever on a list without `fanout` distinct ids
+constexpr uint32_t kDedupMaxProbes = 64;   // ... and on a full table (a seed id met twice by one thread, fanout >= 25)
+
+__global__ __launch_bounds__(kBlock) void k_weighted_hash_dedup(const uint32_t *__restrict__ indptr,
+                                                                const uint32_t *__restrict__ indices,
+                                                                const float *__restrict__ prob,
+                                                                const uint32_t *__restrict__ alias,
+                                                                const uint32_t *__restrict__ input, Count n_arg,
+                                                                uint32_t fanout, const uint32_t *__restrict__ offset,
+                                                                uint32_t *__restrict__ out_src,
+                                                                uint32_t *__restrict__ out_dst,
+                                                                uint32_t *__restrict__ states, SrcMode sm) {
+  __shared__ uint32_t val[kDedupSlots][kBlock], round_of[kDedupSlots][kBlock];
+  const uint64_t n = n_arg.get();
+  const uint32_t t = threadIdx.x;
+  const uint64_t num_tiles = (n + 1023) / 1024;
+  for (uint64_t b = blockIdx.x; b < num_tiles; b += gridDim.x) {
+    for (uint32_t z = 0; z < kDedupSlots; ++z) { val[z][t] = kEmptyKey; round_of[z][t] = kEmptyKey; } // :72-76
+    const uint64_t sid = b * kBlock + t;
+    Xorwow st;
+    st.load(states + 6 * sid);
+    bool drew = false;
+    for (uint32_t r = 0; r < 4; ++r) {
+      const uint64_t index = b * 1024 + t + (uint64_t)r * kBlock;
+      if (index >= n) break;
+      const uint32_t rid = input[index];
+      const uint32_t off = indptr[rid], len = indptr[rid + 1] - off;
+      const uint32_t o = offset[index];
+      const uint32_t sv = sm.value(rid, index);
+      if (len <= fanout) {
+        for (uint32_t j = 0; j < len; ++j) {
+          out_src[o + j] = sv;
+          out_dst[o + j] = indices[off + j];
+        }
+        continue;
+      }
+      drew = true;
+      uint32_t got = 0, tries = 0;
+      while (got < fanout) {
+        const bool give_up = ++tries > kDedupMaxTries;
+        const uint32_t k = st.next() % len;
+        const float u = st.uniform();
+        uint32_t cand = indices[off + k];
+        if (u > prob[off + k]) cand = alias[off + k]; // strict >, :101-103
+        uint32_t pos = cand % kDedupSlots, gap = 1;   // insert_hash_table, :41-57
+        bool is_new = true; // a probe sequence that finds neither a free slot nor the value takes the candidate
+        for (uint32_t probe = 0; probe < kDedupMaxProbes; ++probe) {
+          if (round_of[pos][t] != rid) { round_of[pos][t] = rid; val[pos][t] = cand; break; }
+          if (val[pos][t] == cand) { is_new = false; break; }
+          pos = (pos + gap) % kDedupSlots;
+          ++gap;
+        }
+        if (!is_new && !give_up) continue;
+        out_src[o + got] = sv;
+        out_dst[o + got] = cand;
+        ++got;
+      }
+    }
+    if (drew) st.store(states + 6 * sid);
+  }
+}
+
+int sample_weighted_hash_dedup_impl(const uint32_t *indptr, const uint32_t *indices, const float *prob,
+                                    const uint32_t *alias, const uint32_t *input, size_t n_max, Count n,
+                                    uint32_t fanout, uint32_t *out_src, uint32_t *out_dst, uint64_t *num_out_dev,
+                                    uint32_t *states, uint32_t *workspace, const uint32_t *seed_local, int src_local,
+                                    hipStream_t s, ScanArea *shared_scan) {
+  uint32_t *offset = workspace;
+  const ScanArea sa = shared_scan ? *shared_scan : ScanArea{offset + n_max, false};
+  int rc = tile_scan(MinDegFanout{indptr, input, fanout}, StoreWord{offset}, n_max, n, sa, nullptr, nullptr,
+                     num_out_dev, s);
+  if (rc != GGMS_OK) return rc;
+  hipLaunchKernelGGL(k_weighted_hash_dedup, dim3(grid_for((n_max + 1023) / 1024, 1)), dim3(kBlock), 0, s, indptr,
+                     indices, prob, alias, input, n, fanout, offset, out_src, out_dst, states,
+                     SrcMode{seed_local, src_local});
+  GGMS_LAUNCH_CHECK();
+  return GGMS_OK;
 }
 
 } // namespace ggms
@@ -197,6 +322,50 @@ int ggms_sample_khop1(const ggms_graph_t *graph, const ggms_id_t *input, size_t 
   return sample_weighted_impl(graph->indptr, graph->indices, nullptr, nullptr, input, num_input, count_of(num_input),
                               (uint32_t)fanout, out_src, out_dst, num_out_dev, (uint32_t *)states,
                               (uint32_t *)workspace, nullptr, 0, s);
+}
+
+int ggms_sample_weighted_khop_prefix(const ggms_graph_t *graph, const float *prob_prefix_table, const ggms_id_t *input,
+                                     size_t num_input, size_t fanout, ggms_id_t *out_src, ggms_id_t *out_dst,
+                                     uint64_t *num_out_dev, void *states, size_t num_states, void *workspace,
+                                     size_t workspace_bytes, ggms_stream_t stream) {
+  GGMS_CHECK_ARG(graph && num_out_dev && fanout > 0);
+  GGMS_CHECK_ARG(graph->num_part == 0); // "this algorithm not support DistGraph engine", dist_loops.cc:209-210
+  hipStream_t s = to_stream(stream);
+  if (num_input == 0) {
+    GGMS_HIP(hipMemsetAsync(num_out_dev, 0, sizeof(uint64_t), s));
+    return GGMS_OK;
+  }
+  GGMS_CHECK_ARG(prob_prefix_table && input && out_src && out_dst && states && workspace);
+  GGMS_CHECK_ARG((uint64_t)num_input * fanout < (1ull << 32));
+  GGMS_CHECK_ARG(workspace_bytes >= ggms_sample_weighted_workspace_bytes(num_input, fanout));
+  const uint64_t tasks = (uint64_t)num_input * fanout;
+  const uint64_t threads = tasks < kWeightedMaxThreads ? tasks : kWeightedMaxThreads;
+  const uint64_t span = (threads + 255) / 256 * 256;
+  GGMS_CHECK_ARG((span < tasks ? span : tasks) <= num_states); // prefix.cu:50
+  return sample_weighted_impl(graph->indptr, graph->indices, prob_prefix_table, nullptr, input, num_input,
+                              count_of(num_input), (uint32_t)fanout, out_src, out_dst, num_out_dev, (uint32_t *)states,
+                              (uint32_t *)workspace, nullptr, 0, s);
+}
+
+int ggms_sample_weighted_khop_hash_dedup(const ggms_graph_t *graph, const float *prob_table,
+                                         const ggms_id_t *alias_table, const ggms_id_t *input, size_t num_input,
+                                         size_t fanout, ggms_id_t *out_src, ggms_id_t *out_dst, uint64_t *num_out_dev,
+                                         void *states, size_t num_states, void *workspace, size_t workspace_bytes,
+                                         ggms_stream_t stream) {
+  GGMS_CHECK_ARG(graph && num_out_dev && fanout > 0 && fanout < kDedupSlots);
+  GGMS_CHECK_ARG(graph->num_part == 0); // dist_loops.cc:227-228
+  hipStream_t s = to_stream(stream);
+  if (num_input == 0) {
+    GGMS_HIP(hipMemsetAsync(num_out_dev, 0, sizeof(uint64_t), s));
+    return GGMS_OK;
+  }
+  GGMS_CHECK_ARG(prob_table && alias_table && input && out_src && out_dst && states && workspace);
+  GGMS_CHECK_ARG((uint64_t)num_input * fanout < (1ull << 32));
+  GGMS_CHECK_ARG(workspace_bytes >= ggms_sample_workspace_bytes(GGMS_WEIGHTED_KHOP_HASH_DEDUP, num_input, fanout));
+  GGMS_CHECK_ARG((num_input + 1023) / 1024 * 256 <= num_states); // assert(i < num_random_states), hash_dedup.cu:70
+  return sample_weighted_hash_dedup_impl(graph->indptr, graph->indices, prob_table, alias_table, input, num_input,
+                                         count_of(num_input), (uint32_t)fanout, out_src, out_dst, num_out_dev,
+                                         (uint32_t *)states, (uint32_t *)workspace, nullptr, 0, s);
 }
 
 } // extern "C"

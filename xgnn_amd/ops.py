@@ -112,6 +112,40 @@ def sample_khop0(graph, inp, fanout):
     return _sample("ggms_sample_khop0", KHOP0, graph, inp, fanout, None)
 
 
+def sample_weighted_khop_prefix(graph, prob_prefix_table, inp, fanout, states):
+    """GPUSampleWeightedKHopPrefix (cuda_sampling_weighted_khop_prefix.cu:145-246)."""
+    _require_gpu(inp)
+    _i32(inp)
+    n = inp.numel()
+    dev = inp.device
+    out_src = torch.empty(max(1, n * fanout), dtype=torch.int32, device=dev)
+    out_dst = torch.empty(max(1, n * fanout), dtype=torch.int32, device=dev)
+    num_out = torch.zeros(1, dtype=torch.int64, device=dev)
+    ws = _workspace(lib().ggms_sample_weighted_workspace_bytes(n, fanout), dev)
+    check(lib().ggms_sample_weighted_khop_prefix(C.byref(graph.c), _ptr(prob_prefix_table), _ptr(inp), n, fanout,
+                                                 _ptr(out_src), _ptr(out_dst), _ptr(num_out), _ptr(states),
+                                                 states.shape[0], _ptr(ws), ws.numel() * 4, _stream()),
+          "ggms_sample_weighted_khop_prefix")
+    return out_src, out_dst, num_out
+
+
+def sample_weighted_khop_hash_dedup(graph, prob_table, alias_table, inp, fanout, states):
+    """GPUSampleWeightedKHopHashDedup (cuda_sampling_weighted_khop_hash_dedup.cu:196-283)."""
+    _require_gpu(inp)
+    _i32(inp)
+    n = inp.numel()
+    dev = inp.device
+    out_src = torch.empty(max(1, n * fanout), dtype=torch.int32, device=dev)
+    out_dst = torch.empty(max(1, n * fanout), dtype=torch.int32, device=dev)
+    num_out = torch.zeros(1, dtype=torch.int64, device=dev)
+    ws = _workspace(lib().ggms_sample_workspace_bytes(WEIGHTED_KHOP_HASH_DEDUP, n, fanout), dev)
+    check(lib().ggms_sample_weighted_khop_hash_dedup(C.byref(graph.c), _ptr(prob_table), _ptr(alias_table), _ptr(inp),
+                                                     n, fanout, _ptr(out_src), _ptr(out_dst), _ptr(num_out),
+                                                     _ptr(states), states.shape[0], _ptr(ws), ws.numel() * 4,
+                                                     _stream()), "ggms_sample_weighted_khop_hash_dedup")
+    return out_src, out_dst, num_out
+
+
 def sample_khop1(graph, inp, fanout, states):
     """GPUSampleKHop1 (cuda_sampling_khop1.cu:130-236): uniform with replacement, adjacent duplicates dropped."""
     _require_gpu(inp)
