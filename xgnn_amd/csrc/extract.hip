@@ -102,12 +102,12 @@ __device__ __forceinline__ void store_chunk(uint64_t addr, V v) {
   else *(gp_t)addr = v;
 }
 
-template <int CB, typename Rows, bool IDENT_DST, bool NT, bool NTS>
+// U = independent chunk loads in flight per lane (8 x 16 B; 16 at narrower chunks so that it stays 128 B)
+template <int CB, typename Rows, bool IDENT_DST, bool NT, bool NTS, int U = 8>
 __global__ __launch_bounds__(kBlock) void k_gather_rows(char *__restrict__ out, Rows rows,
                                                         const uint32_t *__restrict__ dst_index, Count n_arg,
                                                         uint32_t rc, uint32_t magic, uint64_t *miss_count) {
   using V = typename ChunkT<CB>::type;
-  constexpr int U = 8;
   const uint64_t n = n_arg.get();
   const uint32_t lane = lane_id();
   const uint64_t wave = ((uint64_t)blockIdx.x * kBlock + threadIdx.x) >> 6;
@@ -209,14 +209,18 @@ static int launch_gather(char *out, Rows rows, const uint32_t *dst_index, size_t
   static const int max_blocks = [] { const char *e = getenv("GGMS_EXTRACT_BLOCKS"); int v = e ? atoi(e) : 256; return v > 0 ? v : 256; }();
   int grid = grid_for(n_max, kBlock);
   if (grid > max_blocks) grid = max_blocks;
-#define GGMS_LAUNCH(CB, ID, NT)                                                                         \
-  do {                                                                                                   \
-    if (env_nts)                                                                                         \
-      hipLaunchKernelGGL((k_gather_rows<CB, Rows, ID, NT, true>), dim3(grid), dim3(kBlock), 0, stream, out, \
-                         rows, dst_index, n, (uint32_t)rc, magic, miss_count);                           \
-    else                                                                                                 \
-      hipLaunchKernelGGL((k_gather_rows<CB, Rows, ID, NT, false>), dim3(grid), dim3(kBlock), 0, stream, out, \
-                         rows, dst_index, n, (uint32_t)rc, magic, miss_count);                           \
+  // narrow chunks (rows that are not a multiple of 16 B) with enough chunks per row: twice the loads in flight
+  const bool deep = cb < 16 && rc >= 8;
+#define GGMS_LAUNCH_U(CB, ID, NT, NTS, UU)                                                                    \
+  hipLaunchKernelGGL((k_gather_rows<CB, Rows, ID, NT, NTS, UU>), dim3(grid), dim3(kBlock), 0, stream, out, rows, \
+                     dst_index, n, (uint32_t)rc, magic, miss_count)
+#define GGMS_LAUNCH(CB, ID, NT)                                                          \
+  do {                                                                                    \
+    if (CB < 16 && deep) {                                                                \
+      if (env_nts) GGMS_LAUNCH_U(CB, ID, NT, true, 16); else GGMS_LAUNCH_U(CB, ID, NT, false, 16); \
+    } else {                                                                              \
+      if (env_nts) GGMS_LAUNCH_U(CB, ID, NT, true, 8); else GGMS_LAUNCH_U(CB, ID, NT, false, 8);   \
+    }                                                                                     \
   } while (0)
 #define GGMS_CASE(CB)                                                \
   case CB:                                                           \
@@ -235,6 +239,7 @@ static int launch_gather(char *out, Rows rows, const uint32_t *dst_index, size_t
   }
 #undef GGMS_CASE
 #undef GGMS_LAUNCH
+#undef GGMS_LAUNCH_U
   GGMS_LAUNCH_CHECK();
   return GGMS_OK;
 }
