@@ -61,9 +61,10 @@ struct StoreOffset {
 //                       Writes POSITIONS (index into the neighbour list), no neighbour loads.
 //   k_gather_neighbours flat over edges: out_dst[e] = neighbours(seed)[out_dst[e]].
 template <int S>
-__device__ __forceinline__ uint32_t row_shr(uint32_t v, uint32_t fill) {
-  // lane l of a 16-lane row reads lane l - S of the same row; lanes l < S get `fill`
-  return (uint32_t)__builtin_amdgcn_update_dpp((int)fill, (int)v, 0x110 + S, 0xf, 0xf, false);
+__device__ __forceinline__ uint32_t row_shr(uint32_t v) {
+  // lane l of a 16-lane row reads lane l - S of the same row; lanes l < S read 0 (bound_ctrl), which lets the
+  // compiler fold the move into the consuming compare (v_cmp_eq_u32_dpp) -- callers shift values that are never 0
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x110 + S, 0xf, 0xf, true);
 }
 
 //
@@ -122,13 +123,13 @@ __global__ __launch_bounds__(128 * (4 / GPW)) void k_khop3_positions(GraphView g
       // w = the raw xorshift word of my draw: the generator's v-array is a sliding window over the
       // sequence (old v0..v4, w of draw 0, w of draw 1, ...), which is what the rewind below reads.
       const Xorwow st0 = st;
-      uint32_t x = 0, w = 0;
+      uint32_t x = 0;
 #pragma unroll
       for (uint32_t i = 0; i < 16; ++i) {
         const uint32_t xi = st.next();
         x = (lig == i) ? xi : x;
-        w = (lig == i) ? st.v4 : w;
       }
+      const uint32_t w = x - (st0.d + (lig + 1) * 362437u); // draw = xorshift word + Weyl counter after lig + 1 steps
       // r = x mod len: q' = mulhi(x, floor(2^32/len)) is q or q - 1 (two fix-ups for safety)
       uint32_t r = x - __umulhi(x, magic) * len;
       r = min(r, r - len);
@@ -144,23 +145,24 @@ __global__ __launch_bounds__(128 * (4 / GPW)) void k_khop3_positions(GraphView g
           pos = (pos + 1) & set_mask;
         }
       }
-      // equal to an EARLIER candidate of this round?
+      // equal to an EARLIER candidate of this round?  (compared as r + 1, never 0)
+      const uint32_t rp = r + 1;
       bool dup = false;
-      dup |= row_shr<1>(r, HASH_EMPTY) == r;
-      dup |= row_shr<2>(r, HASH_EMPTY) == r;
-      dup |= row_shr<3>(r, HASH_EMPTY) == r;
-      dup |= row_shr<4>(r, HASH_EMPTY) == r;
-      dup |= row_shr<5>(r, HASH_EMPTY) == r;
-      dup |= row_shr<6>(r, HASH_EMPTY) == r;
-      dup |= row_shr<7>(r, HASH_EMPTY) == r;
-      dup |= row_shr<8>(r, HASH_EMPTY) == r;
-      dup |= row_shr<9>(r, HASH_EMPTY) == r;
-      dup |= row_shr<10>(r, HASH_EMPTY) == r;
-      dup |= row_shr<11>(r, HASH_EMPTY) == r;
-      dup |= row_shr<12>(r, HASH_EMPTY) == r;
-      dup |= row_shr<13>(r, HASH_EMPTY) == r;
-      dup |= row_shr<14>(r, HASH_EMPTY) == r;
-      dup |= row_shr<15>(r, HASH_EMPTY) == r;
+      dup |= row_shr<1>(rp) == rp;
+      dup |= row_shr<2>(rp) == rp;
+      dup |= row_shr<3>(rp) == rp;
+      dup |= row_shr<4>(rp) == rp;
+      dup |= row_shr<5>(rp) == rp;
+      dup |= row_shr<6>(rp) == rp;
+      dup |= row_shr<7>(rp) == rp;
+      dup |= row_shr<8>(rp) == rp;
+      dup |= row_shr<9>(rp) == rp;
+      dup |= row_shr<10>(rp) == rp;
+      dup |= row_shr<11>(rp) == rp;
+      dup |= row_shr<12>(rp) == rp;
+      dup |= row_shr<13>(rp) == rp;
+      dup |= row_shr<14>(rp) == rp;
+      dup |= row_shr<15>(rp) == rp;
       const bool is_new = !in_set && !dup;
       const uint32_t new_mask = (uint32_t)(__ballot(is_new) >> grp_shift) & 0xffffu;
       const uint32_t rank = __popc(new_mask & ((1u << lig) - 1u));
