@@ -35,7 +35,8 @@ def parse():
     ap.add_argument("--batch", type=int, default=8000)
     ap.add_argument("--fanout", default="25,10")
     ap.add_argument("--sample-type", default="khop3",
-                    choices=["khop3", "khop0", "khop2", "khop1", "weighted_khop", "random_walk"],
+                    choices=["khop3", "khop0", "khop2", "khop1", "weighted_khop", "weighted_khop_hash_dedup",
+                             "random_walk"],
                     help="random_walk: PinSAGE defaults (walk length 3, restart 0.5, 4 walks); --fanout gives the "
                          "top-K per layer, e.g. 5,5,5.  weighted_khop: synthetic alias tables")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -205,9 +206,10 @@ def main():
             store.connect_peers(holder)
 
     code = {"khop3": ops.KHOP3, "khop0": ops.KHOP0, "khop2": ops.KHOP2, "khop1": ops.KHOP1,
-            "weighted_khop": ops.WEIGHTED_KHOP, "random_walk": ops.RANDOM_WALK}[args.sample_type]
+            "weighted_khop": ops.WEIGHTED_KHOP, "weighted_khop_hash_dedup": ops.WEIGHTED_KHOP_HASH_DEDUP,
+            "random_walk": ops.RANDOM_WALK}[args.sample_type]
     extra_kw = {}
-    if args.sample_type == "weighted_khop":  # per-edge acceptance probability + alias neighbour (engine.cc:372-384)
+    if args.sample_type.startswith("weighted_khop"):  # per-edge acceptance probability + alias neighbour (engine.cc:372-384)
         gen = torch.Generator(device=dev).manual_seed(7)
         E = indices.numel()
         extra_kw = dict(prob_table=torch.rand(E, generator=gen, device=dev, dtype=torch.float32),
