@@ -42,7 +42,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline: keep sampling mini-batches this long")
     ap.add_argument("--host-profile", action="store_true", help="print host enqueue time per section to stderr")
-    ap.add_argument("--pipelines", type=int, default=1,
+    ap.add_argument("--pipelines", type=int, default=2,
                     help="sampling batches in flight (each on its own stream with its own dedup table)")
     ap.add_argument("--no-overlap", action="store_true",
                     help="one stream: extract of batch k and sampling of batch k+1 run back to back "
@@ -400,6 +400,10 @@ def main():
                 "kernel": "k_gather_rows<16, CachedRows, ident-dst, nt> (ggms_extract_cached)",
                 "bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                 "frac": achieved / 8000.0, "traffic": traffic,
+                # same launch with nothing beside it (see roofline_alone): in the pipeline the gather shares HBM with
+                # the sampling kernels of the next batches
+                "frac_alone": None if serial_us is None else
+                serial_rows * (4 + 2 * row_bytes) / (serial_us * 1e-6) / 1e9 / 8000.0,
                 "algorithmic_bytes_per_row": 4 + 2 * row_bytes,
                 "avg_launch_us": avg_launch_s * 1e6,
                 "traffic_source": tr["source"] if tr else None,

@@ -16,7 +16,7 @@
 //     through ds_bpermute (no LDS memory), so every wave-instruction moves a full
 //     1 KiB even when a row is 400 B (25 chunks), and the store side of an
 //     identity-destination gather is one contiguous 1 KiB segment;
-//   * U independent 16-B loads per lane are issued before the first store.
+//   * U = 16 independent chunk loads per lane are issued before the first store.
 // Algorithmic bytes per row: 4 (index) + 2 * row_bytes.
 #include <cstdlib>
 
@@ -102,7 +102,7 @@ __device__ __forceinline__ void store_chunk(uint64_t addr, V v) {
   else *(gp_t)addr = v;
 }
 
-// U = independent chunk loads in flight per lane (8 x 16 B; 16 at narrower chunks so that it stays 128 B)
+// U = independent chunk loads in flight per lane (16, or 8 for rows of fewer than 8 chunks)
 template <int CB, typename Rows, bool IDENT_DST, bool NT, bool NTS, int U = 8>
 __global__ __launch_bounds__(kBlock) void k_gather_rows(char *__restrict__ out, Rows rows,
                                                         const uint32_t *__restrict__ dst_index, Count n_arg,
@@ -209,14 +209,17 @@ static int launch_gather(char *out, Rows rows, const uint32_t *dst_index, size_t
   static const int max_blocks = [] { const char *e = getenv("GGMS_EXTRACT_BLOCKS"); int v = e ? atoi(e) : 256; return v > 0 ? v : 256; }();
   int grid = grid_for(n_max, kBlock);
   if (grid > max_blocks) grid = max_blocks;
-  // narrow chunks (rows that are not a multiple of 16 B) with enough chunks per row: twice the loads in flight
-  const bool deep = cb < 16 && rc >= 8;
+  // 16 independent chunk loads per lane instead of 8 once a row has >= 8 chunks.  Measured on MI355X: the gather
+  // alone 222 -> 215 us at 400-B rows (0.58 -> 0.60 of peak), 0.65 -> 0.70 at 512-B rows, and it holds its rate
+  // when the sampler runs beside it (in-pipeline 289 -> 226 us).  GGMS_EXTRACT_DEEP=0 restores 8 (measurement hook).
+  static const bool env_deep = [] { const char *e = getenv("GGMS_EXTRACT_DEEP"); return !(e && e[0] == '0'); }();
+  const bool deep = env_deep && rc >= 8;
 #define GGMS_LAUNCH_U(CB, ID, NT, NTS, UU)                                                                    \
   hipLaunchKernelGGL((k_gather_rows<CB, Rows, ID, NT, NTS, UU>), dim3(grid), dim3(kBlock), 0, stream, out, rows, \
                      dst_index, n, (uint32_t)rc, magic, miss_count)
 #define GGMS_LAUNCH(CB, ID, NT)                                                          \
   do {                                                                                    \
-    if (CB < 16 && deep) {                                                                \
+    if (deep) {                                                                           \
       if (env_nts) GGMS_LAUNCH_U(CB, ID, NT, true, 16); else GGMS_LAUNCH_U(CB, ID, NT, false, 16); \
     } else {                                                                              \
       if (env_nts) GGMS_LAUNCH_U(CB, ID, NT, true, 8); else GGMS_LAUNCH_U(CB, ID, NT, false, 8);   \
