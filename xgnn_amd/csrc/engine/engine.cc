@@ -112,6 +112,8 @@ void Engine::Configure(const std::unordered_map<std::string, std::string> &kv_in
   if (kv.count("seed")) { cfg.has_seed = true; cfg.seed = std::stoull(kv["seed"]); }
   if (kv.count("hash_table")) cfg.direct_table = kv["hash_table"] != "hashed";
   if (kv.count("lookahead")) cfg.lookahead = std::stoull(kv["lookahead"]);
+  if (kv.count("pipelines")) cfg.pipelines = std::max<size_t>(1, std::min<size_t>(4, std::stoull(kv["pipelines"])));
+  if (cfg.lookahead + 1 < cfg.pipelines) cfg.pipelines = cfg.lookahead + 1; // nothing to overlap without batches ahead
   SAM_CHECK(cfg.sample_type >= GGMS_KHOP0 && cfg.sample_type <= GGMS_KHOP3, "unknown sample type");
   if (cfg.sample_type == GGMS_WEIGHTED_KHOP || cfg.sample_type == GGMS_KHOP2 || cfg.sample_type == GGMS_KHOP1 ||
       cfg.sample_type == GGMS_WEIGHTED_KHOP_PREFIX ||
@@ -432,6 +434,25 @@ void Engine::SampleInit(int worker_id, const std::string &ctx) {
   SAM_GGMS(ggms_random_states_init(states_, num_states_, seed, stream_));
   ws_bytes_ = ggms_sample_batch_workspace_bytes(cfg.sample_type, max_seeds_, cfg.fanout.data(), L, &extra_);
   SAM_HIP(hipMalloc(&ws_, ws_bytes_));
+  // pipeline 0 = {stream_, ht_, ws_}; the others get their own stream, table and workspace
+  pipes_.assign(cfg.pipelines, Pipe{});
+  for (size_t p = 0; p < pipes_.size(); ++p) {
+    Pipe &P = pipes_[p];
+    SAM_HIP(hipEventCreateWithFlags(&P.rng_done, hipEventDisableTiming));
+    if (p == 0) {
+      P.stream = stream_;
+      P.ht = ht_;
+      P.ws = ws_;
+      continue;
+    }
+    SAM_HIP(hipStreamCreateWithFlags(&P.stream, hipStreamNonBlocking));
+    P.ht = ht_;
+    SAM_HIP(hipMalloc(&P.ht.o2n, ht_.o2n_size * (cfg.direct_table ? 8 : 16)));
+    SAM_HIP(hipMalloc((void **)&P.ht.n2o, max_unique_ * 4));
+    SAM_HIP(hipMalloc((void **)&P.ht.num_items_dev, 16));
+    SAM_GGMS(ggms_hashtable_init(&P.ht, stream_));
+    SAM_HIP(hipMalloc(&P.ws, ws_bytes_));
+  }
   SAM_HIP(hipStreamSynchronize(stream_));
   prof.Resize(cfg.num_epoch, num_global_step_);
   if (cfg.UsePresample()) { // dist_engine.cc:455-466: worker 0 ranks the nodes, everybody waits
@@ -476,9 +497,10 @@ void Engine::Presample() {
       const size_t off = s * cfg.batch_size, size = std::min(cfg.batch_size, n_train - off);
       ggms_sample_extra_t extra = extra_;
       extra.data = dat.data();
-      SAM_GGMS(ggms_sample_batch(cfg.sample_type, &graph_, d_train + off, size, cfg.fanout.data(), L, &ht_, states_,
-                                 num_states_, row.data(), col.data(), d_counts, &extra, ws_, ws_bytes_, stream_));
-      SAM_GGMS(ggms_count_nodes(d_freq, ht_.n2o, max_unique_, d_counts + 3 * L, stream_));
+      // pipeline 0's table: its version stamp keeps counting when the training batches follow
+      SAM_GGMS(ggms_sample_batch(cfg.sample_type, &graph_, d_train + off, size, cfg.fanout.data(), L, &pipes_[0].ht,
+                                 states_, num_states_, row.data(), col.data(), d_counts, &extra, ws_, ws_bytes_, stream_));
+      SAM_GGMS(ggms_count_nodes(d_freq, pipes_[0].ht.n2o, max_unique_, d_counts + 3 * L, stream_));
     }
     SAM_HIP(hipStreamSynchronize(stream_)); // `data` is reshuffled on the host next
   }
@@ -575,6 +597,7 @@ void Engine::TrainInit(int worker_id, const std::string &ctx) {
     SAM_HIP(hipMemset(b->counts_dev, 0, (3 * L + 4) * 8));
     SAM_HIP(hipHostMalloc((void **)&b->counts, (3 * L + 4) * 8));
     std::memset(b->counts, 0, (3 * L + 4) * 8);
+    SAM_HIP(hipEventCreateWithFlags(&b->ev_seeds, hipEventDisableTiming));
     SAM_HIP(hipEventCreate(&b->ev_start));
     SAM_HIP(hipEventCreate(&b->ev_sampled));
     SAM_HIP(hipEventCreate(&b->ev_done));
@@ -597,6 +620,8 @@ void Engine::Shutdown() {
   bg_stop_ = true;
   pool_cv_.notify_all();
   if (bg_.joinable()) bg_.join();
+  for (auto &P : pipes_)
+    if (P.stream) (void)hipStreamSynchronize(P.stream);
   if (stream_) (void)hipStreamSynchronize(stream_);
   if (stream_extract_) (void)hipStreamSynchronize(stream_extract_);
 }
@@ -643,18 +668,32 @@ bool Engine::EnqueueOne() {
     return false;
   }
   const uint32_t L = (uint32_t)cfg.fanout.size();
-  SAM_HIP(hipEventRecord(b->ev_start, stream_));
+  // Consecutive batches go to the sampling pipelines round-robin.  The seeds were copied on stream_ (the one
+  // stream that touches the shuffled train set); the RNG pool -- and khop2's CSR -- is handed from batch to
+  // batch through rng_wait / rng_done, so the results are those of the one-batch-at-a-time loop.
+  Pipe &P = pipes_[enq_count_++ % pipes_.size()];
+  hipStream_t ss = P.stream;
+  if (ss != stream_) {
+    SAM_HIP(hipEventRecord(b->ev_seeds, stream_));
+    SAM_HIP(hipStreamWaitEvent(ss, b->ev_seeds, 0));
+  }
+  SAM_HIP(hipEventRecord(b->ev_start, ss));
   ggms_sample_extra_t extra = extra_;
   extra.data = b->data.data();
-  SAM_GGMS(ggms_sample_batch(cfg.sample_type, &graph_, b->output_nodes, b->num_seeds, cfg.fanout.data(), L, &ht_,
-                             states_, num_states_, b->row.data(), b->col.data(), b->counts_dev, &extra, ws_, ws_bytes_,
-                             stream_));
+  if (pipes_.size() > 1 && cfg.sample_type != GGMS_KHOP0) {
+    extra.rng_wait = last_rng_done_;
+    extra.rng_done = P.rng_done;
+    last_rng_done_ = P.rng_done;
+  }
+  SAM_GGMS(ggms_sample_batch(cfg.sample_type, &graph_, b->output_nodes, b->num_seeds, cfg.fanout.data(), L, &P.ht,
+                             states_, num_states_, b->row.data(), b->col.data(), b->counts_dev, &extra, P.ws, ws_bytes_,
+                             ss));
   uint64_t *n_in = b->counts_dev + 3 * L, *n_miss = b->counts_dev + 3 * L + 1;
-  SAM_HIP(hipMemsetAsync(n_miss, 0, 8, stream_));
-  // input nodes = the table's unique list (task->input_nodes, dist_loops.cc:357); the next batch's sampling
+  SAM_HIP(hipMemsetAsync(n_miss, 0, 8, ss));
+  // input nodes = the table's unique list (task->input_nodes, dist_loops.cc:357); a later batch's sampling
   // overwrites it, so the slot keeps its own copy and the gather below reads that copy
-  SAM_GGMS(ggms_gather_scatter(b->input_nodes, ht_.n2o, nullptr, nullptr, max_unique_, n_in, 1, GGMS_I32, stream_));
-  SAM_HIP(hipEventRecord(b->ev_sampled, stream_));
+  SAM_GGMS(ggms_gather_scatter(b->input_nodes, P.ht.n2o, nullptr, nullptr, max_unique_, n_in, 1, GGMS_I32, ss));
+  SAM_HIP(hipEventRecord(b->ev_sampled, ss));
   // The gather is HBM-bound, the sampler latency-bound: they run on separate streams so that batch k's
   // extract overlaps batch k+1's sampling (the reference serialises them, dist_loops_arch6.cc:248-251)
   hipStream_t xs = stream_extract_;

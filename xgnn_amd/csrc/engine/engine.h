@@ -69,7 +69,8 @@ struct RunConfig {
   bool has_seed = false;
   uint64_t seed = 0;
   bool direct_table = true;
-  size_t lookahead = 1; // batches sample_once() keeps enqueued beyond the one it was asked for (config key `lookahead`)
+  size_t lookahead = 2; // batches sample_once() keeps enqueued beyond the one it was asked for (config key `lookahead`)
+  size_t pipelines = 2; // batches the sampler itself has in flight: own stream + dedup table + workspace each (`pipelines`)
   size_t presample_epoch = 0;
   bool UsePresample() const { return UseGPUCache() && (cache_policy == 2 /*kCacheByPreSample*/); }
   bool UseGPUCache() const { return cache_percentage > 0 && arch != kArch1; } // run_config.h:124-126
@@ -133,7 +134,7 @@ struct Batch {
   uint64_t *counts = nullptr;
   size_t num_seeds = 0, num_input = 0;
   uint64_t num_miss = 0;
-  hipEvent_t ev_start = nullptr, ev_sampled = nullptr, ev_done = nullptr;
+  hipEvent_t ev_seeds = nullptr, ev_start = nullptr, ev_sampled = nullptr, ev_done = nullptr;
 };
 
 class Engine {
@@ -197,6 +198,16 @@ class Engine {
   size_t num_states_ = 0;
   void *ws_ = nullptr;
   size_t ws_bytes_ = 0;
+  // sampling pipelines 1..K-1 (pipeline 0 is {stream_, ht_, ws_}); the RNG pool is consumed in batch order
+  struct Pipe {
+    hipStream_t stream = nullptr;
+    ggms_hashtable_t ht{};
+    void *ws = nullptr;
+    hipEvent_t rng_done = nullptr;
+  };
+  std::vector<Pipe> pipes_;
+  size_t enq_count_ = 0;
+  hipEvent_t last_rng_done_ = nullptr;
   size_t max_seeds_ = 0, max_unique_ = 0;
   std::vector<size_t> max_input_, max_edges_;
   // shuffler
