@@ -97,6 +97,17 @@ def main():
                                    "64 B for 16-B/lane loads)")
         out["hbm_bytes_per_launch"] = (2 * out["FETCH_SIZE_KB_raw"] + out["WRITE_SIZE_KB"]) * 1024
         out["algorithmic_bytes_per_launch"] = rows_per_launch * row_bytes
+    # the same kernel's durations in the kernel trace: the bench launches it `launches` times inside the pipeline
+    # (warm-up + timed steps) and then 10 times with nothing beside it (roofline_alone)
+    g = [(int(r["Start_Timestamp"]), (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3) for r in tr
+         if "k_gather_rows" in r["Kernel_Name"] and "CachedRows" in r["Kernel_Name"]]
+    g.sort()
+    durs = [d for _, d in g]
+    if len(durs) > launches:
+        timed = durs[launches - bench["steps"]:launches]
+        out["rocprof_avg_us_timed_steps"] = sum(timed) / len(timed)
+        out["rocprof_avg_us_alone"] = sum(durs[launches:]) / len(durs[launches:])
+        out["bench_avg_launch_us_same_run"] = bench["roofline"]["avg_launch_us"]
     with open(f"{dst}_extract_traffic.json", "w") as f:
         json.dump(out, f, indent=1)
     print(json.dumps(out, indent=1))
