@@ -1,10 +1,11 @@
 #!/bin/bash
-# A/B of env-selected variants on ONE box: tools/ab.sh "VAR=a" "VAR=b" ...  (each run: bench.py 40 steps)
+# Same-box A/B of bench.py variants (box-to-box variance is +-5-8 %, so variants are compared inside ONE gpurun call).
+# Each argument is "ENV=.. ENV2=.. | bench flags"; either side may be empty.  Example:
+#   tools/ab.sh " | --pipelines 1" " | --pipelines 2" "GGMS_EXTRACT_BLOCKS=512 | --pipelines 2" "GGMS_KHOP3_GPW=4 | --no-overlap"
+# Hooks: GGMS_EXTRACT_BLOCKS, GGMS_EXTRACT_DEEP, GGMS_EXTRACT_NT, GGMS_EXTRACT_NT_STORE, GGMS_KHOP3_GPW, GGMS_SCAN, GGMS_GRID_CAP.
 for v in "$@"; do
+  envp="${v%%|*}"; flags="${v#*|}"
   for rep in 1 2; do
-    env $v python bench.py --steps 40 --warmup 5 --no-cpu-baseline 2>/dev/null | python -c "
-import json,sys
-d=json.loads(sys.stdin.read()); p=d['per_gpu']
-print('$v rep$rep: step %.3f ms | sample %.3f | extract %.3f' % (d['ms_per_step'], p['sample_ms_per_step'], p['extract_ms_per_step']))"
+    env $envp python bench.py --no-cpu-baseline $flags 2>/dev/null | python tools/brief.py "[$v] rep$rep"
   done
 done
