@@ -408,6 +408,17 @@ def main():
                 "avg_launch_us": avg_launch_s * 1e6,
                 "traffic_source": tr["source"] if tr else None,
             },
+            # the step as a whole against the same roof: profiled HBM bytes of one step (gather, corrected, scaled to
+            # this run's rows + sampler kernels, raw counters = lower bound) / this run's step time
+            "pipeline_hbm": None if not tr or "sampler_hbm_bytes_per_step_raw" not in tr else {
+                "bytes_per_step": tr["hbm_bytes_per_launch"] / tr["rows_per_launch"] * (rows / args.steps)
+                + tr["sampler_hbm_bytes_per_step_raw"],
+                "GBps": (tr["hbm_bytes_per_launch"] / tr["rows_per_launch"] * (rows / args.steps)
+                         + tr["sampler_hbm_bytes_per_step_raw"]) / (elapsed / args.steps) / 1e9,
+                "frac_of_peak": (tr["hbm_bytes_per_launch"] / tr["rows_per_launch"] * (rows / args.steps)
+                                 + tr["sampler_hbm_bytes_per_step_raw"]) / (elapsed / args.steps) / 8e12,
+                "source": tr["source"],
+            },
             "roofline_alone": None if serial_us is None else {
                 "note": "same kernel, last batch's rows, nothing running beside it (10 launches after the timed region)",
                 "avg_launch_us": serial_us, "achieved": serial_rows * (4 + 2 * row_bytes) / (serial_us * 1e-6) / 1e9,

@@ -97,6 +97,14 @@ def main():
                                    "64 B for 16-B/lane loads)")
         out["hbm_bytes_per_launch"] = (2 * out["FETCH_SIZE_KB_raw"] + out["WRITE_SIZE_KB"]) * 1024
         out["algorithmic_bytes_per_launch"] = rows_per_launch * row_bytes
+    # every other ggms kernel of a step (the sampler): raw counter bytes per step.  Their accesses are random 4/8-B
+    # words, for which the guide gives no FETCH_SIZE calibration, so this is a lower bound
+    other = 0.0
+    for (k, c), v in pmc.items():
+        if gk and k == gk[0]:
+            continue
+        other += sum(v) * 1024 / launches
+    out["sampler_hbm_bytes_per_step_raw"] = other
     # the same kernel's durations in the kernel trace: the bench launches it `launches` times inside the pipeline
     # (warm-up + timed steps) and then 10 times with nothing beside it (roofline_alone)
     g = [(int(r["Start_Timestamp"]), (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3) for r in tr
