@@ -39,3 +39,16 @@ def prefix_sums(indptr, weights):
         if b > a:
             out[a:b] = np.cumsum(weights[a:b], dtype=np.float32)
     return out
+
+
+# The literal inputs of the reference's own hash-table unit test (samgraph/unittest/test_hashmap.cc:98-126,166-198):
+# successive FillWithDuplicates calls on one table.  What that test asserts -- and ours with it -- is set equality
+# with the inputs so far, no duplicates in the unique list, and that each fill keeps the previous list as a prefix.
+REF_HASHMAP_VECTORS = {
+    "DupRevised_Ref": [[1, 2, 3, 4, 5, 2, 5, 1, 10, 233],
+                       [1, 2, 3, 6, 9, 2, 8, 1, 3, 7, 1023],
+                       [1, 2, 3, 4, 5, 2, 5, 1, 10, 233, 1, 2, 3, 6, 9, 2, 8, 1, 3, 7, 1023]],
+    "MixedFillMethod": [[1, 2, 3, 4, 5, 2, 5, 1, 10, 256, 6, 9, 2, 13, 5, 64, 512, 1021],
+                        list(range(1, 513))],
+}
+REF_HASHMAP_EXPECT = {"MixedFillMethod": [13, 513]}  # EXPECT_EQ(h_set.size(), 13) / EXPECT_EQ(output_uniq.size(), 513)

@@ -113,6 +113,42 @@ def test_hashtable_fill_and_map(ops, n, direct):
         np.testing.assert_array_equal(host_u32(loc), np.arange(uniq.size, dtype=np.uint32))
 
 
+@pytest.mark.parametrize("direct", [False, True])
+def test_hashtable_reference_unittest_vectors(ops, direct):
+    """The reference's own unit test, samgraph/unittest/test_hashmap.cc:84-276 (DupRevised_Ref, MixedFillMethod,
+    Large), with its literal inputs and its assertions; first-occurrence order on top (canonical semantics)."""
+    from graphgen import REF_HASHMAP_VECTORS, REF_HASHMAP_EXPECT
+
+    def run(fills, num_node, cap):
+        ht = ops.OrderedHashTable(cap, num_node=num_node if direct else None)
+        ht.reset()
+        seen, prev = [], np.zeros(0, np.uint32)
+        sizes = []
+        for data in fills:
+            a = np.asarray(data, np.uint32)
+            ht.fill_with_duplicates(dev(a))
+            uniq = host_u32(ht.unique()).copy()
+            seen = list(dict.fromkeys(list(seen) + a.tolist()))
+            assert len(set(uniq.tolist())) == uniq.size           # unique
+            np.testing.assert_array_equal(uniq[: prev.size], prev)  # prefix kept
+            np.testing.assert_array_equal(uniq, np.array(seen, np.uint32))  # set equality + first-occurrence order
+            loc, _ = ht.map_edges(ht.unique().contiguous(), None)  # ValidateSearch (test_hashmap.cu:24-37)
+            np.testing.assert_array_equal(host_u32(loc), np.arange(uniq.size, dtype=np.uint32))
+            prev = uniq
+            sizes.append(uniq.size)
+        return sizes
+
+    for name, fills in REF_HASHMAP_VECTORS.items():
+        sizes = run(fills, 2048, 4096)
+        if name in REF_HASHMAP_EXPECT:
+            assert sizes == REF_HASHMAP_EXPECT[name]
+    # Large (:200-273): 1 M draws from [1, 800000], then (800000, 1600000], then [1, 1600000]
+    rng = np.random.RandomState(12345)
+    fills = [rng.randint(1, 800001, 1_000_000), rng.randint(800001, 1600001, 1_000_000),
+             rng.randint(1, 1600001, 1_000_000)]
+    run(fills, 1_600_001, 3_000_000)
+
+
 def test_hashtable_unique_out_and_empty(ops):
     ht = ops.OrderedHashTable(64)
     ht.reset()

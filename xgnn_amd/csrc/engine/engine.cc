@@ -181,8 +181,13 @@ void Engine::LoadDataset() {
   const bool share = cfg.arch == kArch6; // forked workers read the same pages
   ds.indptr = MapFile("indptr.bin", (ds.num_node + 1) * 4, share);
   ds.indices = MapFile("indices.bin", ds.num_edge * 4, share);
+  // SAMGRAPH_FAKE_FEAT_DIM (run_config.cc:156-159, engine.cc:202-204): pretend the features have this width and
+  // do not read feat.bin -- lets a big graph run without its feature file
+  size_t fake_dim = 0;
+  if (const char *e = getenv("SAMGRAPH_FAKE_FEAT_DIM")) fake_dim = std::strtoull(e, nullptr, 10);
+  if (fake_dim) ds.feat_dim = fake_dim;
   const size_t row_bytes = ds.feat_dim * ggms_dtype_bytes(ds.feat_dtype);
-  if (file_exists(cfg.dataset_path + "feat.bin")) {
+  if (!fake_dim && file_exists(cfg.dataset_path + "feat.bin")) {
     ds.feat = MapFile("feat.bin", ds.num_node * row_bytes, share);
   } else { // engine.cc:199-235: datasets without feat.bin get an (uninitialised) table; ours is zero-filled
     ds.feat.bytes = ds.num_node * row_bytes;
