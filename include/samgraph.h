@@ -41,6 +41,11 @@ void samgraph_train_init(int worker_id, const char *ctx);   /* :549-554 */
 void samgraph_extract_start(int count);                     /* :556-559 */
 int samgraph_wait_one_child(void);                          /* :573-584 */
 void samgraph_forward_barrier(void);                        /* :507     */
+/* Entry points of deployments this build does not carry (arch9 unified-memory sampling, arch5 switcher;
+ * operation.cc:541-547,561-571): exported so that the reference's loader binds, they abort with a message
+ * like any unsupported configuration (logging.cc:69-73). */
+void samgraph_um_sample_init(int num_workers);
+void samgraph_switch_init(int worker_id, const char *ctx, double cache_percentage);
 
 /* ---- queries: operation.h:45-63 ------------------------------------------ */
 size_t samgraph_num_epoch(void);

@@ -86,6 +86,7 @@ SAMGRAPH_SYMBOLS = {
     "samgraph_init": (None, []), "samgraph_start": (None, []), "samgraph_shutdown": (None, []),
     "samgraph_data_init": (None, []), "samgraph_sample_init": (None, [_i, C.c_char_p]),
     "samgraph_train_init": (None, [_i, C.c_char_p]), "samgraph_extract_start": (None, [_i]),
+    "samgraph_um_sample_init": (None, [_i]), "samgraph_switch_init": (None, [_i, C.c_char_p, C.c_double]),
     "samgraph_wait_one_child": (_i, []), "samgraph_forward_barrier": (None, []),
     "samgraph_num_epoch": (_sz, []), "samgraph_steps_per_epoch": (_sz, []), "samgraph_num_local_step": (_sz, []),
     "samgraph_num_class": (_sz, []), "samgraph_feat_dim": (_sz, []), "samgraph_get_next_batch": (_u64, []),
@@ -141,6 +142,11 @@ class SamGraphBasics(object):
     def sample_init(self, worker_id, ctx): return self.C_LIB_CTYPES.samgraph_sample_init(worker_id, ctx.encode())
     def train_init(self, worker_id, ctx): return self.C_LIB_CTYPES.samgraph_train_init(worker_id, ctx.encode())
     def extract_start(self, count): return self.C_LIB_CTYPES.samgraph_extract_start(count)
+    def um_sample_init(self, num_workers): return self.C_LIB_CTYPES.samgraph_um_sample_init(num_workers)
+
+    def switch_init(self, worker_id, ctx, cache_percentage):
+        return self.C_LIB_CTYPES.samgraph_switch_init(worker_id, ctx.encode(), cache_percentage)
+
     def num_local_step(self): return self.C_LIB_CTYPES.samgraph_num_local_step()
     def start(self): return self.C_LIB_CTYPES.samgraph_start()
     def shutdown(self): return self.C_LIB_CTYPES.samgraph_shutdown()

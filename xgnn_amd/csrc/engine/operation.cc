@@ -34,6 +34,8 @@ void samgraph_sample_init(int worker_id, const char *ctx) { Engine::Get().Sample
 void samgraph_train_init(int worker_id, const char *ctx) { Engine::Get().TrainInit(worker_id, ctx); }
 void samgraph_extract_start(int count) { Engine::Get().ExtractStart(count); }
 void samgraph_forward_barrier(void) { Engine::Get().Barrier(); }
+void samgraph_um_sample_init(int) { sam::fatal(__FILE__, __LINE__, "arch9 (unified-memory sampling) is not part of this build"); }
+void samgraph_switch_init(int, const char *, double) { sam::fatal(__FILE__, __LINE__, "arch5 (switcher) is not part of this build"); }
 
 int samgraph_wait_one_child(void) { // operation.cc:573-584
   int st = 0;

@@ -18,7 +18,8 @@ for _name in ("config init start num_class feat_dim num_epoch steps_per_epoch ge
               "get_log_init_value get_log_step_value get_log_epoch_value report_init report_step report_step_average "
               "report_epoch report_epoch_average report_node_access trace_step_begin trace_step_end "
               "trace_step_begin_now trace_step_end_now dump_trace forward_barrier wait_one_child log_step_by_key "
-              "get_log_step_value_by_key data_init sample_init train_init extract_start num_local_step").split():
+              "get_log_step_value_by_key data_init sample_init train_init extract_start num_local_step "
+              "um_sample_init switch_init").split():
     globals()[_name] = getattr(_basics, _name)
 
 # DataType code -> (numpy typestr, torch dtype); common/common.h:38-46, adapter.cc:33-53
