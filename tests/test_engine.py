@@ -232,6 +232,17 @@ def test_single_pass_scan_variant():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("cap", ["0", "3000"])
+def test_khop0_draw_buffer_overflow_path(cap):
+    """khop0 parks raw draws in a buffer and resolves them in a second kernel; seeds that do not fit are resolved
+    in place.  A tiny buffer (GGMS_KHOP0_CAP) must give the same results."""
+    env = dict(os.environ, GGMS_KHOP0_CAP=cap)
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_parity.py"), "-m", "gpu",
+                        "-q", "-x", "-k", "khop0"], capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:]
+
+
+@pytest.mark.gpu
 def test_arch6_presample_cache_policy(tmp_path):
     """cache_policy = pre_sample (dist/pre_sampler.cc:39-139): worker 0 samples `presample_epoch` epochs of the
     whole train set, ranks nodes by (visit count << 32 | id) descending, and that ranking fills the cache."""

@@ -95,6 +95,7 @@ static size_t sampler_ws_words(int sample_type, const BatchCaps &c, const size_t
                                const ggms_sample_extra_t *extra) {
   size_t w = sample_ws_words(c.max_in_all);
   for (uint32_t i = 0; i < L; ++i) {
+    if (sample_type == GGMS_KHOP0) w = std::max(w, khop0_ws_words(c.max_input[i], fanouts[i]));
     if (sample_type == GGMS_WEIGHTED_KHOP || sample_type == GGMS_KHOP1 || sample_type == GGMS_WEIGHTED_KHOP_PREFIX)
       w = std::max(w, weighted_ws_words(c.max_input[i], fanouts[i]));
     if (sample_type == GGMS_RANDOM_WALK && extra)

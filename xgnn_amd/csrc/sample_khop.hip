@@ -20,8 +20,12 @@
 //   * khop2: one lane per stream as the assignment demands, compact COO written
 //     directly at the seed's scanned offset;
 //   * khop0: one lane per logical reservoir lane (32 per seed, as the RNG stream
-//     assignment demands); the racy atomicExch (khop0.cu:144-148) becomes an LDS
-//     atomicMax on the candidate position, i.e. highest-j-wins, deterministic.
+//     assignment demands) only GENERATES the draws; resolving them (modulo, slot
+//     update) is a separate, fully parallel kernel.  The racy atomicExch
+//     (khop0.cu:144-148) becomes an LDS atomicMax on the candidate position, i.e.
+//     highest-j-wins, deterministic.
+#include <algorithm>
+
 #include "ggms_internal.h"
 
 namespace ggms {
@@ -244,50 +248,191 @@ __global__ __launch_bounds__(kBlock) void k_gather_neighbours(GraphView g, const
 
 // ---- khop0 (reservoir) -------------------------------------------------------
 // Block = 128 threads = 4 logical warps of 32 lanes; thread t: x = t % 32, w = t / 32.
-// Stream seed = (b*128 + x*4 + w) + num_input (khop0.cu:114-117).
-__global__ __launch_bounds__(128) void k_sample_khop0(GraphView g, const uint32_t *__restrict__ input,
-                                                      Count n_arg, uint32_t fanout,
-                                                      const uint32_t *__restrict__ offset,
-                                                      uint32_t *__restrict__ out_src,
-                                                      uint32_t *__restrict__ out_dst, SrcMode sm) {
-  extern __shared__ uint32_t slot_j[]; // [4][fanout]: winning position per reservoir slot
+// Stream seed = (b*128 + x*4 + w) + num_input (khop0.cu:114-117); the stream serves the warp's 16 seeds in
+// turn, position j >= fanout of a seed being drawn by lane j % 32.
+//
+// The reference resolves every draw where it is taken (modulo, slot exchange), so a lane that meets a
+// 17 000-neighbour node runs ~530 draws x ~60 instructions on its own.  Here the serial part is only the
+// generator: k_khop0_generate steps each stream through its draws (9 ALU ops + one store per draw) and parks
+// the raw 32-bit draws in a buffer, laid out by (seed, position); k_khop0_resolve then resolves them with one
+// wave per seed -- modulo, LDS atomicMax on the slot (highest position wins, the canonical reading of the racy
+// atomicExch of khop0.cu:144-148), output.  The buffer holds `cap` draws; a seed whose draws do not fit is
+// resolved in place by the generating lanes, the old way, so the capacity only affects speed.
+struct DrawCount { // draws a seed consumes: one per neighbour position beyond the first `fanout`
+  GraphView g;
+  const uint32_t *input;
+  uint32_t fanout;
+  __device__ __forceinline__ uint32_t operator()(uint64_t i) const {
+    uint32_t len;
+    g.neighbours(input[i], len);
+    return len > fanout ? len - fanout : 0u;
+  }
+};
+
+__global__ __launch_bounds__(128) void k_khop0_generate(GraphView g, const uint32_t *__restrict__ input, Count n_arg,
+                                                        uint32_t fanout, const uint32_t *__restrict__ offset,
+                                                        const uint32_t *__restrict__ draw_base,
+                                                        uint32_t *__restrict__ raw, uint32_t cap,
+                                                        uint32_t *__restrict__ out_src,
+                                                        uint32_t *__restrict__ out_dst, SrcMode sm,
+                                                        uint32_t *__restrict__ heavy_count) {
+  extern __shared__ uint32_t slot_j[]; // [4][fanout]: winning position per reservoir slot (in-place seeds only)
   const uint64_t n = n_arg.get();
   const uint32_t x = threadIdx.x & 31, w = threadIdx.x >> 5;
+  const uint32_t half = threadIdx.x & 32u; // first lane of my logical warp inside the wave64
   uint32_t *my_slots = slot_j + w * fanout;
   const uint64_t num_blocks = (n + 63) / 64;
+  if (blockIdx.x == 0 && threadIdx.x == 0) *heavy_count = 0u; // list filled by k_khop0_resolve
+  uint32_t first_j = x;
+  while (first_j < fanout) first_j += 32; // first position of this lane that is drawn for
   for (uint64_t b = blockIdx.x; b < num_blocks; b += gridDim.x) {
     Xorwow st;
     st.init((uint64_t)(b * 128 + x * 4 + w) + n);
-    const uint64_t last = (64 * (b + 1) < n) ? 64 * (b + 1) : n;
-    for (uint64_t index = 64 * b + w; index < last; index += 4) {
+    // lane k < 16 of the logical warp fetches seed k of the warp (index 64 b + w + 4 k): degree and draw base,
+    // so that the serial walk below waits for memory once, not once per seed
+    const uint64_t my_index = 64 * b + w + 4 * (uint64_t)(x & 15);
+    uint32_t my_len = 0, my_base = 0;
+    if (x < 16 && my_index < n) {
+      g.neighbours(input[my_index], my_len);
+      my_base = draw_base[my_index];
+    }
+    for (uint32_t k = 0; k < 16; ++k) {
+      const uint64_t index = 64 * b + w + 4 * (uint64_t)k;
+      const uint32_t len = __shfl(my_len, (int)(half + k), 64);
+      const uint32_t base = __shfl(my_base, (int)(half + k), 64);
+      if (index >= n || len <= fanout) continue; // no draws; k_khop0_resolve copies short lists
+      uint32_t j = first_j;
+      if ((uint64_t)base + (len - fanout) <= cap) {
+#pragma unroll 5 // the XORWOW registers rotate with period 5: no moves in the unrolled body
+        for (; j < len; j += 32) raw[base + (j - fanout)] = st.next();
+        continue;
+      }
+      // does not fit the draw buffer: resolve in place (uniform per logical warp)
       const uint32_t rid = input[index];
-      uint32_t len;
-      const uint32_t *edges = g.neighbours(rid, len);
+      uint32_t len2;
+      const uint32_t *edges = g.neighbours(rid, len2);
       const uint32_t o = offset[index];
       const uint32_t sv = sm.value(rid, index);
-      if (len <= fanout) {
-        for (uint32_t j = x; j < len; j += 32) {
-          out_src[o + j] = sv;
-          out_dst[o + j] = edges[j];
-        }
-      } else {
-        uint32_t j = x;
-        for (; j < fanout; j += 32) my_slots[j] = j; // slot j starts as position j
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        for (; j < len; j += 32) {
-          const uint32_t kk = st.next() % (j + 1);
-          if (kk < fanout) atomicMax(&my_slots[kk], j); // highest j wins
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        for (uint32_t s = x; s < fanout; s += 32) {
-          out_src[o + s] = sv;
-          out_dst[o + s] = edges[my_slots[s]];
-        }
-        __builtin_amdgcn_wave_barrier();
+      for (uint32_t s0 = x; s0 < fanout; s0 += 32) my_slots[s0] = s0; // slot s starts as position s
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      for (; j < len; j += 32) {
+        const uint32_t kk = st.next() % (j + 1);
+        if (kk < fanout) atomicMax(&my_slots[kk], j); // highest j wins
       }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      for (uint32_t s0 = x; s0 < fanout; s0 += 32) {
+        out_src[o + s0] = sv;
+        out_dst[o + s0] = edges[my_slots[s0]];
+      }
+      __builtin_amdgcn_wave_barrier();
     }
+  }
+}
+
+// A seed with more parked draws than this is left to k_khop0_resolve_heavy (one 1024-thread block per seed)
+constexpr uint32_t kKhop0Heavy = 1024;
+
+// the resolve step proper: lanes `lane`, `lane + stride`, ... of the draws of one seed into its LDS slots
+__device__ __forceinline__ void khop0_resolve_draws(const uint32_t *__restrict__ raw, uint32_t base, uint32_t extra,
+                                                    uint32_t fanout, uint32_t lane, uint32_t stride,
+                                                    uint32_t *slots) {
+  for (uint32_t d0 = 0; d0 < extra; d0 += stride * 8) { // 8 independent loads in flight per lane
+    uint32_t xs[8];
+#pragma unroll
+    for (uint32_t u = 0; u < 8; ++u) {
+      const uint32_t d = d0 + u * stride + lane;
+      xs[u] = d < extra ? raw[base + d] : 0u;
+    }
+#pragma unroll
+    for (uint32_t u = 0; u < 8; ++u) {
+      const uint32_t d = d0 + u * stride + lane;
+      const uint32_t j = fanout + d;
+      const uint32_t kk = xs[u] % (j + 1);
+      if (d < extra && kk < fanout) atomicMax(&slots[kk], j); // highest position wins
+    }
+  }
+}
+
+// 16 lanes per seed (4 seeds per wave, 16 per block): copy (deg <= fanout) or resolve the parked draws.  The
+// per-seed chain of dependent loads (id -> degree -> offsets -> draws -> neighbours) is what bounds this kernel,
+// so several seeds share a wave.
+__global__ __launch_bounds__(kBlock) void k_khop0_resolve(GraphView g, const uint32_t *__restrict__ input, Count n_arg,
+                                                          uint32_t fanout, const uint32_t *__restrict__ offset,
+                                                          const uint32_t *__restrict__ draw_base,
+                                                          const uint32_t *__restrict__ raw, uint32_t cap,
+                                                          uint32_t *__restrict__ out_src,
+                                                          uint32_t *__restrict__ out_dst, SrcMode sm,
+                                                          uint32_t *__restrict__ heavy_count,
+                                                          uint32_t *__restrict__ heavy_list, uint32_t groups) {
+  extern __shared__ uint32_t slot_j[]; // [groups][fanout]
+  constexpr uint32_t G = 16;
+  const uint64_t n = n_arg.get();
+  const uint32_t lig = threadIdx.x & (G - 1), grp = threadIdx.x / G;
+  if (grp >= groups) return; // wide fanouts: fewer seeds per block, the LDS slots decide
+  uint32_t *my_slots = slot_j + grp * fanout;
+  const uint64_t stride = (uint64_t)gridDim.x * groups;
+  for (uint64_t index = (uint64_t)blockIdx.x * groups + grp; index < n; index += stride) {
+    const uint32_t rid = input[index];
+    uint32_t len;
+    const uint32_t *edges = g.neighbours(rid, len);
+    const uint32_t o = offset[index];
+    const uint32_t sv = sm.value(rid, index);
+    if (len <= fanout) {
+      for (uint32_t j = lig; j < len; j += G) {
+        out_src[o + j] = sv;
+        out_dst[o + j] = edges[j];
+      }
+      continue;
+    }
+    const uint32_t base = draw_base[index], extra = len - fanout;
+    if ((uint64_t)base + extra > cap) continue; // resolved in place by k_khop0_generate
+    if (extra > kKhop0Heavy) {                  // a whole block takes it
+      if (lig == 0) heavy_list[atomicAdd(heavy_count, 1u)] = (uint32_t)index;
+      continue;
+    }
+    for (uint32_t s0 = lig; s0 < fanout; s0 += G) my_slots[s0] = s0;
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    khop0_resolve_draws(raw, base, extra, fanout, lig, G, my_slots);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    for (uint32_t s0 = lig; s0 < fanout; s0 += G) {
+      out_src[o + s0] = sv;
+      out_dst[o + s0] = edges[my_slots[s0]];
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// the long neighbour lists: one 1024-thread block per listed seed
+__global__ __launch_bounds__(1024) void k_khop0_resolve_heavy(GraphView g, const uint32_t *__restrict__ input,
+                                                              uint32_t fanout, const uint32_t *__restrict__ offset,
+                                                              const uint32_t *__restrict__ draw_base,
+                                                              const uint32_t *__restrict__ raw,
+                                                              uint32_t *__restrict__ out_src,
+                                                              uint32_t *__restrict__ out_dst, SrcMode sm,
+                                                              const uint32_t *__restrict__ heavy_count,
+                                                              const uint32_t *__restrict__ heavy_list) {
+  extern __shared__ uint32_t slot_j[]; // [fanout]
+  const uint32_t num = *heavy_count;
+  for (uint32_t h = blockIdx.x; h < num; h += gridDim.x) {
+    const uint32_t index = heavy_list[h];
+    const uint32_t rid = input[index];
+    uint32_t len;
+    const uint32_t *edges = g.neighbours(rid, len);
+    const uint32_t o = offset[index], base = draw_base[index];
+    const uint32_t sv = sm.value(rid, index);
+    for (uint32_t s0 = threadIdx.x; s0 < fanout; s0 += 1024) slot_j[s0] = s0;
+    __syncthreads();
+    khop0_resolve_draws(raw, base, len - fanout, fanout, threadIdx.x, 1024, slot_j);
+    __syncthreads();
+    for (uint32_t s0 = threadIdx.x; s0 < fanout; s0 += 1024) {
+      out_src[o + s0] = sv;
+      out_dst[o + s0] = edges[slot_j[s0]];
+    }
+    __syncthreads();
   }
 }
 
@@ -398,17 +543,51 @@ int sample_khop3_impl(GraphView g, const uint32_t *input, size_t n_max, Count n,
   return GGMS_OK;
 }
 
+// draws parked per launch: 8 per output slot (a frontier whose mean degree stays under 9 x fanout fits entirely)
+size_t khop0_draw_cap(size_t num_input, size_t fanout) {
+  static const long long forced = [] { // test hook: GGMS_KHOP0_CAP=<draws> (small values exercise the in-place path)
+    const char *e = getenv("GGMS_KHOP0_CAP");
+    return e ? atoll(e) : -1ll;
+  }();
+  if (forced >= 0) return (size_t)forced;
+  const unsigned long long want = 8ull * num_input * fanout;
+  return (size_t)(want < 0x7fffffffull ? want : 0x7fffffffull);
+}
+size_t khop0_ws_words(size_t num_input, size_t fanout) {
+  return 3 * num_input + tile_scan_words(num_input) + 48 + khop0_draw_cap(num_input, fanout);
+}
+
 int sample_khop0_impl(GraphView g, const uint32_t *input, size_t n_max, Count n, uint32_t fanout, uint32_t *out_src,
                       uint32_t *out_dst, uint64_t *num_out_dev, uint32_t *workspace, const uint32_t *seed_local,
                       int src_local, hipStream_t s, ScanArea *shared_scan) {
   uint32_t *offset = workspace;
-  const ScanArea sa = shared_scan ? *shared_scan : ScanArea{offset + n_max, false};
+  uint32_t *draw_base = offset + n_max;
+  uint32_t *heavy_list = draw_base + n_max;
+  uint32_t *heavy_count = heavy_list + n_max;
+  uint32_t *scan_scr = heavy_count + 16;
+  uint32_t *raw = scan_scr + tile_scan_words(n_max) + 16;
+  const uint32_t cap = (uint32_t)khop0_draw_cap(n_max, fanout);
+  const ScanArea sa = shared_scan ? *shared_scan : ScanArea{scan_scr, false};
   int rc = tile_scan(SeedCount{g, input, fanout}, StoreOffset{offset}, n_max, n, sa, nullptr, nullptr,
                      num_out_dev, s);
   if (rc != GGMS_OK) return rc;
-  const size_t num_blocks = (n_max + 63) / 64;
-  hipLaunchKernelGGL(k_sample_khop0, dim3(grid_for(num_blocks, 1)), dim3(128), 4 * fanout * sizeof(uint32_t), s, g,
-                     input, n, fanout, offset, out_src, out_dst, SrcMode{seed_local, src_local});
+  const ScanArea sb = shared_scan ? *shared_scan : ScanArea{scan_scr, true}; // control words re-armed by the first scan
+  rc = tile_scan(DrawCount{g, input, fanout}, StoreOffset{draw_base}, n_max, n, sb, nullptr, nullptr, nullptr, s);
+  if (rc != GGMS_OK) return rc;
+  const SrcMode sm{seed_local, src_local};
+  const size_t lds = 4 * fanout * sizeof(uint32_t);
+  hipLaunchKernelGGL(k_khop0_generate, dim3(grid_for((n_max + 63) / 64, 1)), dim3(128), lds, s, g, input, n, fanout,
+                     offset, draw_base, raw, cap, out_src, out_dst, sm, heavy_count);
+  GGMS_LAUNCH_CHECK();
+  // seeds per 256-thread block of the resolve kernel: 16 lanes each, as many as 48 KB of LDS slots allow
+  const uint32_t groups = std::max<uint32_t>(1, std::min<uint32_t>(16, (48u << 10) / (4u * fanout)));
+  hipLaunchKernelGGL(k_khop0_resolve, dim3(grid_for(n_max, groups)), dim3(kBlock), groups * fanout * sizeof(uint32_t),
+                     s, g, input, n, fanout, offset, draw_base, raw, cap, out_src, out_dst, sm, heavy_count, heavy_list,
+                     groups);
+  GGMS_LAUNCH_CHECK();
+  // the few neighbour lists with more than kKhop0Heavy parked draws (none on most batches: the kernel then exits at once)
+  hipLaunchKernelGGL(k_khop0_resolve_heavy, dim3(256), dim3(1024), fanout * sizeof(uint32_t), s, g, input, fanout, offset,
+                     draw_base, raw, out_src, out_dst, sm, heavy_count, heavy_list);
   GGMS_LAUNCH_CHECK();
   return GGMS_OK;
 }
@@ -437,8 +616,7 @@ using namespace ggms;
 extern "C" {
 
 size_t ggms_sample_workspace_bytes(int sample_type, size_t num_input, size_t fanout) {
-  (void)sample_type;
-  (void)fanout;
+  if (sample_type == GGMS_KHOP0) return khop0_ws_words(num_input, fanout) * sizeof(uint32_t);
   return sample_ws_words(num_input) * sizeof(uint32_t);
 }
 
@@ -464,7 +642,7 @@ int ggms_sample_khop0(const ggms_graph_t *graph, const ggms_id_t *input, size_t 
                       ggms_id_t *out_src, ggms_id_t *out_dst, uint64_t *num_out_dev, void *workspace,
                       size_t workspace_bytes, ggms_stream_t stream) {
   GGMS_CHECK_ARG(graph && num_out_dev);
-  GGMS_CHECK_ARG(fanout > 0 && fanout <= 8192);
+  GGMS_CHECK_ARG(fanout > 0 && fanout <= 2048); // LDS slots: 4 x fanout words in place, 16 x fanout in the resolver
   hipStream_t s = to_stream(stream);
   if (num_input == 0) {
     GGMS_HIP(hipMemsetAsync(num_out_dev, 0, sizeof(uint64_t), s));
