@@ -163,6 +163,7 @@ def test_hashtable_unique_out_and_empty(ops):
 GRAPHS = {
     "small": dict(num_node=300, mean_deg=12, seed=1),
     "mid": dict(num_node=20_000, mean_deg=30, seed=2),
+    "wide": dict(num_node=70_000, mean_deg=8, seed=3),  # ids need 3 key bytes in the samplers' radix sort
 }
 
 
@@ -213,7 +214,7 @@ def test_sample_khop0(ops, graphs, gname, n, fanout):
 
 
 @pytest.mark.parametrize("gname,n,fanout", [("small", 1, 5), ("small", 300, 25), ("small", 0, 4), ("mid", 8000, 10),
-                                            ("mid", 30000, 25), ("mid", 5000, 3)])
+                                            ("mid", 30000, 25), ("mid", 5000, 3), ("wide", 9000, 6)])
 def test_sample_khop1(ops, graphs, gname, n, fanout):
     """With replacement + stable sort by src + adjacent-duplicate drop (khop1.cu:42-127); 30000*25 > 512 K tasks
     exercises the grid-stride reuse of a stream."""
@@ -278,7 +279,8 @@ def test_sample_khop2_rejects_sharded_graph(ops):
 
 
 @pytest.mark.parametrize("gname,n,fanout", [("small", 1, 5), ("small", 300, 25), ("small", 0, 4), ("mid", 8000, 10),
-                                            ("mid", 20000, 25), ("mid", 5000, 3), ("mid", 40000, 15)])
+                                            ("mid", 20000, 25), ("mid", 5000, 3), ("mid", 40000, 15),
+                                            ("wide", 9000, 6)])
 def test_sample_weighted_khop(ops, graphs, gname, n, fanout):
     """Alias-method sampler incl. stable sort by src and adjacent-duplicate compaction; duplicated seeds too."""
     ip, ix, g = graphs[gname]

@@ -105,22 +105,25 @@ __global__ __launch_bounds__(kBlock) void k_sort_scatter(const uint32_t *__restr
   }
 }
 
-// keys/vals ping-pong between (k0,v0) and (k1,v1); after 4 passes the result is back in (k0,v0).
+// keys/vals ping-pong between (k0,v0) and (k1,v1).  `passes` bytes of the key are sorted (4 = the whole key; fewer
+// when the caller knows the keys' range -- the rest of the key must then agree wherever the sorted bytes do);
+// *in_second tells whether the result ended in (k1,v1) (odd number of passes).
 inline int radix_sort_pairs(uint32_t *k0, uint32_t *v0, uint32_t *k1, uint32_t *v1, size_t n_max, Count n,
-                            uint32_t *scratch, hipStream_t s) {
+                            uint32_t *scratch, hipStream_t s, uint32_t passes = 4, bool *in_second = nullptr) {
+  if (in_second) *in_second = (passes & 1u) != 0;
   if (n_max == 0) return GGMS_OK;
   const uint32_t tiles = (uint32_t)sort_tiles(n_max);
   uint32_t *hist = scratch;
   uint32_t *scan_scratch = scratch + 256 * (size_t)tiles;
   const int grid = grid_for(tiles, 1);
-  for (uint32_t pass = 0; pass < 4; ++pass) {
+  for (uint32_t pass = 0; pass < passes; ++pass) {
     const uint32_t shift = 8 * pass;
     uint32_t *ki = (pass & 1) ? k1 : k0, *vi = (pass & 1) ? v1 : v0;
     uint32_t *ko = (pass & 1) ? k0 : k1, *vo = (pass & 1) ? v0 : v1;
     hipLaunchKernelGGL(k_sort_hist, dim3(grid), dim3(kBlock), 0, s, ki, n, shift, hist, tiles);
     GGMS_LAUNCH_CHECK();
     int rc = tile_scan(HistValue{hist}, HistStore{hist}, 256 * (size_t)tiles, count_of(256 * (size_t)tiles),
-                       ScanArea{scan_scratch, pass != 0}, nullptr, nullptr, nullptr, s); // one clear for 4 passes
+                       ScanArea{scan_scratch, pass != 0}, nullptr, nullptr, nullptr, s); // one clear for all passes
     if (rc != GGMS_OK) return rc;
     hipLaunchKernelGGL(k_sort_scatter, dim3(grid), dim3(kBlock), 0, s, ki, vi, ko, vo, n, shift, hist, tiles);
     GGMS_LAUNCH_CHECK();

@@ -212,11 +212,11 @@ int ggms_sample_batch(int sample_type, const ggms_graph_t *graph, const ggms_id_
     } else if (sample_type == GGMS_KHOP1) {
       rc = sample_weighted_impl(graph->indptr, graph->indices, nullptr, nullptr, input, n_max, n,
                                 (uint32_t)fanouts[i], col[i], tmp_dst, num_edge, (uint32_t *)states, samp_ws,
-                                first ? seed_local : nullptr, 1, s);
+                                first ? seed_local : nullptr, 1, s, &scan, graph->num_node);
     } else if (sample_type == GGMS_WEIGHTED_KHOP_PREFIX) {
       rc = sample_weighted_impl(graph->indptr, graph->indices, extra->prob_table, nullptr, input, n_max, n,
                                 (uint32_t)fanouts[i], col[i], tmp_dst, num_edge, (uint32_t *)states, samp_ws,
-                                first ? seed_local : nullptr, 1, s);
+                                first ? seed_local : nullptr, 1, s, &scan, graph->num_node);
     } else if (sample_type == GGMS_WEIGHTED_KHOP_HASH_DEDUP) {
       rc = sample_weighted_hash_dedup_impl(graph->indptr, graph->indices, extra->prob_table, extra->alias_table, input,
                                            n_max, n, (uint32_t)fanouts[i], col[i], tmp_dst, num_edge,
@@ -224,12 +224,12 @@ int ggms_sample_batch(int sample_type, const ggms_graph_t *graph, const ggms_id_
     } else if (sample_type == GGMS_WEIGHTED_KHOP) {
       rc = sample_weighted_impl(graph->indptr, graph->indices, extra->prob_table, extra->alias_table, input, n_max, n,
                                 (uint32_t)fanouts[i], col[i], tmp_dst, num_edge, (uint32_t *)states, samp_ws,
-                                first ? seed_local : nullptr, 1, s);
+                                first ? seed_local : nullptr, 1, s, &scan, graph->num_node);
     } else { // random walk: fanout[i] = num_neighbor = K (operation.cc:174)
       rc = sample_random_walk_impl(g, input, n_max, n, (uint32_t)extra->random_walk_length,
                                    extra->random_walk_restart_prob, (uint32_t)extra->num_random_walk,
                                    (uint32_t)fanouts[i], col[i], tmp_dst, extra->data[i], num_edge, (uint32_t *)states,
-                                   samp_ws, first ? seed_local : nullptr, 1, s);
+                                   samp_ws, first ? seed_local : nullptr, 1, s, &scan);
     }
     if (rc != GGMS_OK) return rc;
     if (i == 0 && extra && extra->rng_done) GGMS_HIP(hipEventRecord((hipEvent_t)extra->rng_done, s));

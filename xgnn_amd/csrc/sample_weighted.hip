@@ -150,7 +150,8 @@ size_t weighted_ws_words(size_t num_input, size_t fanout) {
 int sample_weighted_impl(const uint32_t *indptr, const uint32_t *indices, const float *prob, const uint32_t *alias,
                          const uint32_t *input, size_t n_max, Count n, uint32_t fanout, uint32_t *out_src,
                          uint32_t *out_dst, uint64_t *num_out_dev, uint32_t *states, uint32_t *workspace,
-                         const uint32_t *seed_local, int src_local, hipStream_t s, ScanArea *shared_scan) {
+                         const uint32_t *seed_local, int src_local, hipStream_t s, ScanArea *shared_scan,
+                         uint32_t num_node) {
   uint32_t *w = workspace;
   uint32_t *tmp_dst = w;  w += n_max * fanout;
   uint32_t *k0 = w;       w += n_max;
@@ -174,9 +175,13 @@ int sample_weighted_impl(const uint32_t *indptr, const uint32_t *indices, const 
   GGMS_LAUNCH_CHECK();
   hipLaunchKernelGGL(k_weighted_keys, dim3(grid_for(n_max, kBlock)), dim3(kBlock), 0, s, indptr, input, n, k0, v0);
   GGMS_LAUNCH_CHECK();
-  int rc = radix_sort_pairs(k0, v0, k1, v1, n_max, n, sort_scr, s);
+  // keys are node ids (< num_node) or kEmptyKey: when the ids fit in 2 or 3 bytes those bytes order them, and the
+  // empty key (all ones) still sorts behind every id
+  const uint32_t passes = (num_node && num_node <= 0xffffu) ? 2u : (num_node && num_node <= 0xffffffu) ? 3u : 4u;
+  bool in_second = false;
+  int rc = radix_sort_pairs(k0, v0, k1, v1, n_max, n, sort_scr, s, passes, &in_second);
   if (rc != GGMS_OK) return rc;
-  const SortedStream ss{k0, v0, tmp_dst, fanout, n};
+  const SortedStream ss{in_second ? k1 : k0, in_second ? v1 : v0, tmp_dst, fanout, n};
   // element count of the compaction = n * fanout with n possibly on the device: a Count cannot multiply,
   // so KeepFlag bounds itself by ss.n and the scan runs over the upper bound
   const ScanArea sa = shared_scan ? *shared_scan : ScanArea{scan_scr, false};
@@ -299,7 +304,7 @@ int ggms_sample_weighted_khop(const ggms_graph_t *graph, const float *prob_table
   GGMS_CHECK_ARG((span < tasks ? span : tasks) <= num_states); // assert(thread_id < num_random_states), :52
   return sample_weighted_impl(graph->indptr, graph->indices, prob_table, alias_table, input, num_input,
                               count_of(num_input), (uint32_t)fanout, out_src, out_dst, num_out_dev, (uint32_t *)states,
-                              (uint32_t *)workspace, nullptr, 0, s);
+                              (uint32_t *)workspace, nullptr, 0, s, nullptr, graph->num_node);
 }
 
 int ggms_sample_khop1(const ggms_graph_t *graph, const ggms_id_t *input, size_t num_input, size_t fanout,
@@ -321,7 +326,7 @@ int ggms_sample_khop1(const ggms_graph_t *graph, const ggms_id_t *input, size_t 
   GGMS_CHECK_ARG((span < tasks ? span : tasks) <= num_states); // assert(thread_id < num_random_states), khop1.cu:51
   return sample_weighted_impl(graph->indptr, graph->indices, nullptr, nullptr, input, num_input, count_of(num_input),
                               (uint32_t)fanout, out_src, out_dst, num_out_dev, (uint32_t *)states,
-                              (uint32_t *)workspace, nullptr, 0, s);
+                              (uint32_t *)workspace, nullptr, 0, s, nullptr, graph->num_node);
 }
 
 int ggms_sample_weighted_khop_prefix(const ggms_graph_t *graph, const float *prob_prefix_table, const ggms_id_t *input,
@@ -344,7 +349,7 @@ int ggms_sample_weighted_khop_prefix(const ggms_graph_t *graph, const float *pro
   GGMS_CHECK_ARG((span < tasks ? span : tasks) <= num_states); // prefix.cu:50
   return sample_weighted_impl(graph->indptr, graph->indices, prob_prefix_table, nullptr, input, num_input,
                               count_of(num_input), (uint32_t)fanout, out_src, out_dst, num_out_dev, (uint32_t *)states,
-                              (uint32_t *)workspace, nullptr, 0, s);
+                              (uint32_t *)workspace, nullptr, 0, s, nullptr, graph->num_node);
 }
 
 int ggms_sample_weighted_khop_hash_dedup(const ggms_graph_t *graph, const float *prob_table,
