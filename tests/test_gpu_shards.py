@@ -25,7 +25,7 @@ def _free_port():
 
 def _worker(rank, world, port, mode, q):
     import oracle
-    from xgnn_amd import ggms_store, ops
+    from xgnn_amd import ggms_store
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.cuda.set_device(0)
