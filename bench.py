@@ -392,7 +392,8 @@ def main():
             "per_gpu": {
                 "sample_ms_per_step": t_sample_ms / args.steps,  # latency of one batch on its pipeline (they overlap)
                 "extract_ms_per_step": t_extract_ms / args.steps,
-                "sample_only_edges_per_s": edges / (t_sample_ms / 1e3),
+                # sampled edges over the time the sampler alone was busy: only meaningful with one pipeline
+                "sample_only_edges_per_s": edges / (t_sample_ms / 1e3) if K == 1 else None,
                 "edges_per_step": edges / args.steps,
                 "rows_per_step": rows / args.steps,
             },
