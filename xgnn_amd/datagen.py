@@ -13,6 +13,10 @@ PRESETS = {
                      num_train=196_615),
     "papers100M": dict(num_node=111_059_956, mean_deg=14.55, alpha=0.7, dmax=300_000, feat_dim=128, num_class=172,
                        num_train=1_207_179),
+    # com-friendster as the reference generates it (datagen/friendster.py:68-69: 65.6 M nodes, 1.8 G directed edges;
+    # synthetic 256-dim f32 features per BASELINE configs[4], 1 % of the nodes as the train set)
+    "friendster": dict(num_node=65_608_366, mean_deg=27.53, alpha=0.7, dmax=6_000, feat_dim=256, num_class=100,
+                       num_train=656_083),
     "tiny": dict(num_node=20_000, mean_deg=30.0, alpha=0.75, dmax=2_000, feat_dim=100, num_class=47,
                  num_train=4_000),
 }
