@@ -2,6 +2,7 @@
 the box's one GPU through the bench's test hooks, gloo for the timing barrier) for every feature-store mode."""
 import json
 import os
+import socket
 import subprocess
 import sys
 
@@ -11,6 +12,14 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 KEYS = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
         "vs_baseline", "dtype", "data", "config", "roofline"}
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
 
 
 def _last_json(stdout):
@@ -29,7 +38,7 @@ def test_single_gpu_line():
 @pytest.mark.parametrize("store", ["replica", "peer", "a2a"])
 def test_two_ranks_one_gpu(store):
     env = dict(os.environ, GGMS_BENCH_DEVICE="0", GGMS_BENCH_BACKEND="gloo")
-    port = 29600 + {"replica": 1, "peer": 2, "a2a": 3}[store]
+    port = _free_port()
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                         "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
                         "--gpus", "2", "--preset", "tiny", "--steps", "4", "--warmup", "1", "--batch", "512",
