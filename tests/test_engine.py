@@ -222,6 +222,20 @@ def test_cpp_driver_over_the_c_abi(tmp_path):
 
 
 @pytest.mark.gpu
+def test_example_training_loop(tmp_path):
+    """tools/example_train_sage.py: the reference's loop (config / init / sample_once / get_next_batch / get_graph_*)
+    feeding a plain-PyTorch GraphSAGE on the GPU -- the engine's zero-copy tensors are usable by torch as they are."""
+    d = make_dataset(tmp_path / "ds", num_node=4000, dim=16, num_train=1500)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "example_train_sage.py"), d["path"], "--epochs", "3",
+                        "--batch-size", "256", "--fanout", "5", "4"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("epoch ")]
+    assert len(lines) == 3
+    losses = [float(l.split("loss ")[1].split(",")[0]) for l in lines]
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0]
+
+
+@pytest.mark.gpu
 def test_single_pass_scan_variant():
     """GGMS_SCAN=1 selects the decoupled look-back form of every ordered scan: same results."""
     env = dict(os.environ, GGMS_SCAN="1")
