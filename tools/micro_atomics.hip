@@ -40,6 +40,24 @@ __global__ __launch_bounds__(256) void k_min_wg(W *tab, const uint32_t *keys, ui
     __hip_atomic_fetch_min(&tab[keys[i]], (W)(hi | i), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
+// XCD-local variant: block b only touches slice (b % 8) of the table (blocks are dealt to the 8 XCDs round-robin, so a
+// slice of 1/8 of the table is what ONE XCD's 4-MiB L2 would see); keys are folded into the slice
+template <typename W, bool WG>
+__global__ __launch_bounds__(256) void k_min_sliced(W *tab, const uint32_t *keys, uint32_t n, W hi, uint32_t slice) {
+  const uint32_t base = (blockIdx.x % 8) * slice;
+  for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    W *p = &tab[base + keys[i] % slice];
+    if (WG) __hip_atomic_fetch_min(p, (W)(hi | i), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    else atomicMin(p, (W)(hi | i));
+  }
+}
+template <typename W>
+__global__ __launch_bounds__(256) void k_load_sliced(const W *tab, const uint32_t *keys, uint32_t n, uint32_t *out,
+                                                     uint32_t slice) {
+  const uint32_t base = (blockIdx.x % 8) * slice;
+  for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) out[i] = (uint32_t)tab[base + keys[i] % slice];
+}
+
 template <typename F>
 static float time_us(F f, int reps = 20) {
   hipEvent_t a, b;
@@ -97,6 +115,15 @@ int main(int argc, char **argv) {
     printf("  store u64                      : %7.1f us  %6.1f G/s\n", t, E / t / 1e3);
     t = time_us([&] { k_store<uint32_t><<<grid, 256>>>((uint32_t *)d_tab, d_keys, E); });
     printf("  store u32                      : %7.1f us  %6.1f G/s\n", t, E / t / 1e3);
+    const uint32_t slice = N / 8;
+    t = time_us([&] { k_min_sliced<unsigned long long, false><<<grid, 256>>>((unsigned long long *)d_tab, d_keys, E, 0x1234ull << 32, slice); });
+    printf("  atomicMin u64 agent, XCD slices: %7.1f us  %6.1f G/s\n", t, E / t / 1e3);
+    t = time_us([&] { k_min_sliced<unsigned long long, true><<<grid, 256>>>((unsigned long long *)d_tab, d_keys, E, 0x1234ull << 32, slice); });
+    printf("  atomicMin u64 wg,    XCD slices: %7.1f us  %6.1f G/s\n", t, E / t / 1e3);
+    t = time_us([&] { k_min_sliced<uint32_t, true><<<grid, 256>>>((uint32_t *)d_tab, d_keys, E, 0u, slice); });
+    printf("  atomicMin u32 wg,    XCD slices: %7.1f us  %6.1f G/s\n", t, E / t / 1e3);
+    t = time_us([&] { k_load_sliced<unsigned long long><<<grid, 256>>>((const unsigned long long *)d_tab, d_keys, E, d_out, slice); });
+    printf("  load u64,            XCD slices: %7.1f us  %6.1f G/s\n", t, E / t / 1e3);
   }
   return 0;
 }
