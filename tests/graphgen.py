@@ -22,6 +22,19 @@ def powerlaw_csr(num_node, mean_deg=8.0, alpha=0.8, dmax=None, seed=0, zero_frac
     return indptr, indices
 
 
+def hub_csr(num_node=3000, num_hub=6, hub_deg=6000, base_deg=9, seed=0):
+    """A few very long neighbour lists among short ones: the samplers' per-list limits (khop3 fanout 127, khop0's
+    heavy-list path and its LDS slot budget) and tail behaviour."""
+    rng = np.random.RandomState(seed)
+    deg = np.full(num_node, base_deg, np.int64)
+    deg[rng.permutation(num_node)[:num_hub]] = hub_deg
+    deg[rng.random_sample(num_node) < 0.03] = 0
+    indptr = np.zeros(num_node + 1, dtype=np.uint32)
+    indptr[1:] = np.cumsum(deg)
+    indices = rng.randint(0, num_node, size=int(indptr[-1])).astype(np.uint32)
+    return indptr, indices
+
+
 def exact_features(num_node, dim, dtype=np.float32):
     """feat[i, j] = (i * dim + j) & 0xFFFF -- exactly representable everywhere."""
     v = (np.arange(num_node * dim, dtype=np.int64) & 0xFFFF).reshape(num_node, dim)

@@ -3,7 +3,7 @@ import numpy as np
 import pytest
 
 import oracle
-from graphgen import exact_features, powerlaw_csr
+from graphgen import hub_csr, exact_features, powerlaw_csr
 
 torch = pytest.importorskip("torch")
 pytestmark = pytest.mark.gpu
@@ -468,6 +468,45 @@ def test_partition_cache_paths(ops, P, dim):
     ops.extract_cached(out2, dev(nodes), dev(table), ptab, P, t_feat, num_miss=nmiss)
     assert out2.cpu().numpy().tobytes() == want.tobytes()
     assert int(nmiss.item()) == wms.size
+
+
+# ------------------------------------------- per-list limits and long lists
+@pytest.mark.parametrize("sampler,fanout", [("khop3", 127), ("khop3", 100), ("khop0", 2048), ("khop0", 100),
+                                            ("khop0", 7), ("khop2", 300), ("khop1", 40)])
+def test_samplers_on_hub_graph(ops, sampler, fanout):
+    """Six 6000-neighbour lists among short ones: khop3 at its fanout limit (127, khop3.cu:85), khop0 at its LDS slot
+    limit (2048) and through its heavy-list kernel, khop2 / khop1 with fanouts above most degrees."""
+    ip, ix = hub_csr()
+    n = 2500
+    inp = np.random.RandomState(fanout).permutation(ip.size - 1)[:n].astype(np.uint32)
+    inp[:6] = np.argsort(ip[1:] - ip[:-1])[-6:].astype(np.uint32)  # the hubs are in
+    inp = np.unique(inp)  # khop2 wants distinct seeds
+    n = inp.size
+    ix_orc = ix.copy()
+    t_ix = dev(ix)
+    g = ops.DeviceGraph(dev(ip), t_ix)
+    nstates = max(1024, n * fanout if sampler == "khop1" else 0)
+    nstates = min(nstates, 512 * 1024)
+    st_gpu = ops.random_states(nstates, 31)
+    st_orc = oracle.random_states(nstates, 31)
+    for rep in range(2):
+        if sampler == "khop3":
+            got = ops.sample_khop3(g, dev(inp), fanout, st_gpu)
+            want = oracle.sample_khop3(ip, ix_orc, inp, fanout, st_orc)
+        elif sampler == "khop0":
+            got = ops.sample_khop0(g, dev(inp), fanout)
+            want = oracle.sample_khop0(ip, ix_orc, inp, fanout)
+        elif sampler == "khop2":
+            got = ops.sample_khop2(g, dev(inp), fanout, st_gpu)
+            want = oracle.sample_khop2(ip, ix_orc, inp, fanout, st_orc)
+        else:
+            got = ops.sample_khop1(g, dev(inp), fanout, st_gpu)
+            want = oracle.sample_khop1(ip, ix_orc, inp, fanout, st_orc)
+        m = int(got[2].item())
+        assert m == want[0].size
+        np.testing.assert_array_equal(host_u32(got[0], m), want[0])
+        np.testing.assert_array_equal(host_u32(got[1], m), want[1])
+    np.testing.assert_array_equal(host_u32(t_ix), ix_orc)
 
 
 # ------------------------------------------------------- multi-layer batch
