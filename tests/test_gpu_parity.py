@@ -61,6 +61,19 @@ def test_extract(ops, dtype, dim, n):
     assert got.cpu().numpy().tobytes() == want.tobytes()
 
 
+def test_extract_row_size_limits(ops):
+    """Rows up to 8191 chunks of 16 B (131 056 B) go through the gather; wider rows are refused, not mangled."""
+    rng = np.random.RandomState(4)
+    dim = 4 * 8191
+    table = rng.standard_normal((40, dim)).astype(np.float32)
+    idx = rng.randint(0, 40, 23).astype(np.uint32)
+    out = ops.extract(dev(table), dev(idx))
+    assert out.cpu().numpy().tobytes() == oracle.extract(table, idx).tobytes()
+    wide = torch.zeros((4, 4 * 8192), dtype=torch.float32, device="cuda")
+    with pytest.raises(RuntimeError):
+        ops.extract(wide, dev(np.array([1, 2], np.uint32)))
+
+
 def test_extract_large_properties(ops):
     """products-sized gather: checksum + idempotence (size-independent properties)."""
     N, dim, n = 2_449_029, 100, 1_190_000
