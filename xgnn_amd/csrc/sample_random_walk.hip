@@ -23,7 +23,8 @@ constexpr uint32_t kMaxVisits = 128; // num_walk * walk_length supported per see
 
 __global__ __launch_bounds__(kBlock) void k_random_walk(GraphView g, const uint32_t *__restrict__ input, Count n_arg,
                                                         uint32_t walk_length, double restart_prob, uint32_t num_walk,
-                                                        uint32_t bx, uint32_t by, uint32_t *__restrict__ tmp_src,
+                                                        uint32_t bx, uint32_t by, uint64_t stride,
+                                                        uint32_t *__restrict__ tmp_src,
                                                         uint32_t *__restrict__ tmp_dst, uint32_t *__restrict__ states) {
   const uint64_t n = n_arg.get();
   // thread t of the block: walk lane tx = t / by, node lane ty = t % by  (state = bx*by*block + by*tx + ty, :50-52)
@@ -39,7 +40,9 @@ __global__ __launch_bounds__(kBlock) void k_random_walk(GraphView g, const uint3
       for (uint32_t walk = tx; walk < num_walk; walk += bx) {
         uint32_t node = start;
         for (uint32_t step = 0; step < walk_length; ++step) {
-          const uint64_t pos = node_idx * num_walk * walk_length + (uint64_t)step * num_walk + walk; // [seed][step][walk]
+          // visit e = step * num_walk + walk of the seed (the reference's [seed][step][walk] order, :84-86), stored
+          // visit-major so that the lanes of a wave -- consecutive seeds -- write and later read consecutive words
+          const uint64_t pos = ((uint64_t)step * num_walk + walk) * stride + node_idx;
           if (node == kEmptyKey) {
             tmp_src[pos] = kEmptyKey;
           } else {
@@ -65,7 +68,8 @@ __global__ __launch_bounds__(kBlock) void k_random_walk(GraphView g, const uint3
 
 // One lane per seed: distinct visited nodes + counts in first-visit order, then K stable arg-max picks.
 __global__ __launch_bounds__(kWave) void k_walk_topk(const uint32_t *__restrict__ tmp_src,
-                                                     const uint32_t *__restrict__ tmp_dst, Count n_arg, uint32_t per,
+                                                     const uint32_t *__restrict__ tmp_dst, Count n_arg, uint64_t stride,
+                                                     uint32_t per,
                                                      uint32_t K, uint32_t *__restrict__ pad_dst,
                                                      uint32_t *__restrict__ pad_cnt, uint32_t *__restrict__ num_top) {
   extern __shared__ uint32_t lds[]; // uniq[per][64], cnt[per][64]
@@ -74,19 +78,28 @@ __global__ __launch_bounds__(kWave) void k_walk_topk(const uint32_t *__restrict_
   const uint32_t lane = threadIdx.x;
   for (uint64_t s = (uint64_t)blockIdx.x * kWave + lane; s < n; s += (uint64_t)gridDim.x * kWave) {
     uint32_t nu = 0;
-    for (uint32_t e = 0; e < per; ++e) {
-      const uint64_t idx = s * per + e;
-      if (tmp_src[idx] == kEmptyKey) continue;
-      const uint32_t d = tmp_dst[idx];
-      uint32_t u = 0;
-      for (; u < nu; ++u)
-        if (uniq[u * kWave + lane] == d) break;
-      if (u == nu) {
-        uniq[nu * kWave + lane] = d;
-        cnt[nu * kWave + lane] = 1;
-        ++nu;
-      } else {
-        cnt[u * kWave + lane] += 1;
+    for (uint32_t e0 = 0; e0 < per; e0 += 8) { // 16 independent loads in flight, then the serial bookkeeping
+      uint32_t sv[8], dv[8];
+#pragma unroll
+      for (uint32_t k = 0; k < 8; ++k) {
+        const uint64_t idx = (uint64_t)(e0 + k) * stride + s;
+        sv[k] = (e0 + k < per) ? tmp_src[idx] : kEmptyKey;
+        dv[k] = (e0 + k < per) ? tmp_dst[idx] : 0u; // tmp_dst of an empty visit is never written: value unused
+      }
+#pragma unroll
+      for (uint32_t k = 0; k < 8; ++k) {
+        if (sv[k] == kEmptyKey) continue;
+        const uint32_t d = dv[k];
+        uint32_t u = 0;
+        for (; u < nu; ++u)
+          if (uniq[u * kWave + lane] == d) break;
+        if (u == nu) {
+          uniq[nu * kWave + lane] = d;
+          cnt[nu * kWave + lane] = 1;
+          ++nu;
+        } else {
+          cnt[u * kWave + lane] += 1;
+        }
       }
     }
     const uint32_t take = nu < K ? nu : K;
@@ -133,6 +146,7 @@ size_t random_walk_ws_words(size_t num_input, size_t walk_length, size_t num_wal
   return 2 * num_input * walk_length * num_walk + 2 * num_input * K + num_input + tile_scan_words(num_input) + 64;
 }
 
+// tmp_src / tmp_dst: [walk_length * num_walk][n_max], visit-major
 int random_walk_raw_impl(GraphView g, const uint32_t *input, size_t n_max, Count n, uint32_t walk_length,
                          double restart_prob, uint32_t num_walk, uint32_t *tmp_src, uint32_t *tmp_dst,
                          uint32_t *states, hipStream_t s) {
@@ -140,7 +154,7 @@ int random_walk_raw_impl(GraphView g, const uint32_t *input, size_t n_max, Count
   walk_block_shape(num_walk, bx, by);
   const size_t num_blocks = (n_max + by - 1) / by;
   hipLaunchKernelGGL(k_random_walk, dim3(grid_for(num_blocks, 1)), dim3(bx * by), 0, s, g, input, n, walk_length,
-                     restart_prob, num_walk, bx, by, tmp_src, tmp_dst, states);
+                     restart_prob, num_walk, bx, by, (uint64_t)n_max, tmp_src, tmp_dst, states);
   GGMS_LAUNCH_CHECK();
   return GGMS_OK;
 }
@@ -160,7 +174,7 @@ int sample_random_walk_impl(GraphView g, const uint32_t *input, size_t n_max, Co
   int rc = random_walk_raw_impl(g, input, n_max, n, walk_length, restart_prob, num_walk, tmp_src, tmp_dst, states, s);
   if (rc != GGMS_OK) return rc;
   hipLaunchKernelGGL(k_walk_topk, dim3(grid_for(n_max, kWave)), dim3(kWave), 2 * per * kWave * sizeof(uint32_t), s,
-                     tmp_src, tmp_dst, n, per, K, pad_dst, pad_cnt, num_top);
+                     tmp_src, tmp_dst, n, (uint64_t)n_max, per, K, pad_dst, pad_cnt, num_top);
   GGMS_LAUNCH_CHECK();
   const ScanArea sa = shared_scan ? *shared_scan : ScanArea{scan_scr, false};
   return tile_scan(TopCount{num_top}, TopEmit{input, pad_dst, pad_cnt, K, out_src, out_dst, out_data, seed_local, src_local},
