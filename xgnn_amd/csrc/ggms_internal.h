@@ -21,7 +21,7 @@ size_t khop0_ws_words(size_t num_input, size_t fanout);
 int sample_khop3_impl(GraphView g, const uint32_t *input, size_t n_max, Count n, uint32_t fanout, uint32_t *out_src,
                       uint32_t *out_dst, uint64_t *num_out_dev, uint32_t *states, uint32_t *workspace,
                       const uint32_t *seed_local, int src_local, const ggms_hashtable_t *insert_into, hipStream_t s,
-                      ScanArea *shared_scan = nullptr);
+                      ScanArea *shared_scan = nullptr, uint32_t *owner_hint = nullptr);
 int sample_khop0_impl(GraphView g, const uint32_t *input, size_t n_max, Count n, uint32_t fanout, uint32_t *out_src,
                       uint32_t *out_dst, uint64_t *num_out_dev, uint32_t *workspace, const uint32_t *seed_local,
                       int src_local, hipStream_t s, ScanArea *shared_scan = nullptr);

@@ -116,11 +116,15 @@ __global__ __launch_bounds__(kBlock) void k_ht_insert(Table t, const uint32_t *_
 
 // count_hashmap / compact_hashmap (cuda_hashtable.cu:197-232, 406-458):
 // instance i owns its key iff the word still says {pending, i}
+// hint (optional, direct layout): hint[i] == 0 means the inserting atomicMin already saw a smaller word, i.e. an earlier
+// instance or an assigned id -- instance i cannot own the key and its word need not be read again
 template <bool DIRECT>
 struct OwnerFlag {
   Table t;
   const uint32_t *item_pos; // hashed: bucket positions; direct: the keys themselves
+  const uint32_t *hint;
   __device__ __forceinline__ uint32_t operator()(uint64_t i) const {
+    if (DIRECT && hint && hint[i] == 0u) return 0u;
     return *t.w1<DIRECT>(item_pos[i]) == make_w1(t.version, 1u, (uint32_t)i) ? 1u : 0u;
   }
 };
@@ -205,12 +209,13 @@ int ht_fill_impl(const ggms_hashtable_t *ht, const uint32_t *input, size_t n_max
       GGMS_LAUNCH_CHECK();
     }
     scratch.stash = item_pos; // the direct layout does not use item_pos: it holds the owner flags between passes
-    rc = tile_scan(OwnerFlag<true>{t, input}, AssignLocal<true>{t, input, input, mapped}, n_max, n, scratch,
+    rc = tile_scan(OwnerFlag<true>{t, input, inserted ? item_pos : nullptr}, AssignLocal<true>{t, input, input, mapped},
+                   n_max, n, scratch,
                    ht->num_items_dev, ht->num_items_dev, nullptr, s, mirror_a, mirror_b);
   } else {
     hipLaunchKernelGGL(k_ht_insert<false>, dim3(grid), dim3(kBlock), 0, s, t, input, n, item_pos, pro);
     GGMS_LAUNCH_CHECK();
-    rc = tile_scan(OwnerFlag<false>{t, item_pos}, AssignLocal<false>{t, input, item_pos, mapped}, n_max, n, scratch,
+    rc = tile_scan(OwnerFlag<false>{t, item_pos, nullptr}, AssignLocal<false>{t, input, item_pos, mapped}, n_max, n, scratch,
                    ht->num_items_dev, ht->num_items_dev, nullptr, s, mirror_a, mirror_b);
   }
   if (rc != GGMS_OK || !mapped) return rc;

@@ -200,7 +200,7 @@ int ggms_sample_batch(int sample_type, const ggms_graph_t *graph, const ggms_id_
       GGMS_HIP(hipMemsetAsync(num_edge, 0, sizeof(uint64_t), s));
     } else if (sample_type == GGMS_KHOP3) {
       rc = sample_khop3_impl(g, input, n_max, n, (uint32_t)fanouts[i], col[i], tmp_dst, num_edge, (uint32_t *)states,
-                             samp_ws, first ? seed_local : nullptr, 1, ht, s, &scan);
+                             samp_ws, first ? seed_local : nullptr, 1, ht, s, &scan, item_pos);
       inserted = ht->direct != 0;
     } else if (sample_type == GGMS_KHOP0) {
       rc = sample_khop0_impl(g, input, n_max, n, (uint32_t)fanouts[i], col[i], tmp_dst, num_edge, samp_ws,

@@ -225,7 +225,8 @@ __global__ __launch_bounds__(kBlock) void k_gather_neighbours(GraphView g, const
                                                               const uint32_t *__restrict__ offset,
                                                               uint32_t *__restrict__ out_src,
                                                               uint32_t *__restrict__ out_dst, SrcMode sm,
-                                                              unsigned long long *table_w, uint32_t table_version) {
+                                                              unsigned long long *table_w, uint32_t table_version,
+                                                              uint32_t *__restrict__ owner_hint) {
   const uint64_t total = n_arg.get() * fanout;
   for (uint64_t t = (uint64_t)blockIdx.x * kBlock + threadIdx.x; t < total; t += (uint64_t)gridDim.x * kBlock) {
     // i = t / fanout for t < 2^32 (host checks n_max * fanout < 2^32): mulhi by ceil(2^32 / fanout), one fix-up
@@ -241,8 +242,11 @@ __global__ __launch_bounds__(kBlock) void k_gather_neighbours(GraphView g, const
     const uint32_t nbr = edges[pos];
     out_src[e] = sm.value(rid, i);
     out_dst[e] = nbr;
-    if (INSERT) // w1 = {0x7fffffff - version : 31 | pending = 1 | first index : 32}, hashtable.hip
-      atomicMin(table_w + nbr, ((((unsigned long long)(0x7fffffffu - table_version)) << 1 | 1ull) << 32) | e);
+    if (INSERT) { // w1 = {0x7fffffff - version : 31 | pending = 1 | first index : 32}, hashtable.hip
+      const unsigned long long mine = ((((unsigned long long)(0x7fffffffu - table_version)) << 1 | 1ull) << 32) | e;
+      const unsigned long long old = atomicMin(table_w + nbr, mine);
+      owner_hint[e] = old < mine ? 0u : 1u; // a smaller word was there already: this instance cannot own the key
+    }
   }
 }
 
@@ -509,7 +513,7 @@ size_t sample_ws_words(size_t num_input) { return num_input + tile_scan_words(nu
 int sample_khop3_impl(GraphView g, const uint32_t *input, size_t n_max, Count n, uint32_t fanout, uint32_t *out_src,
                       uint32_t *out_dst, uint64_t *num_out_dev, uint32_t *states, uint32_t *workspace,
                       const uint32_t *seed_local, int src_local, const ggms_hashtable_t *insert_into, hipStream_t s,
-                      ScanArea *shared_scan) {
+                      ScanArea *shared_scan, uint32_t *owner_hint) {
   uint32_t *offset = workspace;
   const ScanArea sa = shared_scan ? *shared_scan : ScanArea{offset + n_max, false};
   int rc = tile_scan(SeedCount{g, input, fanout}, StoreOffset{offset}, n_max, n, sa, nullptr, nullptr,
@@ -532,13 +536,13 @@ int sample_khop3_impl(GraphView g, const uint32_t *input, size_t n_max, Count n,
                        set_mask);
   GGMS_LAUNCH_CHECK();
   const uint32_t fanout_magic = (uint32_t)((0x100000000ull + fanout - 1) / fanout); // ceil(2^32 / fanout)
-  if (insert_into && insert_into->direct)
+  if (insert_into && insert_into->direct && owner_hint)
     hipLaunchKernelGGL(k_gather_neighbours<true>, dim3(grid_for(n_max * fanout, kBlock)), dim3(kBlock), 0, s, g, input,
                        n, fanout, fanout_magic, offset, out_src, out_dst, sm, (unsigned long long *)insert_into->o2n,
-                       insert_into->version);
+                       insert_into->version, owner_hint);
   else
     hipLaunchKernelGGL(k_gather_neighbours<false>, dim3(grid_for(n_max * fanout, kBlock)), dim3(kBlock), 0, s, g, input,
-                       n, fanout, fanout_magic, offset, out_src, out_dst, sm, nullptr, 0u);
+                       n, fanout, fanout_magic, offset, out_src, out_dst, sm, nullptr, 0u, nullptr);
   GGMS_LAUNCH_CHECK();
   return GGMS_OK;
 }
