@@ -45,6 +45,7 @@ def lib():
         _LIB.orc_predict_num_nodes.restype = C.c_size_t
         _LIB.orc_xorwow_next.restype = C.c_uint32
         _LIB.orc_xorwow_uniform.restype = C.c_float
+        _LIB.orc_xorwow_fold.restype = C.c_uint32
         _LIB.orc_xorwow_uniform_double.restype = C.c_double
         _LIB.orc_mt19937_next.restype = C.c_uint32
         _LIB.orc_mt19937_uniform_u32.restype = C.c_uint32
@@ -100,6 +101,31 @@ def xorwow_stream(seed, n):
     st = np.zeros(1, dtype=XORWOW_DTYPE)
     lib().orc_xorwow_init(_p(st), C.c_uint64(int(seed)))
     return np.array([lib().orc_xorwow_next(_p(st)) for _ in range(n)], dtype=np.uint32)
+
+
+def xorwow_draws(state, n):
+    """n curand() draws from a 1-element XORWOW_DTYPE array (advanced in place)."""
+    out = np.empty(int(n), np.uint32)
+    lib().orc_xorwow_draws(_p(state), _sz(n), _p(out))
+    return out
+
+
+def xorwow_uniforms(state, n, double=False):
+    """n curand_uniform() / curand_uniform_double() values (state advanced in place)."""
+    out = np.empty(int(n), np.float64 if double else np.float32)
+    (lib().orc_xorwow_uniform_doubles if double else lib().orc_xorwow_uniforms)(_p(state), _sz(n), _p(out))
+    return out
+
+
+def rocrand_pin():
+    """librocrand_pin.so: rocRAND's host XORWOW engine (third-party pin of the recurrence), or None."""
+    path = os.path.join(_HERE, "librocrand_pin.so")
+    if not os.path.exists(path) or os.path.getmtime(path) < os.path.getmtime(os.path.join(_HERE, "rocrand_pin.cc")):
+        if subprocess.call(["make", "-s", "-C", _HERE, "pin"]) != 0 or not os.path.exists(path):
+            return None
+    p = C.CDLL(path)
+    p.pin_xorwow_fold.restype = C.c_uint32
+    return p
 
 
 def xorwow_next(state):

@@ -62,6 +62,22 @@ double orc_xorwow_uniform_double(orc_xorwow_t *st) {
   return (double)z * k + (k / 2.0);
 }
 
+/* batch forms for the long-stream checks of tests/test_xorwow_pin.py */
+void orc_xorwow_draws(orc_xorwow_t *st, size_t n, uint32_t *out) {
+  for (size_t i = 0; i < n; ++i) out[i] = orc_xorwow_next(st);
+}
+uint32_t orc_xorwow_fold(orc_xorwow_t *st, size_t n) {
+  uint32_t acc = 0;
+  for (size_t i = 0; i < n; ++i) acc = (acc << 1 | acc >> 31) ^ orc_xorwow_next(st);
+  return acc;
+}
+void orc_xorwow_uniforms(orc_xorwow_t *st, size_t n, float *out) {
+  for (size_t i = 0; i < n; ++i) out[i] = orc_xorwow_uniform(st);
+}
+void orc_xorwow_uniform_doubles(orc_xorwow_t *st, size_t n, double *out) {
+  for (size_t i = 0; i < n; ++i) out[i] = orc_xorwow_uniform_double(st);
+}
+
 void orc_random_states_init(orc_xorwow_t *states, size_t num, uint64_t seed) {
   for (size_t t = 0; t < num; ++t) orc_xorwow_init(&states[t], seed + t);
 }

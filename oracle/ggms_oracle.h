@@ -43,6 +43,10 @@ void orc_xorwow_init(orc_xorwow_t *st, uint64_t seed); /* curand_init(seed,0,0) 
 uint32_t orc_xorwow_next(orc_xorwow_t *st);            /* curand()              */
 float orc_xorwow_uniform(orc_xorwow_t *st);            /* curand_uniform()      */
 double orc_xorwow_uniform_double(orc_xorwow_t *st);    /* curand_uniform_double */
+void orc_xorwow_draws(orc_xorwow_t *st, size_t n, uint32_t *out);
+uint32_t orc_xorwow_fold(orc_xorwow_t *st, size_t n);  /* acc = rotl(acc,1) ^ draw */
+void orc_xorwow_uniforms(orc_xorwow_t *st, size_t n, float *out);
+void orc_xorwow_uniform_doubles(orc_xorwow_t *st, size_t n, double *out);
 /* cuda_random_states.cu:36-46: states[t] = curand_init(seed + t, 0, 0) */
 void orc_random_states_init(orc_xorwow_t *states, size_t num, uint64_t seed);
 

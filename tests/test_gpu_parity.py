@@ -43,6 +43,13 @@ def test_xorwow_state_pool(ops):
     got = states_np(st)
     np.testing.assert_array_equal(got[:, 0], want["d"])
     np.testing.assert_array_equal(got[:, 1:], want["v"])
+    # the committed known-answer file (constants + first states; tests/golden/gen_xorwow_golden.py)
+    import json, os
+    gold = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "xorwow_constants.json")))
+    for seed in (0, 1, 0x5EED):
+        one = states_np(ops.random_states(1, seed))[0]
+        assert int(one[0]) == gold["first_states"][str(seed)]["d"]
+        assert [int(x) for x in one[1:]] == gold["first_states"][str(seed)]["v"]
 
 
 # -------------------------------------------------------------- extract
