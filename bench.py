@@ -251,7 +251,7 @@ def main():
     # out of the timed region (inputs are resident in HBM when timing starts)
     all_seeds = [batch_seeds(s) for s in range(args.warmup + args.steps)]
 
-    acc = torch.zeros(3 * L + 1, dtype=torch.int64, device=dev)
+    acc = torch.zeros(3 * L + 2, dtype=torch.int64, device=dev)
     ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(args.steps)]
     host_t = [0.0] * 6
 

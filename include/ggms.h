@@ -53,6 +53,16 @@ enum ggms_dtype {
 
 int ggms_abi_version(void);
 const char *ggms_last_error(void);
+
+/* Device status word (one per device, sticky).  The reference CHECK-aborts when a device-side bound is hit
+ * (logging.cc:69-73); kernels here cannot abort, so they OR a bit into this word and return:
+ *   GGMS_STATUS_SCAN_SPIN   an ordered scan's look-back gave up waiting for a predecessor tile (protocol error);
+ *   GGMS_STATUS_TABLE_FULL  the hashed dedup table had no free bucket for a key (sized too small).
+ * Results of a call that set a bit are invalid.  ggms_sample_batch copies the word into counts_dev[3 L + 1];
+ * ggms_device_status reads it directly (synchronises the device; clear != 0 also zeroes it). */
+#define GGMS_STATUS_SCAN_SPIN 1u
+#define GGMS_STATUS_TABLE_FULL 2u
+int ggms_device_status(uint32_t *status_host, int clear);
 size_t ggms_dtype_bytes(int dtype);
 
 /* ---------------------------------------------------------------------------
@@ -251,6 +261,7 @@ int ggms_map_edges(const ggms_hashtable_t *ht, const ggms_id_t *global_src,
  *   counts_dev[3*i + 1] = num_src(i)    (= unique nodes after layer i)
  *   counts_dev[3*i + 2] = num_dst(i)    (= size of layer i's frontier)
  *   counts_dev[3*L]     = number of input nodes; the list is ht->n2o
+ *   counts_dev[3*L + 1] = device status word after the batch (0 = ok, see ggms_device_status)
  * row[i] = local id of the sampled neighbour, col[i] = local id of the seed
  * (TrainGraph, dist_loops.cc:303-322).  row/col are HOST arrays of L device
  * pointers with the capacities ggms_sample_batch_capacity reports; fanouts is

@@ -57,7 +57,7 @@ def test_reference_python_surface_present():
 
 def test_host_only_entry_points():
     l = xgnn_amd.lib()
-    assert l.ggms_abi_version() == 1
+    assert l.ggms_abi_version() == 2
     # TableSize(num, 2), cuda_hashtable.cu:146-149
     for cap, want in [(2, 8), (3, 8), (4, 16), (1000, 2048), (2288000, 8388608), (8448000, 33554432)]:
         assert l.ggms_hashtable_num_buckets(cap) == want, cap

@@ -38,6 +38,7 @@ _vp, _sz, _u64, _u32, _i = C.c_void_p, C.c_size_t, C.c_uint64, C.c_uint32, C.c_i
 SYMBOLS = {
     "ggms_abi_version": (_i, []),
     "ggms_last_error": (C.c_char_p, []),
+    "ggms_device_status": (_i, [C.POINTER(_u32), _i]),
     "ggms_dtype_bytes": (_sz, [_i]),
     "ggms_random_states_init": (_i, [_vp, _sz, _u64, _vp]),
     "ggms_random_states_count": (_sz, [_i, C.POINTER(_sz), _sz, _sz, _sz]),

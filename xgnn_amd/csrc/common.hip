@@ -1,6 +1,9 @@
 // common.hip -- error plumbing, XORWOW state pool.
+#include <atomic>
 #include <cstdarg>
 #include <cstdio>
+#include <mutex>
+#include <random>
 
 #include "tile_scan.h"
 
@@ -13,6 +16,30 @@ void set_error(const char *fmt, ...) {
   va_start(ap, fmt);
   vsnprintf(g_err, sizeof(g_err), fmt, ap);
   va_end(ap);
+}
+
+// one status word per device, allocated and zeroed on first use
+uint32_t *device_status_word() {
+  static std::mutex mu;
+  static uint32_t *words[64] = {nullptr};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+  std::lock_guard<std::mutex> lock(mu);
+  if (!words[dev]) {
+    uint32_t *p = nullptr;
+    if (hipMalloc((void **)&p, 64) != hipSuccess) return nullptr;
+    if (hipMemset(p, 0, 64) != hipSuccess) return nullptr;
+    words[dev] = p;
+  }
+  return words[dev];
+}
+
+unsigned long long next_dedup_tag() {
+  static std::atomic<unsigned long long> g{[] {
+    std::random_device rd;
+    return (((unsigned long long)rd() << 32) | rd()) | 1ull;
+  }()};
+  return g.fetch_add(1) + 1;
 }
 
 // cuda_random_states.cu:36-46
@@ -30,7 +57,19 @@ using namespace ggms;
 
 extern "C" {
 
-int ggms_abi_version(void) { return 1; }
+int ggms_abi_version(void) { return 2; }
+
+int ggms_device_status(uint32_t *status_host, int clear) {
+  GGMS_CHECK_ARG(status_host);
+  uint32_t *w = device_status_word();
+  if (!w) {
+    set_error("ggms_device_status: no device status word (no device?)");
+    return GGMS_ERR_NO_DEVICE;
+  }
+  GGMS_HIP(hipMemcpy(status_host, w, sizeof(uint32_t), hipMemcpyDeviceToHost)); // synchronises the device
+  if (clear && *status_host) GGMS_HIP(hipMemset(w, 0, sizeof(uint32_t)));
+  return GGMS_OK;
+}
 
 const char *ggms_last_error(void) { return g_err; }
 

@@ -693,7 +693,7 @@ bool Engine::EnqueueOne() {
   SAM_GGMS(ggms_sample_batch(cfg.sample_type, &graph_, b->output_nodes, b->num_seeds, cfg.fanout.data(), L, &P.ht,
                              states_, num_states_, b->row.data(), b->col.data(), b->counts_dev, &extra, P.ws, ws_bytes_,
                              ss));
-  uint64_t *n_in = b->counts_dev + 3 * L, *n_miss = b->counts_dev + 3 * L + 1;
+  uint64_t *n_in = b->counts_dev + 3 * L, *n_miss = b->counts_dev + 3 * L + 2; // [3L + 1] = the batch's status word
   SAM_HIP(hipMemsetAsync(n_miss, 0, 8, ss));
   // input nodes = the table's unique list (task->input_nodes, dist_loops.cc:357); a later batch's sampling
   // overwrites it, so the slot keeps its own copy and the gather below reads that copy
@@ -730,7 +730,16 @@ void Engine::Finish(Batch *b) {
   SAM_HIP(hipEventSynchronize(b->ev_done));
   const uint32_t L = (uint32_t)cfg.fanout.size();
   b->num_input = b->counts[3 * L];
-  b->num_miss = b->counts[3 * L + 1];
+  b->num_miss = b->counts[3 * L + 2];
+  // a kernel of the batch hit a bound it must not hit (include/ggms.h, device status word): the reference
+  // CHECK-aborts in these places (logging.cc:69-73), and so does the engine
+  if (b->counts[3 * L + 1] != 0) {
+    fprintf(stderr, "[samgraph] FATAL: device status %#llx after batch %llu (%s%s): results are invalid\n",
+            (unsigned long long)b->counts[3 * L + 1], (unsigned long long)b->key,
+            (b->counts[3 * L + 1] & GGMS_STATUS_SCAN_SPIN) ? "ordered scan: look-back gave up " : "",
+            (b->counts[3 * L + 1] & GGMS_STATUS_TABLE_FULL) ? "hashed dedup table full" : "");
+    abort();
+  }
   float ms_sample = 0, ms_copy = 0;
   (void)hipEventElapsedTime(&ms_sample, b->ev_start, b->ev_sampled);
   (void)hipEventElapsedTime(&ms_copy, b->ev_sampled, b->ev_done);

@@ -54,6 +54,15 @@ inline int grid_for(size_t n, size_t per_block) {
   return (int)g;
 }
 
+// ---- device status word ---------------------------------------------------------
+// One sticky 32-bit word per device (allocated on first use): a kernel that hits a bound it must not hit
+// ORs a bit in instead of hanging or carrying on silently; ggms_sample_batch copies it into
+// counts_dev[3 L + 1], ggms_device_status() reads it.  The reference CHECK-aborts in these places
+// (logging.cc:69-73); the engine does the same once it has seen the word.
+constexpr uint32_t kErrScanSpin = 1u;    // decoupled look-back gave up waiting for a predecessor tile
+constexpr uint32_t kErrTableFull = 2u;   // hashed dedup table: probing found no free bucket
+uint32_t *device_status_word();          // common.hip; NULL if it cannot be allocated
+
 // ---- a count that lives either in an argument or in device memory ---------
 // Lets a whole mini-batch be enqueued without a host round trip: the size of
 // layer l's frontier is only known on the device when layer l+1 is enqueued.
@@ -145,6 +154,37 @@ struct Xorwow {
     p[0] = d; p[1] = v0; p[2] = v1; p[3] = v2; p[4] = v3; p[5] = v4;
   }
 };
+
+// ---- ordered dedup word (direct-mapped table, one per node id; hashtable.hip has the full story) ---------
+//   { (0x7fffffff - version) : 31 | pending : 1 | value : 32 } under unsigned 64-bit min:
+//   newer version < older, assigned < pending, smaller first index < larger.
+__host__ __device__ __forceinline__ unsigned long long make_w1(uint32_t version, uint32_t pending, uint32_t value) {
+  const unsigned long long hi = ((unsigned long long)(0x7fffffffu - version) << 1) | pending;
+  return (hi << 32) | value;
+}
+
+// Who owns a key without re-reading the table: instance e enters {pending, e} with ONE returning atomicMin.
+//   old < mine : an earlier instance or an assigned id is there  -> e cannot own the key   (cand[e] = 0)
+//   old > mine : e is the smallest so far                         -> candidate              (cand[e] = 1);
+//                if old is a pending word of THIS fill, its instance old.value has just been beaten: the
+//                thief says so in lost[old.value] (each candidate is beaten at most once -- by the next smaller
+//                arrival -- and only thieves write `lost`, only e writes cand[e]: no word has two writers).
+// After the fill (kernel boundary): e owns its key  <=>  cand[e] && lost[e] != tag.  `tag` is a 64-bit launch
+// counter started from a random nonce, so `lost` never needs clearing (a stale or foreign word cannot match).
+struct DedupInsert {
+  unsigned long long *w; // table words, indexed by node id
+  uint32_t version;
+  uint32_t *cand;
+  unsigned long long *lost;
+  unsigned long long tag;
+  __device__ __forceinline__ void enter(uint32_t key, uint32_t e) const {
+    const unsigned long long mine = make_w1(version, 1u, e);
+    const unsigned long long old = atomicMin(w + key, mine);
+    cand[e] = old > mine ? 1u : 0u;
+    if (old > mine && (old >> 32) == (mine >> 32)) lost[(uint32_t)old] = tag;
+  }
+};
+unsigned long long next_dedup_tag(); // common.hip
 
 // ---- wave / block prefix sums (wave64) -------------------------------------
 __device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }

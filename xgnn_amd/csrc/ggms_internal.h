@@ -20,8 +20,8 @@ size_t sample_ws_words(size_t num_input);
 size_t khop0_ws_words(size_t num_input, size_t fanout);
 int sample_khop3_impl(GraphView g, const uint32_t *input, size_t n_max, Count n, uint32_t fanout, uint32_t *out_src,
                       uint32_t *out_dst, uint64_t *num_out_dev, uint32_t *states, uint32_t *workspace,
-                      const uint32_t *seed_local, int src_local, const ggms_hashtable_t *insert_into, hipStream_t s,
-                      ScanArea *shared_scan = nullptr, uint32_t *owner_hint = nullptr);
+                      const uint32_t *seed_local, int src_local, hipStream_t s, ScanArea *shared_scan = nullptr,
+                      const DedupInsert *insert = nullptr);
 int sample_khop0_impl(GraphView g, const uint32_t *input, size_t n_max, Count n, uint32_t fanout, uint32_t *out_src,
                       uint32_t *out_dst, uint64_t *num_out_dev, uint32_t *workspace, const uint32_t *seed_local,
                       int src_local, hipStream_t s, ScanArea *shared_scan = nullptr);
@@ -60,12 +60,24 @@ struct BatchPrologue {
   uint32_t *num_items;
   uint64_t *record_n;
 };
-// insert + ordered local-id assignment; item_pos[i] = bucket of input[i] (hashed layout only).
+// the end-of-batch id look-ups of the instances that do not own their key: one job per layer
+struct MapRestJobs {
+  uint32_t *row[16];
+  const uint32_t *key[16];
+  const uint64_t *num[16];
+};
+int launch_map_rest_all(const ggms_hashtable_t *ht, const MapRestJobs &jobs, uint32_t num_jobs, size_t max_items,
+                        uint64_t *status_out, hipStream_t s);
+size_t owner_scan_tiles(size_t n_max);
+// insert + ordered local-id assignment.  item_pos: n_max words (hashed layout: bucket of input[i]; direct layout:
+// the insert's `cand` flags); lost: n_max 64-bit words (direct layout).
 // mirror_a/b (optional): 64-bit device slots that also receive the new item count.
-// mapped (optional): mapped[i] = local id of input[i] (the dst half of GPUMapEdges, fused).
-// inserted = true: the producer of `input` already entered every item (k_gather_neighbours<true>).
+// mapped (optional): mapped[i] = local id of input[i] (the dst half of GPUMapEdges, fused); with defer_rest the
+// instances that do not own their key keep kEmptyKey for the caller's launch_map_rest_all.
+// pre (direct layout): the producer of `input` already entered every item (fused sampler).
 int ht_fill_impl(const ggms_hashtable_t *ht, const uint32_t *input, size_t n_max, Count n, uint32_t *item_pos,
-                 ScanArea scan, uint64_t *mirror_a, uint64_t *mirror_b, hipStream_t s, uint32_t *mapped = nullptr,
-                 const BatchPrologue *prologue = nullptr, bool inserted = false);
+                 unsigned long long *lost, ScanArea scan, uint64_t *mirror_a, uint64_t *mirror_b, hipStream_t s,
+                 uint32_t *mapped = nullptr, const BatchPrologue *prologue = nullptr, const DedupInsert *pre = nullptr,
+                 bool defer_rest = false);
 
 } // namespace ggms

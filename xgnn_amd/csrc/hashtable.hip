@@ -31,10 +31,6 @@ __device__ __forceinline__ unsigned long long make_w0(uint32_t version, uint32_t
   return ((unsigned long long)key << 32) | version;
 }
 __device__ __forceinline__ uint32_t w0_version(unsigned long long w) { return (uint32_t)w; }
-__device__ __forceinline__ unsigned long long make_w1(uint32_t version, uint32_t pending, uint32_t value) {
-  const unsigned long long hi = ((unsigned long long)(0x7fffffffu - version) << 1) | pending;
-  return (hi << 32) | value;
-}
 
 // Two layouts share the w1 word and all the ordering logic:
 //   hashed : o2n = buckets {w0, w1} (16 B), open addressing, the reference's sizing;
@@ -54,12 +50,18 @@ struct Table {
     return DIRECT ? (w + pos) : (w + 2ull * pos + 1);
   }
 
-  // hashed only: bucket position of `key`, inserting it if absent
-  __device__ __forceinline__ uint32_t find_or_claim(uint32_t key) const {
+  // hashed only: bucket position of `key`, inserting it if absent.  The probe sequence (triangular steps over a
+  // power-of-two table) visits every bucket once in mask + 1 steps: after that the table is full -- the reference
+  // would spin forever / trip its assert; here kErrTableFull goes into the status word and 0xffffffff comes back.
+  __device__ __forceinline__ uint32_t find_or_claim(uint32_t key, uint32_t *err) const {
     uint32_t pos = key & mask;
     uint32_t delta = 1;
     const unsigned long long want = make_w0(version, key);
     for (;;) {
+      if (delta > mask + 1u) {
+        if (err) atomicOr(err, kErrTableFull);
+        return 0xffffffffu;
+      }
       unsigned long long *p0 = w + 2ull * pos;
       unsigned long long cur = *p0;
       if (w0_version(cur) != version) {
@@ -94,7 +96,8 @@ struct Table {
 // pro: the batch prologue rides on the first kernel of a batch (three 5-us launches less)
 template <bool DIRECT>
 __global__ __launch_bounds__(kBlock) void k_ht_insert(Table t, const uint32_t *__restrict__ items, Count n_arg,
-                                                      uint32_t *__restrict__ item_pos, BatchPrologue pro) {
+                                                      uint32_t *__restrict__ item_pos, BatchPrologue pro,
+                                                      DedupInsert di, uint32_t *err) {
   const uint64_t n = n_arg.get();
   if (blockIdx.x == 0) {
     for (uint32_t z = threadIdx.x; z < pro.num_zero; z += kBlock) pro.zero_words[z] = 0u;
@@ -105,27 +108,26 @@ __global__ __launch_bounds__(kBlock) void k_ht_insert(Table t, const uint32_t *_
   }
   for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (uint64_t)gridDim.x * kBlock) {
     const uint32_t key = items[i];
-    uint32_t pos = key;
-    if (!DIRECT) {
-      pos = t.find_or_claim(key);
+    if (DIRECT) {
+      di.enter(key, (uint32_t)i); // one returning atomicMin; cand / lost say who owns the key (ggms_device.h)
+    } else {
+      const uint32_t pos = t.find_or_claim(key, err);
       item_pos[i] = pos;
+      if (pos != 0xffffffffu) atomicMin(t.w1<false>(pos), make_w1(t.version, 1u, (uint32_t)i));
     }
-    atomicMin(t.w1<DIRECT>(pos), make_w1(t.version, 1u, (uint32_t)i));
   }
 }
 
-// count_hashmap / compact_hashmap (cuda_hashtable.cu:197-232, 406-458):
+// count_hashmap / compact_hashmap (cuda_hashtable.cu:197-232, 406-458), hashed layout:
 // instance i owns its key iff the word still says {pending, i}
-// hint (optional, direct layout): hint[i] == 0 means the inserting atomicMin already saw a smaller word, i.e. an earlier
-// instance or an assigned id -- instance i cannot own the key and its word need not be read again
 template <bool DIRECT>
 struct OwnerFlag {
   Table t;
-  const uint32_t *item_pos; // hashed: bucket positions; direct: the keys themselves
-  const uint32_t *hint;
+  const uint32_t *item_pos; // bucket positions
   __device__ __forceinline__ uint32_t operator()(uint64_t i) const {
-    if (DIRECT && hint && hint[i] == 0u) return 0u;
-    return *t.w1<DIRECT>(item_pos[i]) == make_w1(t.version, 1u, (uint32_t)i) ? 1u : 0u;
+    const uint32_t pos = item_pos[i];
+    if (pos == 0xffffffffu) return 0u; // table full (status word set): the item is dropped
+    return *t.w1<DIRECT>(pos) == make_w1(t.version, 1u, (uint32_t)i) ? 1u : 0u;
   }
 };
 // mapped (optional): local id of instance i -- known right here for the owners; the others get kEmptyKey and
@@ -175,23 +177,180 @@ static inline Table table_of(const ggms_hashtable_t *ht) {
   return Table{(unsigned long long *)ht->o2n, ht->n2o, (uint32_t)(ht->o2n_size - 1), ht->version};
 }
 
-// the instances that do not own their key (AssignLocal left kEmptyKey): read the owner's local id
+// the instances that do not own their key (AssignLocal / k_owner_scan left kEmptyKey): read the owner's local id
 template <bool DIRECT>
 __global__ __launch_bounds__(kBlock) void k_map_rest(Table t, const uint32_t *__restrict__ item_pos, Count n_arg,
                                                      uint32_t *__restrict__ out) {
   const uint64_t n = n_arg.get();
   for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (uint64_t)gridDim.x * kBlock)
-    if (out[i] == kEmptyKey) out[i] = (uint32_t)*t.w1<DIRECT>(item_pos[i]);
+    if (out[i] == kEmptyKey) {
+      const uint32_t pos = item_pos[i];
+      if (DIRECT || pos != 0xffffffffu) out[i] = (uint32_t)*t.w1<DIRECT>(pos);
+    }
 }
 
-size_t ht_ws_words(size_t num_input) { return num_input + tile_scan_words(num_input) + 16; }
+// Same for every layer of a batch in ONE launch (blockIdx.y = layer): an assigned word never changes within a
+// batch, so the look-ups of all layers can wait until the last fill is done.  Also hands the device status word
+// to the batch's counts (counts_dev[3 L + 1]).
+__global__ __launch_bounds__(kBlock) void k_map_rest_all(const unsigned long long *__restrict__ w, MapRestJobs jobs,
+                                                         const uint32_t *status, uint64_t *status_out) {
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && status_out) *status_out = status ? *status : 0u;
+  const uint32_t l = blockIdx.y;
+  uint32_t *__restrict__ row = jobs.row[l];
+  const uint32_t *__restrict__ key = jobs.key[l];
+  const uint64_t n = *jobs.num[l];
+  for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (uint64_t)gridDim.x * kBlock)
+    if (row[i] == kEmptyKey) row[i] = (uint32_t)w[key[i]];
+}
+
+// ---- direct layout: owners -> local ids, one launch -----------------------------------------------------------
+// count_hashmap + scan + compact_hashmap (cuda_hashtable.cu:197-232, 406-458, 812-827) as ONE single-pass ordered
+// scan.  Ownership comes from the insert's own return values (DedupInsert: cand / lost), so the pass reads three
+// coalesced streams and touches the table only to WRITE the owners' assigned words.  A thread owns 8 consecutive
+// items (two 16-byte loads per stream), a tile is 2048 items; tiles are taken from a ticket and chained by
+// decoupled look-back (tile_scan.h).  mapped[i] = local id for the owners, kEmptyKey for the rest (looked up later).
+constexpr uint32_t kOwnItems = 8, kOwnTile = kOwnItems * kBlock;
+
+__global__ __launch_bounds__(kBlock) void k_owner_scan(unsigned long long *__restrict__ w, uint32_t version,
+                                                       uint32_t *__restrict__ n2o,
+                                                       const uint32_t *__restrict__ items,
+                                                       const uint32_t *__restrict__ cand,
+                                                       const unsigned long long *__restrict__ lost,
+                                                       unsigned long long tag, uint32_t *__restrict__ mapped,
+                                                       Count n_arg, uint32_t *ctl, unsigned long long *desc,
+                                                       uint32_t epoch, uint32_t *num_items, uint64_t *mirror_a,
+                                                       uint64_t *mirror_b, uint32_t *err) {
+  constexpr uint32_t FLAG_A = 1, FLAG_P = 2;
+  __shared__ uint32_t smem[kBlock / kWave];
+  __shared__ uint32_t s_tile, s_prefix;
+  const uint64_t n = n_arg.get();
+  const uint64_t num_tiles = (n + kOwnTile - 1) / kOwnTile;
+  const uint32_t base = *num_items; // only the block that takes tile 0 uses it; the total is written last of all
+  // 16-byte accesses need 16-byte aligned streams (workspace pieces are; a caller's sliced tensor may not be)
+  const bool vec_ok = ((((uintptr_t)items) | ((uintptr_t)cand) | ((uintptr_t)lost) | ((uintptr_t)mapped)) & 15u) == 0;
+  for (;;) {
+    if (threadIdx.x == 0) s_tile = atomicAdd(&ctl[0], 1u);
+    __syncthreads();
+    const uint64_t tile = s_tile;
+    if (tile >= num_tiles) break;
+    const uint64_t i0 = tile * kOwnTile + (uint64_t)threadIdx.x * kOwnItems;
+    uint32_t key[kOwnItems], flag[kOwnItems];
+    if (vec_ok && i0 + kOwnItems <= n) {
+      const uint4 c0 = *reinterpret_cast<const uint4 *>(cand + i0), c1 = *reinterpret_cast<const uint4 *>(cand + i0 + 4);
+      const uint4 k0 = *reinterpret_cast<const uint4 *>(items + i0), k1 = *reinterpret_cast<const uint4 *>(items + i0 + 4);
+      const ulonglong2 l0 = *reinterpret_cast<const ulonglong2 *>(lost + i0);
+      const ulonglong2 l1 = *reinterpret_cast<const ulonglong2 *>(lost + i0 + 2);
+      const ulonglong2 l2 = *reinterpret_cast<const ulonglong2 *>(lost + i0 + 4);
+      const ulonglong2 l3 = *reinterpret_cast<const ulonglong2 *>(lost + i0 + 6);
+      key[0] = k0.x; key[1] = k0.y; key[2] = k0.z; key[3] = k0.w; key[4] = k1.x; key[5] = k1.y; key[6] = k1.z; key[7] = k1.w;
+      flag[0] = c0.x && l0.x != tag; flag[1] = c0.y && l0.y != tag; flag[2] = c0.z && l1.x != tag;
+      flag[3] = c0.w && l1.y != tag; flag[4] = c1.x && l2.x != tag; flag[5] = c1.y && l2.y != tag;
+      flag[6] = c1.z && l3.x != tag; flag[7] = c1.w && l3.y != tag;
+    } else {
+#pragma unroll
+      for (uint32_t k = 0; k < kOwnItems; ++k) {
+        const uint64_t i = i0 + k;
+        key[k] = i < n ? items[i] : 0u;
+        flag[k] = (i < n && cand[i] && lost[i] != tag) ? 1u : 0u;
+      }
+    }
+    uint32_t mine = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < kOwnItems; ++k) mine += flag[k];
+    uint32_t running;
+    const uint32_t excl = block_exclusive_scan(mine, smem, running);
+    if (threadIdx.x < kWave) { // wave 0 publishes the tile and looks back
+      const uint32_t lane = threadIdx.x;
+      uint32_t prefix = base;
+      if (tile == 0) {
+        if (lane == 0)
+          __hip_atomic_store(&desc[0], scan_desc(epoch, FLAG_P, base + running), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      } else {
+        if (lane == 0)
+          __hip_atomic_store(&desc[tile], scan_desc(epoch, FLAG_A, running), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        prefix = scan_lookback(desc, tile, epoch, err);
+        if (lane == 0)
+          __hip_atomic_store(&desc[tile], scan_desc(epoch, FLAG_P, prefix + running), __ATOMIC_RELAXED,
+                             __HIP_MEMORY_SCOPE_AGENT);
+      }
+      if (lane == 0) {
+        s_prefix = prefix;
+        if (tile + 1 == num_tiles) {
+          const uint32_t total = prefix + running;
+          *num_items = total;
+          if (mirror_a) *mirror_a = (uint64_t)total;
+          if (mirror_b) *mirror_b = (uint64_t)total;
+        }
+      }
+    }
+    __syncthreads();
+    uint32_t local = s_prefix + excl;
+    uint32_t out[kOwnItems];
+#pragma unroll
+    for (uint32_t k = 0; k < kOwnItems; ++k) {
+      out[k] = kEmptyKey;
+      if (flag[k]) {
+        w[key[k]] = make_w1(version, 0u, local);
+        n2o[local] = key[k];
+        out[k] = local++;
+      }
+    }
+    if (mapped) {
+      if (vec_ok && i0 + kOwnItems <= n) {
+        *reinterpret_cast<uint4 *>(mapped + i0) = make_uint4(out[0], out[1], out[2], out[3]);
+        *reinterpret_cast<uint4 *>(mapped + i0 + 4) = make_uint4(out[4], out[5], out[6], out[7]);
+      } else {
+#pragma unroll
+        for (uint32_t k = 0; k < kOwnItems; ++k)
+          if (i0 + k < n) mapped[i0 + k] = out[k];
+      }
+    }
+    __syncthreads(); // s_tile / s_prefix are rewritten next iteration
+  }
+  if (threadIdx.x == 0) {
+    if (num_tiles == 0 && blockIdx.x == 0) { // empty input: the count stays what it is
+      if (mirror_a) *mirror_a = (uint64_t)base;
+      if (mirror_b) *mirror_b = (uint64_t)base;
+    }
+    if (atomicAdd(&ctl[1], 1u) == gridDim.x - 1) { // the last block out re-arms the control words
+      ctl[0] = 0;
+      ctl[1] = 0;
+    }
+  }
+}
+
+// descriptors the owner scan needs for n_max items (64-bit words behind the 8 control words)
+size_t owner_scan_tiles(size_t n_max) { return (n_max + kOwnTile - 1) / kOwnTile; }
+
+// workspace of one fill: cand / item_pos [n], lost [n] (64-bit), scan area
+size_t ht_ws_words(size_t num_input) { return 3 * num_input + tile_scan_words(num_input) + 24; }
+
+__global__ void k_status_copy(const uint32_t *status, uint64_t *status_out) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) *status_out = status ? *status : 0u;
+}
+
+int launch_map_rest_all(const ggms_hashtable_t *ht, const MapRestJobs &jobs, uint32_t num_jobs, size_t max_items,
+                        uint64_t *status_out, hipStream_t s) {
+  if (num_jobs == 0) { // nothing deferred (hashed layout, or no layer could sample): only the status word
+    hipLaunchKernelGGL(k_status_copy, dim3(1), dim3(64), 0, s, (const uint32_t *)device_status_word(), status_out);
+    GGMS_LAUNCH_CHECK();
+    return GGMS_OK;
+  }
+  const int gx = grid_for(max_items ? max_items : 1, kBlock);
+  hipLaunchKernelGGL(k_map_rest_all, dim3(gx, num_jobs), dim3(kBlock), 0, s, (const unsigned long long *)ht->o2n, jobs,
+                     (const uint32_t *)device_status_word(), status_out);
+  GGMS_LAUNCH_CHECK();
+  return GGMS_OK;
+}
 
 // mapped != NULL: also produce the local id of every input instance (FillWithDuplicates + the dst half of
-// GPUMapEdges in one go): owners write theirs while assigning, k_map_rest looks up the rest.
-// clear_area: this is the first kernel of a batch -- it also zeroes the shared scan area's control words.
+// GPUMapEdges in one go): owners write theirs while assigning, the rest is looked up afterwards -- here
+// (k_map_rest) or, with defer_rest, by the caller's k_map_rest_all at the end of the batch (direct layout only).
+// prologue: this is the first kernel of a batch -- it also zeroes the shared scan area's control words.
+// pre (direct layout): the producer of `input` already entered every item with these cand / lost / tag.
 int ht_fill_impl(const ggms_hashtable_t *ht, const uint32_t *input, size_t n_max, Count n, uint32_t *item_pos,
-                 ScanArea scratch, uint64_t *mirror_a, uint64_t *mirror_b, hipStream_t s, uint32_t *mapped,
-                 const BatchPrologue *prologue, bool inserted) {
+                 unsigned long long *lost, ScanArea scratch, uint64_t *mirror_a, uint64_t *mirror_b, hipStream_t s,
+                 uint32_t *mapped, const BatchPrologue *prologue, const DedupInsert *pre, bool defer_rest) {
   BatchPrologue pro{nullptr, 0, nullptr, nullptr};
   if (prologue) pro = *prologue;
   if (n_max == 0) { // no kernel to ride on
@@ -201,28 +360,42 @@ int ht_fill_impl(const ggms_hashtable_t *ht, const uint32_t *input, size_t n_max
     return GGMS_OK;
   }
   Table t = table_of(ht);
+  uint32_t *err = device_status_word();
   const int grid = grid_for(n_max, kBlock);
   int rc;
   if (ht->direct) {
-    if (!inserted) {
-      hipLaunchKernelGGL(k_ht_insert<true>, dim3(grid), dim3(kBlock), 0, s, t, input, n, item_pos, pro);
+    DedupInsert di{(unsigned long long *)ht->o2n, ht->version, item_pos, lost, 0ull};
+    if (pre) {
+      di = *pre;
+    } else {
+      di.tag = next_dedup_tag();
+      hipLaunchKernelGGL(k_ht_insert<true>, dim3(grid), dim3(kBlock), 0, s, t, input, n, item_pos, pro, di, err);
       GGMS_LAUNCH_CHECK();
     }
-    scratch.stash = item_pos; // the direct layout does not use item_pos: it holds the owner flags between passes
-    rc = tile_scan(OwnerFlag<true>{t, input, inserted ? item_pos : nullptr}, AssignLocal<true>{t, input, input, mapped},
-                   n_max, n, scratch,
-                   ht->num_items_dev, ht->num_items_dev, nullptr, s, mirror_a, mirror_b);
-  } else {
-    hipLaunchKernelGGL(k_ht_insert<false>, dim3(grid), dim3(kBlock), 0, s, t, input, n, item_pos, pro);
+    uint32_t *ctl = scan_align(scratch.words);
+    unsigned long long *desc = reinterpret_cast<unsigned long long *>(ctl + 8);
+    if (!scratch.cleared) {
+      GGMS_HIP(hipMemsetAsync(ctl, 0, (8 + 2 * (owner_scan_tiles(n_max) + 1)) * sizeof(uint32_t), s));
+    }
+    hipLaunchKernelGGL(k_owner_scan, dim3(grid_for(owner_scan_tiles(n_max), 1)), dim3(kBlock), 0, s, di.w, di.version,
+                       ht->n2o, input, di.cand, di.lost, di.tag, mapped, n, ctl, desc, next_scan_epoch(),
+                       ht->num_items_dev, mirror_a, mirror_b, err);
     GGMS_LAUNCH_CHECK();
-    rc = tile_scan(OwnerFlag<false>{t, item_pos, nullptr}, AssignLocal<false>{t, input, item_pos, mapped}, n_max, n, scratch,
+    rc = GGMS_OK;
+  } else {
+    hipLaunchKernelGGL(k_ht_insert<false>, dim3(grid), dim3(kBlock), 0, s, t, input, n, item_pos, pro,
+                       DedupInsert{nullptr, 0, nullptr, nullptr, 0ull}, err);
+    GGMS_LAUNCH_CHECK();
+    rc = tile_scan(OwnerFlag<false>{t, item_pos}, AssignLocal<false>{t, input, item_pos, mapped}, n_max, n, scratch,
                    ht->num_items_dev, ht->num_items_dev, nullptr, s, mirror_a, mirror_b);
   }
   if (rc != GGMS_OK || !mapped) return rc;
-  if (ht->direct)
+  if (ht->direct) {
+    if (defer_rest) return GGMS_OK;
     hipLaunchKernelGGL(k_map_rest<true>, dim3(grid), dim3(kBlock), 0, s, t, input, n, mapped);
-  else
+  } else {
     hipLaunchKernelGGL(k_map_rest<false>, dim3(grid), dim3(kBlock), 0, s, t, item_pos, n, mapped);
+  }
   GGMS_LAUNCH_CHECK();
   return GGMS_OK;
 }
@@ -266,7 +439,7 @@ int ggms_hashtable_reset(ggms_hashtable_t *ht, ggms_stream_t stream) {
 }
 
 size_t ggms_hashtable_workspace_bytes(size_t num_input) {
-  // item_pos[num_input] + tile scan scratch
+  // item_pos / cand [num_input] + lost [num_input] (64-bit) + scan scratch
   return ht_ws_words(num_input) * sizeof(uint32_t);
 }
 
@@ -280,8 +453,10 @@ int ggms_hashtable_fill_with_duplicates(ggms_hashtable_t *ht, const ggms_id_t *i
     GGMS_CHECK_ARG(workspace_bytes >= ggms_hashtable_workspace_bytes(num_input));
     GGMS_CHECK_ARG(num_input < (1ull << 32));
     uint32_t *item_pos = (uint32_t *)workspace;
-    int rc = ht_fill_impl(ht, input, num_input, count_of(num_input), item_pos,
-                          ScanArea{item_pos + num_input, false}, nullptr, nullptr, s, nullptr, nullptr);
+    unsigned long long *lost = (unsigned long long *)(((uintptr_t)(item_pos + num_input) + 15) & ~(uintptr_t)15);
+    uint32_t *scan_words = (uint32_t *)(lost + num_input);
+    int rc = ht_fill_impl(ht, input, num_input, count_of(num_input), item_pos, lost, ScanArea{scan_words, false},
+                          nullptr, nullptr, s, nullptr, nullptr, nullptr, false);
     if (rc != GGMS_OK) return rc;
   }
   if (unique_out) {

@@ -104,16 +104,41 @@ static size_t sampler_ws_words(int sample_type, const BatchCaps &c, const size_t
   return w;
 }
 
+// ---- workspace layout of one batch (uint32 words; every piece starts 16-byte aligned) --------------------------
+struct BatchLayout {
+  size_t seed_local, samp_ws, tmp_dst[16], cand, lost, scan, total;
+  size_t dedup_items; // entries of cand / lost
+  size_t scan_tiles;  // descriptors the scans of the batch may use (cleared by the batch prologue)
+};
+static inline size_t up4(size_t w) { return (w + 3) & ~(size_t)3; }
+
+static BatchLayout layout_of(int sample_type, size_t num_seeds, const size_t *fanouts, uint32_t L, const BatchCaps &c,
+                             const ggms_sample_extra_t *extra) {
+  BatchLayout l{};
+  size_t w = 0;
+  l.seed_local = w;  w += up4(num_seeds + 16);
+  l.samp_ws = w;     w += up4(sampler_ws_words(sample_type, c, fanouts, L, extra));
+  for (uint32_t i = 0; i < L; ++i) { // global neighbour ids of every layer: kept for the end-of-batch id look-ups
+    l.tmp_dst[i] = w;
+    w += up4(c.max_edges[i] + 16);
+  }
+  l.dedup_items = std::max(c.max_e_all, num_seeds);
+  l.cand = w;        w += up4(l.dedup_items + 16);          // hashed layout: bucket positions
+  l.lost = w;        w += up4(2 * (l.dedup_items + 16));    // 64-bit tags
+  // ONE scan area for the batch: sampler offsets (tiles of 128 seeds), owner scans (tiles of 2048 items), the
+  // generic tile scans of the other samplers (<= kSinglePassTiles descriptors, else three launches)
+  l.scan_tiles = std::max<size_t>({c.max_in_all / 128 + 2, owner_scan_tiles(l.dedup_items) + 2, kSinglePassTiles + 2});
+  l.scan = w;
+  w += up4(std::max(tile_scan_words(std::max(c.max_e_all, c.max_in_all)), 8 + 2 * l.scan_tiles + 4) + 16);
+  l.total = w;
+  return l;
+}
+
 size_t ggms_sample_batch_workspace_bytes(int sample_type, size_t num_seeds, const size_t *fanouts, uint32_t num_layer,
                                          const ggms_sample_extra_t *extra) {
   if (!fanouts || num_layer < 1 || num_layer > 16) return 0;
   const BatchCaps c = caps_of(num_seeds, fanouts, num_layer);
-  const size_t words = num_seeds + 16                      // seed_local
-                       + sampler_ws_words(sample_type, c, fanouts, num_layer, extra) // sampler scratch
-                       + c.max_e_all + 16                  // global neighbour ids of the layer
-                       + c.max_e_all + 16                  // item_pos (hashed table layout)
-                       + tile_scan_words(std::max(c.max_e_all, c.max_in_all)) + 16; // ONE scan area for the batch
-  return words * sizeof(uint32_t);
+  return layout_of(sample_type, num_seeds, fanouts, num_layer, c, extra).total * sizeof(uint32_t) + 16;
 }
 
 int ggms_sample_batch(int sample_type, const ggms_graph_t *graph, const ggms_id_t *seeds, size_t num_seeds,
@@ -154,19 +179,15 @@ int ggms_sample_batch(int sample_type, const ggms_graph_t *graph, const ggms_id_
     for (uint32_t i = 0; i < num_layer; ++i) GGMS_CHECK_ARG(fanouts[i] > 0 && fanouts[i] < 128);
   }
 
-  uint32_t *w = (uint32_t *)workspace;
-  uint32_t *seed_local = w;            w += num_seeds + 16;
-  uint32_t *samp_ws = w;               w += sampler_ws_words(sample_type, c, fanouts, num_layer, extra);
-  uint32_t *tmp_dst = w;               w += c.max_e_all + 16;
-  uint32_t *item_pos = w;              w += c.max_e_all + 16;
+  const BatchLayout lay = layout_of(sample_type, num_seeds, fanouts, num_layer, c, extra);
+  uint32_t *w = (uint32_t *)(((uintptr_t)workspace + 15) & ~(uintptr_t)15);
+  uint32_t *seed_local = w + lay.seed_local;
+  uint32_t *samp_ws = w + lay.samp_ws;
+  uint32_t *item_pos = w + lay.cand;
+  unsigned long long *lost = reinterpret_cast<unsigned long long *>(w + lay.lost);
   // every ordered scan of the batch (seed offsets, owner flags) shares one control/descriptor area that is
   // cleared once here: descriptors are epoch-tagged, the control words re-arm themselves
-  ScanArea scan{w, true};
-  const size_t scan_items = std::max(c.max_e_all, c.max_in_all);
-  if (scan_mode() == 1) { // every scan single-pass: the whole descriptor region, by memset
-    int rc0 = clear_scan_area(scan.words, scan_items, s);
-    if (rc0 != GGMS_OK) return rc0;
-  }
+  ScanArea scan{w + lay.scan, true};
 
   const GraphView g = view_of(graph);
   // hash_table->Reset (dist_loops.cc:105): a new version stamp; the item count is zeroed by the prologue below
@@ -178,15 +199,20 @@ int ggms_sample_batch(int sample_type, const ggms_graph_t *graph, const ggms_id_
   // FillWithDupRevised(seeds), dist_loops.cc:110-111, + the local ids of the raw seeds (they may repeat): the
   // first layer's `col`.  Its insert kernel is the first kernel of the batch and carries the prologue:
   // scan-area clear, item count reset, num_dst of the first layer = |seeds| (dist_loops.cc:305).
-  const BatchPrologue pro{scan_align(scan.words), (uint32_t)scan_clear_words(scan_items), ht->num_items_dev,
-                          counts_dev + 3 * (num_layer - 1) + 2};
-  int rc = ht_fill_impl(ht, seeds, num_seeds, count_of(num_seeds), item_pos, scan, nullptr, nullptr, s, seed_local,
-                        &pro);
+  const size_t clear_words = scan_mode() == 1 ? 8 + 2 * (num_tiles_for(std::max(c.max_e_all, c.max_in_all)) + 1) : 0;
+  const BatchPrologue pro{scan_align(scan.words), (uint32_t)std::max<size_t>(8 + 2 * lay.scan_tiles, clear_words),
+                          ht->num_items_dev, counts_dev + 3 * (num_layer - 1) + 2};
+  int rc = ht_fill_impl(ht, seeds, num_seeds, count_of(num_seeds), item_pos, lost, scan, nullptr, nullptr, s,
+                        seed_local, &pro);
   if (rc != GGMS_OK) return rc;
 
+  MapRestJobs jobs{};
+  uint32_t num_jobs = 0;
+  size_t job_items = 0;
   for (int i = (int)num_layer - 1; i >= 0; --i) {
     const bool first = (i == (int)num_layer - 1);
     const uint32_t *input = first ? seeds : ht->n2o;
+    uint32_t *tmp_dst = w + lay.tmp_dst[i];
     const size_t n_max = c.max_input[i], e_max = c.max_edges[i];
     const Count n = first ? count_of(num_seeds) : count_of32(n_max, ht->num_items_dev);
     uint64_t *num_edge = counts_dev + 3 * i + 0;
@@ -195,13 +221,16 @@ int ggms_sample_batch(int sample_type, const ggms_graph_t *graph, const ggms_id_
                                : counts_dev + 3 * num_layer;          // = number of input nodes
     // batch order on the shared RNG pool (and on khop2's CSR): only the sampler kernels are ordered
     if (first && extra && extra->rng_wait) GGMS_HIP(hipStreamWaitEvent(s, (hipEvent_t)extra->rng_wait, 0));
-    bool inserted = false; // the sampler entered its output into the table itself
+    // direct table + khop3: the sampler enters its output into the table itself (DedupInsert)
+    DedupInsert pre{(unsigned long long *)ht->o2n, ht->version, item_pos, lost, 0ull};
+    bool inserted = false;
     if (n_max == 0) {
       GGMS_HIP(hipMemsetAsync(num_edge, 0, sizeof(uint64_t), s));
     } else if (sample_type == GGMS_KHOP3) {
+      inserted = ht->direct != 0 && e_max != 0;
+      if (inserted) pre.tag = next_dedup_tag();
       rc = sample_khop3_impl(g, input, n_max, n, (uint32_t)fanouts[i], col[i], tmp_dst, num_edge, (uint32_t *)states,
-                             samp_ws, first ? seed_local : nullptr, 1, ht, s, &scan, item_pos);
-      inserted = ht->direct != 0;
+                             samp_ws, first ? seed_local : nullptr, 1, s, &scan, inserted ? &pre : nullptr);
     } else if (sample_type == GGMS_KHOP0) {
       rc = sample_khop0_impl(g, input, n_max, n, (uint32_t)fanouts[i], col[i], tmp_dst, num_edge, samp_ws,
                              first ? seed_local : nullptr, 1, s, &scan);
@@ -241,10 +270,20 @@ int ggms_sample_batch(int sample_type, const ggms_graph_t *graph, const ggms_id_
       continue;
     }
     // FillWithDuplicates (:279) + the dst half of GPUMapEdges (:296): row[i] = local id of every sampled neighbour
-    rc = ht_fill_impl(ht, tmp_dst, e_max, ne, item_pos, scan, num_src, next_dst, s, row[i], nullptr, inserted);
+    // (direct table: the instances that do not own their key are resolved for all layers at once, below)
+    rc = ht_fill_impl(ht, tmp_dst, e_max, ne, item_pos, lost, scan, num_src, next_dst, s, row[i], nullptr,
+                      inserted ? &pre : nullptr, ht->direct != 0);
     if (rc != GGMS_OK) return rc;
+    if (ht->direct) {
+      jobs.row[num_jobs] = row[i];
+      jobs.key[num_jobs] = tmp_dst;
+      jobs.num[num_jobs] = num_edge;
+      ++num_jobs;
+      job_items = std::max(job_items, e_max);
+    }
   }
-  return GGMS_OK;
+  // the rest of GPUMapEdges' dst half for every layer + the batch's status word (counts_dev[3 L + 1])
+  return launch_map_rest_all(ht, jobs, num_jobs, job_items, counts_dev + 3 * num_layer + 1, s);
 }
 
 } // extern "C"

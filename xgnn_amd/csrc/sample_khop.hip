@@ -25,6 +25,7 @@
 //     (khop0.cu:144-148) becomes an LDS atomicMax on the candidate position, i.e.
 //     highest-j-wins, deterministic.
 #include <algorithm>
+#include <atomic>
 
 #include "ggms_internal.h"
 
@@ -50,20 +51,24 @@ struct StoreOffset {
 // Group (b, y) of the reference grid == stream id i = 8 b + y; it serves seeds
 // 128 b + y + 8 k, k = 0..15, in that order (khop3.cu:86-89,106).
 //
-// Two launches:
-//   k_khop3_positions   the reference's own geometry -- 16 lanes per stream, 8 streams per
-//                       128-thread block -- but the 16 lanes do useful work.  The stream is
-//                       serial only in its XORWOW recurrence (9 ALU ops per draw); everything
-//                       else is done 16 draws at a time: every lane of the group steps the
-//                       generator 16 times and keeps draw number `lig`, then the 16 candidates
-//                       are reduced mod deg, looked up in the group's LDS set, de-duplicated
-//                       against EARLIER candidates with DPP row shifts (first occurrence wins,
-//                       exactly what the one-draw-at-a-time loop of khop3.cu:125-131 yields),
-//                       ranked with a ballot, and the accepted ones written in rank order.
-//                       If the set completes at candidate t*, the generator is rewound to just
-//                       after draw t*, so the stream position is the reference's.
-//                       Writes POSITIONS (index into the neighbour list), no neighbour loads.
-//   k_gather_neighbours flat over edges: out_dst[e] = neighbours(seed)[out_dst[e]].
+// ONE launch per layer (k_khop3_fused); a workgroup takes reference block b (128 seeds) from a ticket and
+//   1. loads the 128 seeds' neighbour-list heads (pointer, degree) into LDS -- the only time they are read;
+//   2. scans min(deg, fanout) over the 128 seeds (their slice of the compact COO) and publishes the tile
+//      aggregate for the decoupled look-back (tile_scan.h) -- the reference's padded tmp arrays and its
+//      count / DeviceScan / compact passes (khop3.cu:148-230,272-302) are this scan;
+//   3. draws the positions: the reference's own geometry -- 16 lanes per stream, 8 streams -- but the 16 lanes
+//      do useful work.  The stream is serial only in its XORWOW recurrence (9 ALU ops per draw); everything
+//      else is done 16 draws at a time: every lane of the group steps the generator 16 times and keeps draw
+//      number `lig`, then the 16 candidates are reduced mod deg, looked up in the group's LDS set,
+//      de-duplicated against EARLIER candidates with DPP row shifts (first occurrence wins, exactly what the
+//      one-draw-at-a-time loop of khop3.cu:125-131 yields), ranked with a ballot, and the accepted ones kept
+//      in rank order.  If the set completes at candidate t*, the generator is rewound to just after draw t*,
+//      so the stream position is the reference's.  Positions stay in LDS;
+//   4. looks back for the tile's base offset (by now the predecessors have published: the wait hides behind 3);
+//   5. sweeps the tile's (seed, slot) pairs with all lanes: neighbour load, COO write (src value, neighbour id)
+//      and -- INSERT, direct dedup table -- the neighbour's table entry (DedupInsert::enter: one returning
+//      atomicMin, which is also all that the owner scan needs to know).  The sampler's ALU-bound phase 3 and the
+//      memory-bound phase 5 of different workgroups overlap on the chip instead of being two kernels.
 template <int S>
 __device__ __forceinline__ uint32_t row_shr(uint32_t v) {
   // lane l of a 16-lane row reads lane l - S of the same row; lanes l < S read 0 (bound_ctrl), which lets the
@@ -71,181 +76,228 @@ __device__ __forceinline__ uint32_t row_shr(uint32_t v) {
   return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x110 + S, 0xf, 0xf, true);
 }
 
-//
-// Only seeds with more neighbours than `fanout` enter the serial loop; the "take them all" seeds
-// consume no draws and are filled in by k_gather_neighbours.  GPW = groups per wave64: 4 packs the
-// lanes (large frontiers: the loop is issue-bound), 1 gives every group a wave of its own (small
-// frontiers: the chip has idle SIMDs and a group no longer waits for its three neighbours).
-template <int GPW>
-__global__ __launch_bounds__(128 * (4 / GPW)) void k_khop3_positions(GraphView g, const uint32_t *__restrict__ input,
-                                                                     Count n_arg, uint32_t fanout,
-                                                                     const uint32_t *__restrict__ offset,
-                                                                     uint32_t *__restrict__ out_dst,
-                                                                     uint32_t *__restrict__ states,
-                                                                     uint32_t set_mask) {
-  constexpr uint32_t HASH_EMPTY = 0xffffffffu;
+struct FusedScan {
+  uint32_t *ctl;             // {ticket, done}
+  unsigned long long *desc;  // one descriptor per 128-seed tile
+  uint32_t epoch;
+  uint64_t *num_out;         // total number of edges
+  uint32_t *err;
+};
+
+// Only seeds with more neighbours than `fanout` enter the serial loop; the "take them all" seeds consume no
+// draws.  GPW = groups per wave64: 4 packs the lanes (large frontiers: the loop is issue-bound), 1 gives every
+// group a wave of its own (small frontiers: the chip has idle SIMDs and a group no longer waits for its three
+// neighbours); the idle lanes of a sparse wave still work in phase 5.
+template <int GPW, bool INSERT>
+__global__ __launch_bounds__(128 * (4 / GPW)) void k_khop3_fused(GraphView g, const uint32_t *__restrict__ input,
+                                                                 Count n_arg, uint32_t fanout, uint32_t fanout_magic,
+                                                                 uint32_t *__restrict__ out_src,
+                                                                 uint32_t *__restrict__ out_dst, SrcMode sm,
+                                                                 uint32_t *__restrict__ states, uint32_t set_mask,
+                                                                 FusedScan fs, DedupInsert di) {
+  constexpr uint32_t HASH_EMPTY = 0xffffffffu, NT = 128 * (4 / GPW), FLAG_A = 1, FLAG_P = 2;
+  extern __shared__ uint32_t s_pos[];  // [128][fanout]: sampled positions of the tile's seeds
   __shared__ uint32_t set_tab[8][128]; // one open-addressing set per group; set_mask + 1 slots in use
+  __shared__ const uint32_t *s_ptr[128];
+  __shared__ uint32_t s_len[128], s_rid[128], s_off[129];
+  __shared__ uint32_t s_tile, s_prefix;
   const uint32_t lane = threadIdx.x & 63u;
-  if (GPW < 4 && lane >= 16u * GPW) return; // the unused lanes of a sparse wave
+  const bool active = GPW == 4 || lane < 16u * GPW; // lanes that belong to a group
   const uint64_t n = n_arg.get();
   const uint32_t y = (threadIdx.x >> 6) * GPW + (lane >> 4), lig = lane & 15u;
   const uint32_t grp_shift = lane & ~15u; // first lane of my group inside the wave
-  uint32_t *const tab = set_tab[y];
-  const uint64_t num_blocks = (n + 127) / 128;
+  uint32_t *const tab = set_tab[active ? y : 0];
+  const uint64_t num_tiles = (n + 127) / 128;
+  const uint32_t my_s = y + 8u * lig; // my seed of the tile (as a group lane)
 
-  for (uint32_t s = lig; s <= set_mask; s += 16) tab[s] = HASH_EMPTY;
+  if (active)
+    for (uint32_t s = lig; s <= set_mask; s += 16) tab[s] = HASH_EMPTY;
   bool dirty = false; // group-uniform: the set holds entries
 
-  for (uint64_t b = blockIdx.x; b < num_blocks; b += gridDim.x) {
-    const uint64_t stream = 8 * b + y;
-    // lane lig fetches seed k = lig of the group: id -> (degree, output offset, 2^32/deg)
-    const uint64_t my_index = 128 * b + y + 8 * (uint64_t)lig;
-    uint32_t my_len = 0, my_off = 0, my_magic = 0;
-    if (my_index < n) {
-      g.neighbours(input[my_index], my_len);
-      my_off = offset[my_index];
-      if (my_len > fanout) my_magic = (uint32_t)(4294967296.0 / (double)my_len); // floor(2^32 / len), exact
+  for (;;) {
+    if (threadIdx.x == 0) s_tile = atomicAdd(&fs.ctl[0], 1u);
+    __syncthreads();
+    const uint64_t b = s_tile;
+    if (b >= num_tiles) break;
+    // ---- 1: lane lig of group y fetches seed k = lig of the group: id -> (list, degree, 2^32/deg)
+    uint32_t my_len = 0, my_magic = 0;
+    if (active) {
+      const uint64_t my_index = 128 * b + my_s;
+      const uint32_t *ptr = nullptr;
+      uint32_t rid = 0;
+      if (my_index < n) {
+        rid = input[my_index];
+        ptr = g.neighbours(rid, my_len);
+        if (my_len > fanout) my_magic = (uint32_t)(4294967296.0 / (double)my_len); // floor(2^32 / len), exact
+      }
+      s_ptr[my_s] = ptr;
+      s_len[my_s] = my_len;
+      s_rid[my_s] = rid;
     }
-    // seeds of the group that draw, in order k = 0..15
-    uint32_t todo = (uint32_t)(__ballot(my_len > fanout) >> grp_shift) & 0xffffu;
-    if (__builtin_expect(todo == 0, 0)) continue; // the stream is not touched (khop3.cu:111-116 draws nothing)
-    Xorwow st;
-    st.load(states + 6 * stream);
-
-    bool fetch = true;
-    uint32_t len = 0, o = 0, magic = 0, count = 0;
-    while (todo != 0) {
-      if (fetch) {
-        const int src_lane = (int)(grp_shift + (uint32_t)__ffs(todo) - 1u);
-        len = __shfl(my_len, src_lane, 64);
-        o = __shfl(my_off, src_lane, 64);
-        magic = __shfl(my_magic, src_lane, 64);
-        count = 0;
-        fetch = false;
-      }
-      // ---- one round: 16 consecutive draws of the stream; lane lig keeps draw lig.
-      // w = the raw xorshift word of my draw: the generator's v-array is a sliding window over the
-      // sequence (old v0..v4, w of draw 0, w of draw 1, ...), which is what the rewind below reads.
-      const Xorwow st0 = st;
-      uint32_t x = 0;
-#pragma unroll
-      for (uint32_t i = 0; i < 16; ++i) {
-        const uint32_t xi = st.next();
-        x = (lig == i) ? xi : x;
-      }
-      const uint32_t w = x - (st0.d + (lig + 1) * 362437u); // draw = xorshift word + Weyl counter after lig + 1 steps
-      // r = x mod len: q' = mulhi(x, floor(2^32/len)) is q or q - 1 (two fix-ups for safety)
-      uint32_t r = x - __umulhi(x, magic) * len;
-      r = min(r, r - len);
-      r = min(r, r - len);
-      // already chosen for this seed?  (nothing is, in a seed's first round)
-      bool in_set = false;
-      if (count != 0) {
-        uint32_t pos = r & set_mask;
-        for (;;) {
-          const uint32_t cur = tab[pos];
-          if (cur == HASH_EMPTY) break;
-          if (cur == r) { in_set = true; break; }
-          pos = (pos + 1) & set_mask;
-        }
-      }
-      // equal to an EARLIER candidate of this round?  (compared as r + 1, never 0)
-      const uint32_t rp = r + 1;
-      bool dup = false;
-      dup |= row_shr<1>(rp) == rp;
-      dup |= row_shr<2>(rp) == rp;
-      dup |= row_shr<3>(rp) == rp;
-      dup |= row_shr<4>(rp) == rp;
-      dup |= row_shr<5>(rp) == rp;
-      dup |= row_shr<6>(rp) == rp;
-      dup |= row_shr<7>(rp) == rp;
-      dup |= row_shr<8>(rp) == rp;
-      dup |= row_shr<9>(rp) == rp;
-      dup |= row_shr<10>(rp) == rp;
-      dup |= row_shr<11>(rp) == rp;
-      dup |= row_shr<12>(rp) == rp;
-      dup |= row_shr<13>(rp) == rp;
-      dup |= row_shr<14>(rp) == rp;
-      dup |= row_shr<15>(rp) == rp;
-      const bool is_new = !in_set && !dup;
-      const uint32_t new_mask = (uint32_t)(__ballot(is_new) >> grp_shift) & 0xffffu;
-      const uint32_t rank = __popc(new_mask & ((1u << lig) - 1u));
-      const uint32_t total_new = __popc(new_mask);
-      const uint32_t need = fanout - count;
-      const bool accept = is_new && rank < need;
-      if (accept) out_dst[o + count + rank] = r; // insertion order == output order (items[] of khop3.cu:64)
-      if (total_new >= need) {
-        // The set completed at draw t* = the lane of the need-th new candidate.  State after m = t* + 1
-        // draws: v_j = element m + j of the window, d = d0 + m * 362437 -- five lane reads, no replay.
-        const uint32_t last_mask = (uint32_t)(__ballot(accept && rank == need - 1) >> grp_shift) & 0xffffu;
-        const uint32_t m = (uint32_t)__ffs(last_mask); // t* + 1, in 1..16
-        uint32_t v[5];
-#pragma unroll
-        for (uint32_t j = 0; j < 5; ++j) {
-          const uint32_t e = m + j; // window element: 0..4 = old v0..v4, 5 + i = w of draw i
-          const uint32_t from_draw = __shfl(w, (int)(grp_shift + (e >= 5 ? e - 5 : 0)), 64);
-          uint32_t from_old = st0.v4;
-          from_old = (e == 3) ? st0.v3 : from_old;
-          from_old = (e == 2) ? st0.v2 : from_old;
-          from_old = (e == 1) ? st0.v1 : from_old;
-          v[j] = (e >= 5) ? from_draw : from_old; // e >= 1 always
-        }
-        st.v0 = v[0]; st.v1 = v[1]; st.v2 = v[2]; st.v3 = v[3]; st.v4 = v[4];
-        st.d = st0.d + m * 362437u;
-        if (dirty) { // next seed starts from an empty set
-          __builtin_amdgcn_wave_barrier();
-          for (uint32_t s = lig; s <= set_mask; s += 16) tab[s] = HASH_EMPTY;
-          __builtin_amdgcn_wave_barrier();
-          dirty = false;
-        }
-        todo &= todo - 1;
-        fetch = true;
-      } else {
-        __builtin_amdgcn_wave_barrier();
-        if (accept) {
-          uint32_t pos = r & set_mask;
-          while (atomicCAS(&tab[pos], HASH_EMPTY, r) != HASH_EMPTY) pos = (pos + 1) & set_mask;
-        }
-        __builtin_amdgcn_wave_barrier();
-        count += total_new;
-        dirty = true;
+    __syncthreads();
+    // ---- 2: offsets of the 128 seeds inside the tile's slice (wave 0, two seeds per lane) + the tile aggregate
+    if (threadIdx.x < kWave) {
+      const uint32_t a = min(s_len[2 * lane], fanout), c = min(s_len[2 * lane + 1], fanout);
+      const uint32_t incl = wave_inclusive_scan(a + c);
+      s_off[2 * lane] = incl - (a + c);
+      s_off[2 * lane + 1] = incl - c;
+      if (lane == 63) {
+        s_off[128] = incl;
+        __hip_atomic_store(&fs.desc[b], scan_desc(fs.epoch, b == 0 ? FLAG_P : FLAG_A, incl), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
       }
     }
-    if (lig == 0) st.store(states + 6 * stream);
+    // ---- 3: positions (no barrier needed before it: it reads registers and writes s_pos / the group's set)
+    if (active) {
+      const uint64_t stream = 8 * b + y;
+      const uint32_t my_off = my_s * fanout;
+      // seeds of the group that draw, in order k = 0..15
+      uint32_t todo = (uint32_t)(__ballot(my_len > fanout) >> grp_shift) & 0xffffu;
+      if (todo != 0) { // else the stream is not touched (khop3.cu:111-116 draws nothing)
+        Xorwow st;
+        st.load(states + 6 * stream);
+        bool fetch = true;
+        uint32_t len = 0, o = 0, magic = 0, count = 0;
+        while (todo != 0) {
+          if (fetch) {
+            const int src_lane = (int)(grp_shift + (uint32_t)__ffs(todo) - 1u);
+            len = __shfl(my_len, src_lane, 64);
+            o = __shfl(my_off, src_lane, 64);
+            magic = __shfl(my_magic, src_lane, 64);
+            count = 0;
+            fetch = false;
+          }
+          // ---- one round: 16 consecutive draws of the stream; lane lig keeps draw lig.
+          // w = the raw xorshift word of my draw: the generator's v-array is a sliding window over the
+          // sequence (old v0..v4, w of draw 0, w of draw 1, ...), which is what the rewind below reads.
+          const Xorwow st0 = st;
+          uint32_t x = 0;
+#pragma unroll
+          for (uint32_t i = 0; i < 16; ++i) {
+            const uint32_t xi = st.next();
+            x = (lig == i) ? xi : x;
+          }
+          const uint32_t w = x - (st0.d + (lig + 1) * 362437u); // draw = xorshift word + Weyl counter after lig + 1 steps
+          // r = x mod len: q' = mulhi(x, floor(2^32/len)) is q or q - 1 (two fix-ups for safety)
+          uint32_t r = x - __umulhi(x, magic) * len;
+          r = min(r, r - len);
+          r = min(r, r - len);
+          // already chosen for this seed?  (nothing is, in a seed's first round)
+          bool in_set = false;
+          if (count != 0) {
+            uint32_t pos = r & set_mask;
+            for (;;) {
+              const uint32_t cur = tab[pos];
+              if (cur == HASH_EMPTY) break;
+              if (cur == r) { in_set = true; break; }
+              pos = (pos + 1) & set_mask;
+            }
+          }
+          // equal to an EARLIER candidate of this round?  (compared as r + 1, never 0)
+          const uint32_t rp = r + 1;
+          bool dup = false;
+          dup |= row_shr<1>(rp) == rp;
+          dup |= row_shr<2>(rp) == rp;
+          dup |= row_shr<3>(rp) == rp;
+          dup |= row_shr<4>(rp) == rp;
+          dup |= row_shr<5>(rp) == rp;
+          dup |= row_shr<6>(rp) == rp;
+          dup |= row_shr<7>(rp) == rp;
+          dup |= row_shr<8>(rp) == rp;
+          dup |= row_shr<9>(rp) == rp;
+          dup |= row_shr<10>(rp) == rp;
+          dup |= row_shr<11>(rp) == rp;
+          dup |= row_shr<12>(rp) == rp;
+          dup |= row_shr<13>(rp) == rp;
+          dup |= row_shr<14>(rp) == rp;
+          dup |= row_shr<15>(rp) == rp;
+          const bool is_new = !in_set && !dup;
+          const uint32_t new_mask = (uint32_t)(__ballot(is_new) >> grp_shift) & 0xffffu;
+          const uint32_t rank = __popc(new_mask & ((1u << lig) - 1u));
+          const uint32_t total_new = __popc(new_mask);
+          const uint32_t need = fanout - count;
+          const bool accept = is_new && rank < need;
+          if (accept) s_pos[o + count + rank] = r; // insertion order == output order (items[] of khop3.cu:64)
+          if (total_new >= need) {
+            // The set completed at draw t* = the lane of the need-th new candidate.  State after m = t* + 1
+            // draws: v_j = element m + j of the window, d = d0 + m * 362437 -- five lane reads, no replay.
+            const uint32_t last_mask = (uint32_t)(__ballot(accept && rank == need - 1) >> grp_shift) & 0xffffu;
+            const uint32_t m = (uint32_t)__ffs(last_mask); // t* + 1, in 1..16
+            uint32_t v[5];
+#pragma unroll
+            for (uint32_t j = 0; j < 5; ++j) {
+              const uint32_t e = m + j; // window element: 0..4 = old v0..v4, 5 + i = w of draw i
+              const uint32_t from_draw = __shfl(w, (int)(grp_shift + (e >= 5 ? e - 5 : 0)), 64);
+              uint32_t from_old = st0.v4;
+              from_old = (e == 3) ? st0.v3 : from_old;
+              from_old = (e == 2) ? st0.v2 : from_old;
+              from_old = (e == 1) ? st0.v1 : from_old;
+              v[j] = (e >= 5) ? from_draw : from_old; // e >= 1 always
+            }
+            st.v0 = v[0]; st.v1 = v[1]; st.v2 = v[2]; st.v3 = v[3]; st.v4 = v[4];
+            st.d = st0.d + m * 362437u;
+            if (dirty) { // next seed starts from an empty set
+              __builtin_amdgcn_wave_barrier();
+              for (uint32_t s = lig; s <= set_mask; s += 16) tab[s] = HASH_EMPTY;
+              __builtin_amdgcn_wave_barrier();
+              dirty = false;
+            }
+            todo &= todo - 1;
+            fetch = true;
+          } else {
+            __builtin_amdgcn_wave_barrier();
+            if (accept) {
+              uint32_t pos = r & set_mask;
+              while (atomicCAS(&tab[pos], HASH_EMPTY, r) != HASH_EMPTY) pos = (pos + 1) & set_mask;
+            }
+            __builtin_amdgcn_wave_barrier();
+            count += total_new;
+            dirty = true;
+          }
+        }
+        if (lig == 0) st.store(states + 6 * stream);
+      }
+    }
+    // ---- 4: base offset of the tile (wave 0); the last tile knows the total
+    if (threadIdx.x < kWave) {
+      uint32_t prefix = 0;
+      if (b != 0) {
+        prefix = scan_lookback(fs.desc, b, fs.epoch, fs.err);
+        if (lane == 0)
+          __hip_atomic_store(&fs.desc[b], scan_desc(fs.epoch, FLAG_P, prefix + s_off[128]), __ATOMIC_RELAXED,
+                             __HIP_MEMORY_SCOPE_AGENT);
+      }
+      if (lane == 0) {
+        s_prefix = prefix;
+        if (b + 1 == num_tiles) *fs.num_out = (uint64_t)prefix + s_off[128];
+      }
+    }
+    __syncthreads();
+    // ---- 5: slot j of seed s -> edge prefix + off[s] + j: its position inside the seed's neighbour list is j
+    // for a "take them all" seed and the sampler's pick otherwise; written out as (src value, neighbour id)
+    const uint32_t prefix = s_prefix;
+    const uint32_t slots = 128u * fanout;
+    for (uint32_t t = threadIdx.x; t < slots; t += NT) {
+      // s = t / fanout (t < 2^14): mulhi by ceil(2^32 / fanout), one fix-up
+      uint32_t sd = fanout == 1 ? t : __umulhi(t, fanout_magic);
+      if (sd * fanout > t) --sd;
+      const uint32_t j = t - sd * fanout;
+      const uint32_t len = s_len[sd];
+      if (j >= min(len, fanout)) continue;
+      const uint32_t e = prefix + s_off[sd] + j;
+      const uint32_t pos = len <= fanout ? j : s_pos[t];
+      const uint32_t nbr = s_ptr[sd][pos];
+      out_src[e] = sm.value(s_rid[sd], 128 * b + sd);
+      out_dst[e] = nbr;
+      if (INSERT) di.enter(nbr, e);
+    }
+    __syncthreads(); // LDS is rewritten by the next tile
   }
-}
-
-// Slot j of seed i -> the edge at offset[i] + j: its position inside the seed's neighbour list is j for
-// a "take them all" seed and the sampler's pick otherwise; written out as (src value, neighbour id).
-// INSERT: the batch loop's dedup table is direct-indexed, so the neighbour is also entered right here
-// (one fire-and-forget atomicMin, what k_ht_insert<true> would do in a pass of its own).
-template <bool INSERT>
-__global__ __launch_bounds__(kBlock) void k_gather_neighbours(GraphView g, const uint32_t *__restrict__ input,
-                                                              Count n_arg, uint32_t fanout, uint32_t fanout_magic,
-                                                              const uint32_t *__restrict__ offset,
-                                                              uint32_t *__restrict__ out_src,
-                                                              uint32_t *__restrict__ out_dst, SrcMode sm,
-                                                              unsigned long long *table_w, uint32_t table_version,
-                                                              uint32_t *__restrict__ owner_hint) {
-  const uint64_t total = n_arg.get() * fanout;
-  for (uint64_t t = (uint64_t)blockIdx.x * kBlock + threadIdx.x; t < total; t += (uint64_t)gridDim.x * kBlock) {
-    // i = t / fanout for t < 2^32 (host checks n_max * fanout < 2^32): mulhi by ceil(2^32 / fanout), one fix-up
-    uint32_t i = fanout == 1 ? (uint32_t)t : __umulhi((uint32_t)t, fanout_magic);
-    if ((uint64_t)i * fanout > t) --i;
-    const uint32_t j = (uint32_t)t - i * fanout;
-    const uint32_t rid = input[i];
-    uint32_t len;
-    const uint32_t *edges = g.neighbours(rid, len);
-    if (j >= min(len, fanout)) continue;
-    const uint32_t e = offset[i] + j;
-    const uint32_t pos = len <= fanout ? j : out_dst[e];
-    const uint32_t nbr = edges[pos];
-    out_src[e] = sm.value(rid, i);
-    out_dst[e] = nbr;
-    if (INSERT) { // w1 = {0x7fffffff - version : 31 | pending = 1 | first index : 32}, hashtable.hip
-      const unsigned long long mine = ((((unsigned long long)(0x7fffffffu - table_version)) << 1 | 1ull) << 32) | e;
-      const unsigned long long old = atomicMin(table_w + nbr, mine);
-      owner_hint[e] = old < mine ? 0u : 1u; // a smaller word was there already: this instance cannot own the key
+  if (threadIdx.x == 0) {
+    if (num_tiles == 0 && blockIdx.x == 0) *fs.num_out = 0;
+    if (atomicAdd(&fs.ctl[1], 1u) == gridDim.x - 1) { // the last block out re-arms the ticket
+      fs.ctl[0] = 0;
+      fs.ctl[1] = 0;
     }
   }
 }
@@ -507,42 +559,52 @@ static int khop3_groups_per_wave(size_t blocks) {
   return 4;
 }
 
-size_t sample_ws_words(size_t num_input) { return num_input + tile_scan_words(num_input) + 16; }
+size_t sample_ws_words(size_t num_input) { return num_input + tile_scan_words(num_input) + 16 + 2 * (num_input / 128 + 2); }
 
-// offsets by exclusive scan of min(deg, fanout), then the sampler proper
+template <int GPW, bool INSERT>
+static void launch_khop3_fused(int grid, size_t lds, hipStream_t s, GraphView g, const uint32_t *input, Count n,
+                               uint32_t fanout, uint32_t *out_src, uint32_t *out_dst, SrcMode sm, uint32_t *states,
+                               uint32_t set_mask, FusedScan fs, DedupInsert di) {
+  const uint32_t fanout_magic = (uint32_t)((0x100000000ull + fanout - 1) / fanout); // ceil(2^32 / fanout)
+  if (lds > (48u << 10)) { // large fan-outs: more dynamic LDS than the default per-kernel limit (gfx950 has 160 KB)
+    static std::atomic<bool> raised{false};
+    if (!raised.exchange(true))
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_khop3_fused<GPW, INSERT>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 127 * 4);
+  }
+  hipLaunchKernelGGL((k_khop3_fused<GPW, INSERT>), dim3(grid), dim3(128 * (4 / GPW)), lds, s, g, input, n, fanout,
+                     fanout_magic, out_src, out_dst, sm, states, set_mask, fs, di);
+}
+
+// the whole layer in one launch (see k_khop3_fused).  shared_scan: the batch's scan area (cleared by the batch
+// prologue); else the workspace holds a private one that is cleared here.  insert (direct dedup table): the
+// neighbours are entered into the table on the way out.
 int sample_khop3_impl(GraphView g, const uint32_t *input, size_t n_max, Count n, uint32_t fanout, uint32_t *out_src,
                       uint32_t *out_dst, uint64_t *num_out_dev, uint32_t *states, uint32_t *workspace,
-                      const uint32_t *seed_local, int src_local, const ggms_hashtable_t *insert_into, hipStream_t s,
-                      ScanArea *shared_scan, uint32_t *owner_hint) {
-  uint32_t *offset = workspace;
-  const ScanArea sa = shared_scan ? *shared_scan : ScanArea{offset + n_max, false};
-  int rc = tile_scan(SeedCount{g, input, fanout}, StoreOffset{offset}, n_max, n, sa, nullptr, nullptr,
-                     num_out_dev, s);
-  if (rc != GGMS_OK) return rc;
+                      const uint32_t *seed_local, int src_local, hipStream_t s, ScanArea *shared_scan,
+                      const DedupInsert *insert) {
+  const size_t tiles = (n_max + 127) / 128;
+  uint32_t *ctl = scan_align(shared_scan ? shared_scan->words : workspace);
+  if (!shared_scan || !shared_scan->cleared)
+    GGMS_HIP(hipMemsetAsync(ctl, 0, (8 + 2 * (tiles + 1)) * sizeof(uint32_t), s));
+  const FusedScan fs{ctl, reinterpret_cast<unsigned long long *>(ctl + 8), next_scan_epoch(), num_out_dev,
+                     device_status_word()};
   const SrcMode sm{seed_local, src_local};
   // 64 slots up to fanout 31 (load < 0.5), else the reference's 128 (HASHTABLE_SIZE, khop3.cu:43)
   const uint32_t set_mask = fanout < 32 ? 63u : 127u;
-  const size_t blocks = (n_max + 127) / 128;
-  const int gpw = khop3_groups_per_wave(blocks);
-  const int grid = grid_for(blocks, 1);
-  if (gpw == 1)
-    hipLaunchKernelGGL(k_khop3_positions<1>, dim3(grid), dim3(512), 0, s, g, input, n, fanout, offset, out_dst, states,
-                       set_mask);
-  else if (gpw == 2)
-    hipLaunchKernelGGL(k_khop3_positions<2>, dim3(grid), dim3(256), 0, s, g, input, n, fanout, offset, out_dst, states,
-                       set_mask);
-  else
-    hipLaunchKernelGGL(k_khop3_positions<4>, dim3(grid), dim3(128), 0, s, g, input, n, fanout, offset, out_dst, states,
-                       set_mask);
-  GGMS_LAUNCH_CHECK();
-  const uint32_t fanout_magic = (uint32_t)((0x100000000ull + fanout - 1) / fanout); // ceil(2^32 / fanout)
-  if (insert_into && insert_into->direct && owner_hint)
-    hipLaunchKernelGGL(k_gather_neighbours<true>, dim3(grid_for(n_max * fanout, kBlock)), dim3(kBlock), 0, s, g, input,
-                       n, fanout, fanout_magic, offset, out_src, out_dst, sm, (unsigned long long *)insert_into->o2n,
-                       insert_into->version, owner_hint);
-  else
-    hipLaunchKernelGGL(k_gather_neighbours<false>, dim3(grid_for(n_max * fanout, kBlock)), dim3(kBlock), 0, s, g, input,
-                       n, fanout, fanout_magic, offset, out_src, out_dst, sm, nullptr, 0u, nullptr);
+  const int gpw = khop3_groups_per_wave(tiles);
+  const int grid = grid_for(tiles, 1);
+  const size_t lds = 128 * (size_t)fanout * sizeof(uint32_t);
+  const DedupInsert none{nullptr, 0, nullptr, nullptr, 0ull};
+  if (insert) {
+    if (gpw == 1) launch_khop3_fused<1, true>(grid, lds, s, g, input, n, fanout, out_src, out_dst, sm, states, set_mask, fs, *insert);
+    else if (gpw == 2) launch_khop3_fused<2, true>(grid, lds, s, g, input, n, fanout, out_src, out_dst, sm, states, set_mask, fs, *insert);
+    else launch_khop3_fused<4, true>(grid, lds, s, g, input, n, fanout, out_src, out_dst, sm, states, set_mask, fs, *insert);
+  } else {
+    if (gpw == 1) launch_khop3_fused<1, false>(grid, lds, s, g, input, n, fanout, out_src, out_dst, sm, states, set_mask, fs, none);
+    else if (gpw == 2) launch_khop3_fused<2, false>(grid, lds, s, g, input, n, fanout, out_src, out_dst, sm, states, set_mask, fs, none);
+    else launch_khop3_fused<4, false>(grid, lds, s, g, input, n, fanout, out_src, out_dst, sm, states, set_mask, fs, none);
+  }
   GGMS_LAUNCH_CHECK();
   return GGMS_OK;
 }
@@ -639,7 +701,7 @@ int ggms_sample_khop3(const ggms_graph_t *graph, const ggms_id_t *input, size_t 
   GGMS_CHECK_ARG((uint64_t)num_input * fanout < (1ull << 32));
   GGMS_CHECK_ARG((num_input + 127) / 128 * 8 <= num_states); // assert(i < num_random_states), khop3.cu:89
   return sample_khop3_impl(view_of(graph), input, num_input, count_of(num_input), (uint32_t)fanout, out_src, out_dst,
-                           num_out_dev, (uint32_t *)states, (uint32_t *)workspace, nullptr, 0, nullptr, s);
+                           num_out_dev, (uint32_t *)states, (uint32_t *)workspace, nullptr, 0, s);
 }
 
 int ggms_sample_khop0(const ggms_graph_t *graph, const ggms_id_t *input, size_t num_input, size_t fanout,

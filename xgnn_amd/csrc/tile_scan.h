@@ -61,11 +61,48 @@ __device__ __forceinline__ unsigned long long scan_desc(uint32_t epoch, uint32_t
   return ((unsigned long long)((epoch << 2) | flag) << 32) | value;
 }
 
+// Decoupled look-back, run by the 64 lanes of ONE wave: sum of the aggregates of the tiles before `tile`, back to
+// the nearest published inclusive prefix (which carries `base` in from tile 0).  64 predecessors per step.
+// Bounded: a protocol error must not hang the GPU -- after 2^22 polls the wave gives up, ORs kErrScanSpin into
+// the device status word (the host fails the batch on it) and returns what it has.
+__device__ __forceinline__ uint32_t scan_lookback(const unsigned long long *desc, uint64_t tile, uint32_t epoch,
+                                                  uint32_t *err) {
+  constexpr uint32_t FLAG_P = 2;
+  const uint32_t lane = threadIdx.x & 63u;
+  uint32_t acc = 0;
+  int64_t start = (int64_t)tile - 1; // nearest predecessor is read by lane 0
+  for (uint32_t spins = 0;; ++spins) {
+    if (spins > (1u << 22)) {
+      if (lane == 0 && err) atomicOr(err, kErrScanSpin);
+      break;
+    }
+    const int64_t t = start - (int64_t)lane;
+    unsigned long long d = scan_desc(epoch, FLAG_P, 0); // lanes past tile 0 read as "prefix 0"
+    if (t >= 0) d = __hip_atomic_load(&desc[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t tag = (uint32_t)(d >> 32);
+    const bool ready = (tag >> 2) == epoch && (tag & 3u) != 0;
+    const uint64_t pmask = __ballot(ready && (tag & 3u) == FLAG_P);
+    const uint64_t rmask = __ballot(ready);
+    const uint32_t first_p = pmask ? (uint32_t)__builtin_ctzll(pmask) : 64u;
+    const uint64_t needed = first_p < 64u ? ((first_p == 63u) ? ~0ull : ((1ull << (first_p + 1)) - 1ull)) : ~0ull;
+    if ((rmask & needed) != needed) { // a descriptor between us and the nearest prefix is not written yet
+      __builtin_amdgcn_s_sleep(1);
+      continue;
+    }
+    const uint32_t mine = (lane <= first_p || first_p == 64u) ? (uint32_t)d : 0u;
+    acc += wave_reduce_sum(mine);
+    if (first_p < 64u) break;
+    start -= kWave;
+  }
+  return acc;
+}
+
 template <typename ValueF, typename EmitF>
 __global__ __launch_bounds__(kBlock) void k_tile_scan(ValueF value, EmitF emit, Count n_arg, uint32_t *ctl,
                                                       unsigned long long *desc, uint32_t epoch,
                                                       const uint32_t *base_in, uint32_t *total32_out,
-                                                      uint64_t *total64_out, uint64_t *mirror_a, uint64_t *mirror_b) {
+                                                      uint64_t *total64_out, uint64_t *mirror_a, uint64_t *mirror_b,
+                                                      uint32_t *err) {
   constexpr uint32_t ROUNDS = kTile / kBlock, FLAG_A = 1, FLAG_P = 2;
   __shared__ uint32_t smem[kBlock / kWave];
   __shared__ uint32_t s_tile, s_prefix;
@@ -96,28 +133,7 @@ __global__ __launch_bounds__(kBlock) void k_tile_scan(ValueF value, EmitF emit, 
       } else {
         if (lane == 0)
           __hip_atomic_store(&desc[tile], scan_desc(epoch, FLAG_A, running), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        uint32_t acc = 0;
-        int64_t start = (int64_t)tile - 1; // nearest predecessor is read by lane 0
-        for (uint32_t spins = 0;; ++spins) {
-          if (spins > (1u << 22)) break; // bounded: a protocol error must not hang the GPU (result is then wrong, not stuck)
-          const int64_t t = start - (int64_t)lane;
-          unsigned long long d = scan_desc(epoch, FLAG_P, 0); // lanes past tile 0 read as "prefix 0"
-          if (t >= 0) d = __hip_atomic_load(&desc[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          const uint32_t tag = (uint32_t)(d >> 32);
-          const bool ready = (tag >> 2) == epoch && (tag & 3u) != 0;
-          const uint64_t pmask = __ballot(ready && (tag & 3u) == FLAG_P);
-          const uint64_t rmask = __ballot(ready);
-          const uint32_t first_p = pmask ? (uint32_t)__builtin_ctzll(pmask) : 64u;
-          const uint64_t needed = first_p < 64u ? ((first_p == 63u) ? ~0ull : ((1ull << (first_p + 1)) - 1ull)) : ~0ull;
-          if ((rmask & needed) != needed) { // a descriptor between us and the nearest prefix is not written yet
-            __builtin_amdgcn_s_sleep(1);
-            continue;
-          }
-          const uint32_t mine = (lane <= first_p || first_p == 64u) ? (uint32_t)d : 0u;
-          acc += wave_reduce_sum(mine);
-          if (first_p < 64u) break;
-          start -= kWave;
-        }
+        const uint32_t acc = scan_lookback(desc, tile, epoch, err);
         prefix = acc; // already includes `base` through tile 0's inclusive prefix
         if (lane == 0)
           __hip_atomic_store(&desc[tile], scan_desc(epoch, FLAG_P, prefix + running), __ATOMIC_RELAXED,
@@ -338,7 +354,7 @@ inline int tile_scan(ValueF value, EmitF emit, size_t n_max, Count n, ScanArea a
     return GGMS_OK;
   }
   hipLaunchKernelGGL((k_tile_scan<ValueF, EmitF>), dim3(grid), dim3(kBlock), 0, stream, value, emit, n, ctl, desc,
-                     next_scan_epoch(), base_in, total32_out, total64_out, mirror_a, mirror_b);
+                     next_scan_epoch(), base_in, total32_out, total64_out, mirror_a, mirror_b, device_status_word());
   GGMS_LAUNCH_CHECK();
   return GGMS_OK;
 }

@@ -77,6 +77,22 @@ def random_states(num_states, seed, device="cuda"):
     return st
 
 
+def device_status(clear=False):
+    """The device status word (include/ggms.h): 0 = ok, 1 = a scan's look-back gave up, 2 = hashed table full.
+    Synchronises the device."""
+    st = C.c_uint32(0)
+    check(lib().ggms_device_status(C.byref(st), 1 if clear else 0), "ggms_device_status")
+    return st.value
+
+
+def check_device_status(what=""):
+    """Raise if a kernel reported a device-side failure (the reference CHECK-aborts there, logging.cc:69-73)."""
+    st = device_status(clear=True)
+    if st:
+        raise _lib.GgmsError(f"{what}: device status {st:#x} "
+                             f"({'scan look-back gave up ' if st & 1 else ''}{'hashed dedup table full' if st & 2 else ''})")
+
+
 def _workspace(nbytes, device):
     return torch.empty(max(16, (nbytes + 3) // 4), dtype=torch.int32, device=device)
 
@@ -417,7 +433,7 @@ class BatchSampler:
                      for _ in range(num_slots)]
         self._rows = [(C.c_void_p * L)(*[t.data_ptr() for t in r]) for r in self.rows]
         self._cols = [(C.c_void_p * L)(*[t.data_ptr() for t in c]) for c in self.cols]
-        self.counts_slots = [torch.zeros(3 * L + 1, dtype=torch.int64, device=device) for _ in range(num_slots)]
+        self.counts_slots = [torch.zeros(3 * L + 2, dtype=torch.int64, device=device) for _ in range(num_slots)]
         self.input_nodes = [torch.empty(self.max_unique, dtype=torch.int32, device=device) for _ in range(num_slots)]
         self.row, self.col, self.counts = self.rows[0], self.cols[0], self.counts_slots[0]
         self.data = None
@@ -490,6 +506,9 @@ class BatchSampler:
     def result(self):
         """Sync and slice the outputs (host round trip: for tests and hand-off, not for the hot loop)."""
         c = self.counts.cpu().tolist()
+        if c[3 * self.L + 1]:  # a kernel of the batch hit a bound it must not hit: the outputs are invalid
+            check_device_status("ggms_sample_batch")
+            raise _lib.GgmsError(f"ggms_sample_batch: device status {c[3 * self.L + 1]:#x}")
         layers = []
         for i in range(self.L):
             ne = c[3 * i]
