@@ -2,21 +2,29 @@
 """bench.py -- GGMS hot path on MI355X: sampled edges/s + feature-extract GB/s.
 
 One "step" = one mini-batch of the hot path on ONE GPU, inputs resident in HBM:
-    seeds (8000 train nodes) -> 2-layer khop3 neighbour sampling with ordered
+    seeds (8000 train nodes) -> k-layer khop3 neighbour sampling with ordered
     dedup/remap (DoGPUSample) -> feature rows of the batch's input nodes gathered
-    through the cache table (cache_ratio = 1.0) + label gather.
-Workload (BASELINE.json configs[1]): products-shaped synthetic power-law CSR
-(N 2,449,029, E ~1.24e8, f32 dim 100), GraphSAGE fanout [25,10], batch 8000.
+    from the GGMS feature store + label gather.
+Default workload = the largest single-GPU configuration of BASELINE.json: papers100M-shaped
+synthetic power-law CSR (N 111,059,956, E ~1.62e9, f32 dim 128 = 56.9 GB of features), 3-hop GCN
+fanout [5,10,15] (sgnn/train_gcn.py:84), batch 8000, graph + features in HBM (cache_ratio 1.0).
+The same line carries, as sub-records measured after the timed region:
+    host_tier     BASELINE configs[2]: the same workload with every feature row in pinned host DRAM
+                  (cache_ratio 0), read zero-copy by the gather kernel, next to the box's pinned-copy rate;
+    cpu_baseline  the reference's CPU sampler / extractor objects on the host cores, same graph.
+`--preset products` is BASELINE configs[1] (fanout [25,10]).
 
-N > 1 (driver: torch.distributed.run, one rank per GPU): data parallel over seed
-mini-batches, every rank samples its own slice of the shuffled train set from
-its own replica of graph + features -- no data-path collective (weak scaling).
+N > 1 (driver: torch.distributed.run, one rank per GPU): data parallel over seed mini-batches
+(DistAlignedShuffler slices), graph replicated, FEATURES SHARDED across the GPUs (GGMS, `--store peer`:
+slot s on GPU s % N, rows read from the owner's HBM inside the gather kernel over xGMI); the line also
+reports the replicated store (no xGMI traffic) and the hybrid one (hot prefix replicated, tail sharded).
 
 Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -29,33 +37,40 @@ sys.path.insert(0, ROOT)
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=40)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--preset", default="products")
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--repeats", type=int, default=3,
+                    help="the K timed steps are run this many times (each block bracketed by barrier + synchronize); "
+                         "the line reports the MEDIAN block (a block is a few ms: one hiccup must not move the headline)")
+    ap.add_argument("--preset", default="papers100M")
     ap.add_argument("--batch", type=int, default=8000)
-    ap.add_argument("--fanout", default="25,10")
+    ap.add_argument("--fanout", default=None, help="default: 5,10,15 (papers100M / friendster), 25,10 (products)")
     ap.add_argument("--sample-type", default="khop3",
                     choices=["khop3", "khop0", "khop2", "khop1", "weighted_khop", "weighted_khop_hash_dedup",
                              "random_walk"],
                     help="random_walk: PinSAGE defaults (walk length 3, restart 0.5, 4 walks); --fanout gives the "
-                         "top-K per layer, e.g. 5,5,5.  weighted_khop: synthetic alias tables")
+                         "top-K per layer, e.g. 5,5,5.  weighted_khop: alias tables built from synthetic weights")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-host-tier", action="store_true", help="skip the cache_ratio 0 sub-record (configs[2])")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline: keep sampling mini-batches this long")
+    ap.add_argument("--host-steps", type=int, default=5, help="timed steps of the host-tier sub-record")
     ap.add_argument("--host-profile", action="store_true", help="print host enqueue time per section to stderr")
     ap.add_argument("--pipelines", type=int, default=1,
-                    help="sampling batches in flight (each on its own stream with its own dedup table).  1: the gather "
-                         "keeps ~93 %% of its standalone rate beside the sampler; 2: +18 %% edges/s (the engine's "
-                         "default) while the gather, sharing HBM with two sampled batches, drops to ~0.40 of peak")
+                    help="sampling batches in flight (each on its own stream with its own dedup table)")
     ap.add_argument("--no-overlap", action="store_true",
                     help="one stream: extract of batch k and sampling of batch k+1 run back to back "
                          "(default: two streams, the HBM-bound gather overlaps the latency-bound sampler)")
-    ap.add_argument("--store", default="replica", choices=["replica", "peer", "a2a"],
-                    help="N > 1: 'replica' = every GPU holds the cached features (DP over seeds only); 'peer' = GGMS "
-                         "feature shards (slot %% N), rows read from the owner's HBM inside the gather kernel over xGMI "
-                         "(hipIpc); 'a2a' = same shards, rows exchanged with RCCL all-to-all")
+    ap.add_argument("--store", default=None, choices=["replica", "peer", "a2a", "hybrid"],
+                    help="N > 1 (default peer): 'peer' = GGMS feature shards (slot %% N), rows read from the owner's HBM "
+                         "inside the gather kernel over xGMI (hipIpc); 'a2a' = same shards, rows exchanged with RCCL "
+                         "all-to-all; 'hybrid' = the --replicate-frac hottest rows (degree rank) on every GPU, the tail "
+                         "sharded; 'replica' = every GPU holds all cached rows (DP over seeds only)")
+    ap.add_argument("--replicate-frac", type=float, default=0.25, help="hybrid store: fraction of rows replicated")
+    ap.add_argument("--other-stores", default="replica,hybrid",
+                    help="N > 1: stores measured after the main timed region (one block) and reported under 'stores'")
     ap.add_argument("--cache-ratio", type=float, default=1.0,
                     help="fraction of feature rows (by degree rank) resident in HBM; the rest is gathered from "
-                         "pinned host memory by the same kernel (GGMS host tier). 1.0 = BASELINE configs[1]")
+                         "pinned host memory by the same kernel (GGMS host tier)")
     return ap.parse_args()
 
 
@@ -71,11 +86,11 @@ def usable_cores():
     return n
 
 
-def measured_traffic():
-    """HBM traffic of the extract kernel from the committed PMC profile (profiles/*_extract_traffic.json):
+def measured_traffic(preset):
+    """HBM traffic of the extract kernel from the committed PMC profile (profiles/*_extract_traffic_<preset>.json):
     collected with separate `rocprofv3 --pmc` passes of this same command, FETCH_SIZE corrected x2."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_extract_traffic.json")))
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"*_extract_traffic_{preset}.json")))
     if not files:
         return None
     d = json.load(open(files[-1]))
@@ -83,14 +98,14 @@ def measured_traffic():
     return d
 
 
-def cpu_baseline(graph, fanouts, batch, feat_dim, seconds):
-    """CPU leg: the oracle (port) and, when shipped, the reference's own CPU leaves (oracle/_ref).
-    Bounded sample: mini-batches of the same workload on the usable host cores for about `seconds` of CPU work."""
+def cpu_baseline(graph, fanouts, batch, feat, seconds):
+    """CPU leg on the same graph: the reference's own CPU leaves (oracle/_ref: CPUSampleKHop0, CPUExtract) where
+    shipped, else the oracle's port; dedup/remap = the oracle's OpenMP restatement of CPUHashTable2 (the reference's
+    default table) -- every leg on all usable host cores.  Bounded: mini-batches for about `seconds` of CPU work."""
     import oracle
     cores = usable_cores()
     ip, ix, train = graph["indptr"], graph["indices"], graph["train_set"]
     n_node = ip.size - 1
-    feat = (np.arange(n_node * feat_dim, dtype=np.int64) & 0xFFFF).astype(np.float32).reshape(n_node, feat_dim)
     have_ref = oracle.ref_lib() is not None
     sample = oracle.ref_cpu_sample_khop0 if have_ref else oracle.cpu_sample_khop0
     extract = oracle.ref_cpu_extract if have_ref else oracle.extract
@@ -98,6 +113,7 @@ def cpu_baseline(graph, fanouts, batch, feat_dim, seconds):
     edges = rows = 0
     n_batches = 0
     per_epoch = max(1, len(train) // batch)
+    ht = oracle.CpuHashTable2(n_node, cores)
     t_begin = time.perf_counter()
     while time.perf_counter() - t_begin < seconds or n_batches < 3:
         b = n_batches % per_epoch
@@ -105,8 +121,8 @@ def cpu_baseline(graph, fanouts, batch, feat_dim, seconds):
             train = train[np.random.RandomState(n_batches).permutation(len(train))]
         n_batches += 1
         seeds = train[b * batch:(b + 1) * batch]
-        ht = oracle.HashTable(n_node, oracle.predict_num_nodes(len(seeds), fanouts, len(fanouts)) + 1)
         t0 = time.perf_counter()
+        ht.reset()
         ht.fill_with_duplicates(seeds)
         t_remap += time.perf_counter() - t0
         cur = seeds
@@ -127,15 +143,20 @@ def cpu_baseline(graph, fanouts, batch, feat_dim, seconds):
         rows += cur.size
         del out
     total = t_sample + t_remap + t_extract
+    dim = feat.shape[1]
     return {
         "value": edges / total, "unit": "edges/s", "cores": cores,
-        "kind": "reference" if have_ref else "port",
-        "sample": f"{n_batches} mini-batches of {batch} seeds, fanout {fanouts}, same synthetic graph; "
-                  f"sampler+extract = {'reference CPUSampleKHop0/CPUExtract objects (oracle/_ref)' if have_ref else 'oracle port'}"
-                  f" on {cores} threads, dedup/remap = oracle port of CPUHashTable2 (1 thread)",
+        # "reference" would claim every leg is reference code; the dedup/remap leg is a port
+        "kind": "port",
+        "legs": {"sample": "reference CPUSampleKHop0 (oracle/_ref)" if have_ref else "oracle port of CPUSampleKHop0",
+                 "remap": "oracle OpenMP port of CPUHashTable2 (Populate/MapEdges/Reset, cpu_hashtable2.cc:53-191)",
+                 "extract": "reference CPUExtract (oracle/_ref)" if have_ref else "oracle port of CPUExtract"},
+        "sample": f"{n_batches} mini-batches of {batch} seeds, fanout {fanouts}, same synthetic graph and feature table; "
+                  f"all three legs on {cores} threads",
+        "seconds": {"sample": t_sample, "remap": t_remap, "extract": t_extract, "total": total},
         "sample_only_edges_per_s": edges / t_sample,
-        "feature_GBps": rows * feat_dim * 4 / t_extract / 1e9,
-        "seconds": total,
+        "sample_plus_remap_edges_per_s": edges / (t_sample + t_remap),
+        "feature_GBps": rows * dim * 4 / t_extract / 1e9,
     }
 
 
@@ -161,12 +182,16 @@ def main():
             dist.init_process_group(backend)
     dev = torch.device("cuda", dev_index)
 
-    from xgnn_amd import datagen, ops, parallel
+    from xgnn_amd import datagen, ggms_store, ops, parallel
 
+    if args.fanout is None:
+        args.fanout = "25,10" if args.preset in ("products", "tiny") else "5,10,15"
     fanouts = [int(x) for x in args.fanout.split(",")]
+    main_store = (args.store or "peer") if world > 1 else "local"
     graph = datagen.make_graph(args.preset, seed=42)
     meta = graph["meta"]
     N, dim = meta["num_node"], meta["feat_dim"]
+    row_bytes = dim * 4
 
     def to_dev(a):
         return torch.from_numpy(a.view(np.int32) if a.dtype == np.uint32 else a).to(dev)
@@ -178,34 +203,67 @@ def main():
     def feat_rows(node_ids, out):
         """feat[i, j] = float((i*dim + j) & 0xFFFF), generated in place for the given node ids."""
         cols = torch.arange(dim, dtype=torch.int64, device=out.device)
-        step = 1 << 22
+        step = 1 << 21
         for lo in range(0, node_ids.numel(), step):
             ids = node_ids[lo:lo + step].to(out.device, torch.int64)
             out[lo:lo + step] = ((ids[:, None] * dim + cols[None, :]) & 0xFFFF).to(torch.float32)
 
-    # degree policy: cache slot r holds node rank[r] (r < num_cached); table[node] = slot or kEmptyKey
-    rank_list = datagen.degree_rank(graph["indptr"])
-    t_rank = to_dev(rank_list)
-    num_cached = int(N * args.cache_ratio)
-    store = None
-    if args.store == "replica" or world == 1:
-        cache = torch.empty((max(num_cached, 1), dim), dtype=torch.float32, device=dev)
-        feat_rows(t_rank[:num_cached], cache)
-    else:  # GGMS: cache slot s lives on rank s % world at row s // world
-        from xgnn_amd import ggms_store
-        cache, holder = ggms_store.shard_rows(feat_rows, t_rank, num_cached, world, rank, dim, torch.float32, dev,
-                                              shared=(args.store == "peer"))
-    table = torch.full((N,), -1, dtype=torch.int32, device=dev)  # 0xffffffff
-    table[t_rank[:num_cached].long()] = torch.arange(num_cached, dtype=torch.int32, device=dev)
-    ptab = ops.part_pointer_table([cache], dev)
+    # ---- the feature store ---------------------------------------------------------------------------------
+    # cache_ratio 1.0: every row in HBM, kept in NODE order (slot = node id, no id -> slot table: ggms_extract_cached
+    # with table = NULL).  cache_ratio < 1: degree policy -- slot r holds node rank[r] (r < num_cached), table[node] =
+    # slot or kEmptyKey, the rest comes from pinned host memory.
+    full = args.cache_ratio >= 1.0
+    num_cached = N if full else int(N * args.cache_ratio)
+    t_rank = None if full and world == 1 else to_dev(datagen.degree_rank(graph["indptr"]))
     host_feat = None
-    if num_cached < N:  # host tier: the full table in pinned host memory, read zero-copy by the gather kernel
+    if not full:  # host tier: the full table in pinned host memory, read zero-copy by the gather kernel
         host_feat = torch.empty((N, dim), dtype=torch.float32, pin_memory=True)
         feat_rows(torch.arange(N, dtype=torch.int64), host_feat)
-    if args.store != "replica" and world > 1:
-        store = ggms_store.FeatureShards(cache, table, world, rank, mode=args.store, dist=dist, host_feat=host_feat)
-        if args.store == "peer":
-            store.connect_peers(holder)
+
+    def build_store(kind):
+        """-> (extract(nodes, num_max, out, num_dev, counters), what it keeps alive) for one store kind."""
+        keep = {}
+        if kind in ("local", "replica"):
+            if full:
+                cache = torch.empty((N, dim), dtype=torch.float32, device=dev)
+                feat_rows(torch.arange(N, dtype=torch.int64, device=dev), cache)
+                table = None
+            else:
+                cache = torch.empty((max(num_cached, 1), dim), dtype=torch.float32, device=dev)
+                feat_rows(t_rank[:num_cached], cache)
+                table = torch.full((N,), -1, dtype=torch.int32, device=dev)  # 0xffffffff
+                table[t_rank[:num_cached].long()] = torch.arange(num_cached, dtype=torch.int32, device=dev)
+            ptab = ops.part_pointer_table([cache], dev)
+            keep.update(cache=cache, table=table, ptab=ptab)
+
+            def extract(nodes, num_max, out, num_dev, counters):
+                ops.extract_cached(out, nodes, table, ptab, 0, host_feat, num=num_max, num_dev=num_dev,
+                                   num_miss=counters[0:1])
+            return extract, keep
+        # sharded kinds.  Everything cached and nothing replicated: slot = node id, no table (as on one GPU).
+        # Otherwise slots in degree-rank order (hot first); hybrid replicates the first R of them on every GPU.
+        R = int(num_cached * args.replicate_frac) if kind == "hybrid" else 0
+        if full and R == 0:
+            order, table = torch.arange(N, dtype=torch.int64, device=dev), None
+        else:
+            order = t_rank
+            table = torch.full((N,), -1, dtype=torch.int32, device=dev)
+            table[order[:num_cached].long()] = torch.arange(num_cached, dtype=torch.int32, device=dev)
+        replica = None
+        if R:
+            replica = torch.empty((R, dim), dtype=torch.float32, device=dev)
+            feat_rows(order[:R], replica)
+        shard, holder = ggms_store.shard_rows(feat_rows, order[R:], num_cached - R, world, rank, dim, torch.float32,
+                                              dev, shared=(kind != "a2a"))
+        st = ggms_store.FeatureShards(shard, table, world, rank, mode="a2a" if kind == "a2a" else "peer", dist=dist,
+                                      host_feat=host_feat, replica=replica)
+        if kind != "a2a":
+            st.connect_peers(holder)
+        keep.update(store=st, holder=holder, table=table, replica=replica)
+
+        def extract(nodes, num_max, out, num_dev, counters):
+            st.extract(nodes, num_max, out, num_dev=num_dev, counters=counters)
+        return extract, keep
 
     code = {"khop3": ops.KHOP3, "khop0": ops.KHOP0, "khop2": ops.KHOP2, "khop1": ops.KHOP1,
             "weighted_khop": ops.WEIGHTED_KHOP, "weighted_khop_hash_dedup": ops.WEIGHTED_KHOP_HASH_DEDUP,
@@ -226,7 +284,6 @@ def main():
                                num_slots=NSLOT, num_pipelines=K, **extra_kw)
     out = [torch.empty((sampler.max_unique, dim), dtype=torch.float32, device=dev) for _ in range(NSLOT)]
     out_label = [torch.empty(sampler.max_seeds, dtype=torch.int64, device=dev) for _ in range(NSLOT)]
-    nmiss = torch.zeros(1, dtype=torch.int64, device=dev)
     L = len(fanouts)
     s_samples = [torch.cuda.Stream(device=dev) for _ in range(K)]
     s_extract = s_samples[0] if args.no_overlap else torch.cuda.Stream(device=dev)
@@ -237,7 +294,6 @@ def main():
     train = graph["train_set"]
     steps_per_epoch = parallel.steps_per_epoch(len(train), world, args.batch)
     per_rank = len(parallel.pad_train_set(train, world)) // world
-
     epoch_cache = {}
 
     def batch_seeds(step):
@@ -247,125 +303,204 @@ def main():
         lo = ls * args.batch
         return epoch_cache[ep][lo:min(per_rank, lo + args.batch)]
 
-    # the per-epoch reshuffle + H2D of the rank's slice happens once per epoch in the real loop; keep it
-    # out of the timed region (inputs are resident in HBM when timing starts)
-    all_seeds = [batch_seeds(s) for s in range(args.warmup + args.steps)]
-
-    acc = torch.zeros(3 * L + 2, dtype=torch.int64, device=dev)
-    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(args.steps)]
-    host_t = [0.0] * 6
-
-    def run_step(step, timed_idx=None):
-        seeds = all_seeds[step]
-        slot = step % NSLOT
-        s_sample = s_samples[step % K]
-        h0 = time.perf_counter()
-        with torch.cuda.stream(s_sample):
-            if slot_free[slot] is not None:
-                s_sample.wait_event(slot_free[slot])
-            if timed_idx is not None:
-                ev[timed_idx][0].record(s_sample)
-            h1 = time.perf_counter()
-            sampler.sample(seeds, slot=slot, copy_input_nodes=True)
-            h2 = time.perf_counter()
-            sampled = torch.cuda.Event()
-            sampled.record(s_sample)
-            if timed_idx is not None:
-                ev[timed_idx][1].record(s_sample)
-        h3 = time.perf_counter()
-        with torch.cuda.stream(s_extract):
-            s_extract.wait_event(sampled)
-            counts = sampler.counts_slots[slot]
-            if timed_idx is not None:
-                ev[timed_idx][2].record(s_extract)
-            if store is None:
-                ops.extract_cached(out[slot], sampler.input_nodes[slot], table, ptab, 0, host_feat,
-                                   num=sampler.max_unique, num_dev=counts[3 * L:3 * L + 1], num_miss=nmiss)
-            else:  # sharded store: peer loads inside the same kernel, or the all-to-all exchange
-                store.extract(sampler.input_nodes[slot], sampler.max_unique, out[slot],
-                              num_dev=counts[3 * L:3 * L + 1], num_miss=nmiss)
-            if timed_idx is not None:
-                ev[timed_idx][3].record(s_extract)
-            h4 = time.perf_counter()
-            ops.extract(labels, seeds, out=out_label[slot][:seeds.numel()])
-            h5 = time.perf_counter()
-            acc.add_(counts)
-            done = torch.cuda.Event()
-            done.record(s_extract)
-            slot_free[slot] = done
-        h6 = time.perf_counter()
-        for i, (a, b) in enumerate([(h0, h1), (h1, h2), (h2, h3), (h3, h4), (h4, h5), (h5, h6)]):
-            host_t[i] += b - a
-
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for s in range(args.warmup):
-        run_step(s)
-    barrier()
-    acc.zero_()
-    barrier()
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        run_step(args.warmup + k, k)
-    barrier()
-    elapsed = time.perf_counter() - t0
+    host_t = [0.0] * 6
 
+    def make_step(extract_fn, counters, acc, seeds_of):
+        """One step of the hot path: sample on the batch's pipeline stream, gather + labels on the extract stream."""
+        def run_step(step, ev4=None):
+            seeds = seeds_of(step)
+            slot = step % NSLOT
+            s_sample = s_samples[step % K]
+            h0 = time.perf_counter()
+            with torch.cuda.stream(s_sample):
+                if slot_free[slot] is not None:
+                    s_sample.wait_event(slot_free[slot])
+                if ev4 is not None:
+                    ev4[0].record(s_sample)
+                h1 = time.perf_counter()
+                sampler.sample(seeds, slot=slot, copy_input_nodes=True)
+                h2 = time.perf_counter()
+                sampled = torch.cuda.Event()
+                sampled.record(s_sample)
+                if ev4 is not None:
+                    ev4[1].record(s_sample)
+            h3 = time.perf_counter()
+            with torch.cuda.stream(s_extract):
+                s_extract.wait_event(sampled)
+                counts = sampler.counts_slots[slot]
+                if ev4 is not None:
+                    ev4[2].record(s_extract)
+                extract_fn(sampler.input_nodes[slot], sampler.max_unique, out[slot], counts[3 * L:3 * L + 1], counters)
+                if ev4 is not None:
+                    ev4[3].record(s_extract)
+                h4 = time.perf_counter()
+                ops.extract(labels, seeds, out=out_label[slot][:seeds.numel()])
+                h5 = time.perf_counter()
+                acc.add_(counts)
+                done = torch.cuda.Event()
+                done.record(s_extract)
+                slot_free[slot] = done
+            h6 = time.perf_counter()
+            for i, (a, b) in enumerate([(h0, h1), (h1, h2), (h2, h3), (h3, h4), (h4, h5), (h5, h6)]):
+                host_t[i] += b - a
+        return run_step
+
+    def measure(extract_fn, steps, warmup, repeats, first_step=0):
+        """warmup untimed steps, then `repeats` blocks of `steps` timed steps, each bracketed by barrier + synchronize.
+        Returns per-block dicts (elapsed = max over ranks) and the step index after the last one."""
+        total = warmup + steps * repeats
+        seeds_all = [batch_seeds(first_step + s) for s in range(total)]  # the per-epoch reshuffle + H2D stay outside
+        # rows by tier: [host misses, remote-shard rows, local-shard rows, replica rows]
+        counters = torch.zeros(4, dtype=torch.int64, device=dev)
+        acc = torch.zeros(3 * L + 2, dtype=torch.int64, device=dev)
+        run_step = make_step(extract_fn, counters, acc, lambda s: seeds_all[s])
+        for s in range(warmup):
+            run_step(s)
+        blocks = []
+        for r in range(repeats):
+            ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(steps)]
+            barrier()
+            acc.zero_()
+            counters.zero_()
+            barrier()
+            t0 = time.perf_counter()
+            for k in range(steps):
+                run_step(warmup + r * steps + k, ev[k])
+            barrier()
+            elapsed = time.perf_counter() - t0
+            c = acc.cpu().tolist()
+            if c[3 * L + 1]:
+                ops.check_device_status("bench")
+                raise SystemExit(f"device status {c[3 * L + 1]} after a timed block")
+            edges, rows = sum(c[3 * i] for i in range(L)), c[3 * L]
+            t_sample_ms = sum(e[0].elapsed_time(e[1]) for e in ev)   # on the sampling stream
+            t_extract_ms = sum(e[2].elapsed_time(e[3]) for e in ev)  # HIP events on the stream the gather is launched on
+            stats = torch.tensor([elapsed, float(edges), float(rows), t_sample_ms, t_extract_ms,
+                                  rows * row_bytes / (t_extract_ms / 1e3) / 1e9]
+                                 + [float(x) for x in counters.cpu().tolist()], dtype=torch.float64, device=dev)
+            if world > 1 and backend != "nccl":
+                stats = stats.cpu()
+            mx, sm = parallel.reduce_stats(stats, dist if world > 1 else None)
+            blocks.append(dict(elapsed=mx[0].item(), edges_all=sm[1].item(), rows_all=sm[2].item(), edges=edges,
+                               rows=rows, t_sample_ms=t_sample_ms, t_extract_ms=t_extract_ms,
+                               feat_rate_all=sm[5].item(), tiers_all=[sm[6 + i].item() for i in range(4)]))
+        return blocks, first_step + total
+
+    def median_block(blocks):
+        order = sorted(range(len(blocks)), key=lambda i: blocks[i]["elapsed"])
+        return blocks[order[(len(blocks) - 1) // 2]]
+
+    # ---- the main timed region -------------------------------------------------------------------------------
+    repeats = max(1, args.repeats)
+    extract_main, keep_main = build_store(main_store)
+    blocks, next_step = measure(extract_main, args.steps, args.warmup, repeats)
+    blk = median_block(blocks)
+    elapsed, edges_all = blk["elapsed"], blk["edges_all"]
+    edges, rows = blk["edges"], blk["rows"]
     if args.host_profile and rank == 0:
-        names = ["ev0", "sample", "ev1", "extract_cached", "ev2+label", "acc"]
-        print("host enqueue ms/step:", {n: round(1e3 * t / (args.steps + args.warmup), 4) for n, t in zip(names, host_t)},
-              file=sys.stderr)
+        names = ["ev0", "sample", "ev1", "extract", "ev2+label", "acc"]
+        n_all = args.warmup + args.steps * repeats
+        print("host enqueue ms/step:", {n: round(1e3 * t / n_all, 4) for n, t in zip(names, host_t)}, file=sys.stderr)
+
+    # self-check outside the timed region: the last batch's rows against the generator's closed form
+    last_slot = (args.warmup + args.steps * repeats - 1) % NSLOT
+    n_last = int(sampler.counts_slots[last_slot][3 * L].item())
+    ids = sampler.input_nodes[last_slot][:n_last].to(torch.int64)
+    stride = max(1, n_last // 4096)
+    want = torch.empty((ids[::stride].numel(), dim), dtype=torch.float32, device=dev)
+    feat_rows(ids[::stride], want)
+    rows_ok = bool(torch.equal(out[last_slot][:n_last][::stride], want))
+    if not rows_ok:
+        raise SystemExit("bench self-check failed: gathered rows differ from the feature generator")
+
     # the same gather with nothing beside it (one stream), for reference next to the in-pipeline figure
-    serial_us = None
-    if not args.no_overlap and store is None:
+    serial_us = serial_rows = None
+    if not args.no_overlap:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         reps = 10
-        counts = sampler.counts_slots[(args.warmup + args.steps - 1) % NSLOT]
-        slot = (args.warmup + args.steps - 1) % NSLOT
+        counts = sampler.counts_slots[last_slot]
+        scratch = torch.zeros(4, dtype=torch.int64, device=dev)
+        barrier()
         e0.record()
         for _ in range(reps):
-            ops.extract_cached(out[slot], sampler.input_nodes[slot], table, ptab, 0, host_feat,
-                               num=sampler.max_unique, num_dev=counts[3 * L:3 * L + 1], num_miss=nmiss)
+            extract_main(sampler.input_nodes[last_slot], sampler.max_unique, out[last_slot], counts[3 * L:3 * L + 1], scratch)
         e1.record()
         torch.cuda.synchronize()
         serial_us = e0.elapsed_time(e1) / reps * 1e3
-        serial_rows = int(counts[3 * L].item())
-    # self-check outside the timed region: the last batch's rows against the generator's closed form
-    last_slot = (args.warmup + args.steps - 1) % NSLOT
-    n_last = int(sampler.counts_slots[last_slot][3 * L].item())
-    ids = sampler.input_nodes[last_slot][:n_last].to(torch.int64)
-    sample_ids = ids[:: max(1, n_last // 4096)]
-    want = torch.empty((sample_ids.numel(), dim), dtype=torch.float32, device=dev)
-    feat_rows(sample_ids, want)
-    rows_ok = bool(torch.equal(out[last_slot][:n_last][:: max(1, n_last // 4096)], want))
-    if not rows_ok:
-        raise SystemExit("bench self-check failed: gathered rows differ from the feature generator")
-    c = acc.cpu().tolist()
-    edges = sum(c[3 * i] for i in range(L))
-    rows = c[3 * L]
-    t_sample_ms = sum(e[0].elapsed_time(e[1]) for e in ev)   # on the sampling stream
-    t_extract_ms = sum(e[2].elapsed_time(e[3]) for e in ev)  # HIP events on the stream the gather is launched on
+        serial_rows = n_last
 
-    feat_rate = rows * dim * 4 / (t_extract_ms / 1e3) / 1e9  # this rank's GB/s over its own gather time
-    stats = torch.tensor([elapsed, float(edges), float(rows), t_sample_ms, t_extract_ms, feat_rate],
-                         dtype=torch.float64, device=dev)
-    if world > 1 and backend != "nccl":
-        stats = stats.cpu()
-    mx, sm = parallel.reduce_stats(stats, dist if world > 1 else None)
-    elapsed, edges_all, rows_all, feat_rate_all = mx[0].item(), sm[1].item(), sm[2].item(), sm[5].item()
+    # ---- N > 1: the other stores, one block each ------------------------------------------------------------------
+    stores = None
+    if world > 1:
+        def store_record(b, kind):
+            t = b["tiers_all"]
+            remote_rows = t[1] if kind != "a2a" else b["rows_all"] * (world - 1) / world
+            return {"edges_per_s": b["edges_all"] / b["elapsed"], "ms_per_step": b["elapsed"] / args.steps * 1e3,
+                    "feature_extract_GBps": b["feat_rate_all"], "rows_per_step": b["rows_all"] / args.steps,
+                    "remote_row_fraction": remote_rows / max(1.0, b["rows_all"]),
+                    "xgmi_bytes_per_step": remote_rows * row_bytes / args.steps,
+                    "rows_by_tier": {"host": t[0], "remote_shard": t[1], "local_shard": t[2], "replica": t[3]}}
+        stores = {main_store: store_record(blk, main_store)}
+        for kind in [k for k in args.other_stores.split(",") if k and k != main_store]:
+            extract_main = keep_main = None
+            torch.cuda.empty_cache()
+            ex, keep_main = build_store(kind)
+            b2, next_step = measure(ex, args.steps, 2, 1, first_step=next_step)
+            stores[kind] = store_record(b2[0], kind)
+
+    # ---- N = 1: BASELINE configs[2], every row in pinned host DRAM (cache_ratio 0) -----------------------------
+    host_tier = None
+    cpu_feat = None
+    if world == 1 and full and not args.no_host_tier:
+        cache = keep_main["cache"]
+        t0 = time.perf_counter()
+        hf = torch.empty((N, dim), dtype=torch.float32, pin_memory=True)  # hipHostMalloc, device-mapped
+        t_pin = time.perf_counter() - t0
+        hf.copy_(cache)  # the same rows the HBM tier holds (node order)
+        torch.cuda.synchronize()
+        # the box's pinned-copy rate, the ceiling of this tier: H2D of a 4-GiB slice of the table, 3 times
+        probe_rows = min(N, (4 << 30) // row_bytes)
+        dst = torch.empty((probe_rows, dim), dtype=torch.float32, device=dev)
+        c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        dst.copy_(hf[:probe_rows], non_blocking=True)
+        c0.record()
+        for _ in range(3):
+            dst.copy_(hf[:probe_rows], non_blocking=True)
+        c1.record()
+        torch.cuda.synchronize()
+        pinned_GBps = 3 * probe_rows * row_bytes / (c0.elapsed_time(c1) / 1e3) / 1e9
+        del dst
+
+        def extract_host(nodes, num_max, o, num_dev, counters):  # DoGPUFeatureExtract, dist_loops.cc:585-634
+            ops.gather_scatter(o, hf, nodes, None, num=num_max, num_dev=num_dev)
+        hb, next_step = measure(extract_host, args.host_steps, 1, 1, first_step=next_step)
+        h = hb[0]
+        host_tier = {
+            "config": "BASELINE configs[2]: same workload, cache_ratio 0 -- every feature row in pinned host DRAM "
+                      "(hipHostMalloc, device-mapped), gathered zero-copy by the same kernel",
+            "steps": args.host_steps, "ms_per_step": h["elapsed"] / args.host_steps * 1e3,
+            "edges_per_s": h["edges_all"] / h["elapsed"],
+            "feature_extract_GBps": h["feat_rate_all"], "rows_per_step": h["rows"] / args.host_steps,
+            "pinned_h2d_copy_GBps": pinned_GBps, "frac_of_pinned_copy": h["feat_rate_all"] / pinned_GBps,
+            "pinned_GiB": N * row_bytes / 2 ** 30, "pin_seconds": t_pin,
+        }
+        cpu_feat = hf.numpy()
 
     if rank == 0:
-        row_bytes = dim * 4
-        ext_s = t_extract_ms / 1e3
+        ext_s = blk["t_extract_ms"] / 1e3
         algo_bytes_per_launch = rows / args.steps * (4 + 2 * row_bytes)
         avg_launch_s = ext_s / args.steps
         achieved = algo_bytes_per_launch / avg_launch_s / 1e9
-        tr = measured_traffic()
+        tr = measured_traffic(args.preset)
         traffic = None
-        if tr is not None:  # PMC bytes per row (profiled run) x rows of this run / this run's launch time
+        if tr is not None:  # PMC bytes per row (profiled run of this command) x rows of this run / this run's launch time
             traffic = tr["hbm_bytes_per_launch"] / tr["rows_per_launch"] * (rows / args.steps) / avg_launch_s / 1e9
+        elapsed_all = [b["elapsed"] for b in blocks]
         res = {
             "metric": "sampled edges/s + feature-extract GB/s per epoch-step",
             "value": edges_all / elapsed,
@@ -380,56 +515,59 @@ def main():
             "dtype": "u32 ids / f32 rows (bit copy)",
             "data": "synthetic",
             "rows_verified": rows_ok,
+            "repeats": {"blocks": len(blocks), "reported": "median block of K timed steps",
+                        "edges_per_s_each": [b["edges_all"] / b["elapsed"] for b in blocks],
+                        "spread": (max(elapsed_all) - min(elapsed_all)) / statistics.median(elapsed_all)},
             "config": {
                 "workload": f"{args.preset}-shaped power-law CSR N={N} E={meta['num_edge']} f32 dim {dim}, "
-                            f"GraphSAGE fanout {fanouts} {args.sample_type}, batch {args.batch}, "
-                            f"graph in HBM, feature cache_ratio {args.cache_ratio} (rest in pinned host DRAM), "
-                            f"seeds DP over {world} GPU(s), feature store: {args.store if world > 1 else 'local'}",
+                            f"fanout {fanouts} {args.sample_type}, batch {args.batch}, "
+                            f"graph in HBM, feature cache_ratio {args.cache_ratio}"
+                            f"{' (all rows in HBM, node order)' if full else ' (rest in pinned host DRAM)'}, "
+                            f"seeds DP over {world} GPU(s), feature store: {main_store}",
                 "global_batch": args.batch * world,
                 "parallelism": f"dp{world}",
                 "streams": "1 (serial)" if args.no_overlap else
-                           f"{K} sampling pipelines (batches in flight, RNG pool consumed in batch order) + 1 extract stream",
+                           f"{K} sampling pipeline(s) (batches in flight, RNG pool consumed in batch order) + 1 extract stream",
             },
-            "feature_extract_GBps": feat_rate_all,  # sum over ranks of rows*dim*4 / (time inside the gather kernel)
+            "feature_extract_GBps": blk["feat_rate_all"],  # sum over ranks of rows*dim*4 / (time inside the gather kernel)
             "per_gpu": {
-                "sample_ms_per_step": t_sample_ms / args.steps,  # latency of one batch on its pipeline (they overlap)
-                "extract_ms_per_step": t_extract_ms / args.steps,
+                "sample_ms_per_step": blk["t_sample_ms"] / args.steps,  # latency of one batch on its pipeline (they overlap)
+                "extract_ms_per_step": blk["t_extract_ms"] / args.steps,
                 # sampled edges over the time the sampler alone was busy: only meaningful with one pipeline
-                "sample_only_edges_per_s": edges / (t_sample_ms / 1e3) if K == 1 else None,
+                "sample_only_edges_per_s": edges / (blk["t_sample_ms"] / 1e3) if K == 1 else None,
                 "edges_per_step": edges / args.steps,
                 "rows_per_step": rows / args.steps,
             },
             "roofline": {
-                "kernel": "k_gather_rows<16, CachedRows, ident-dst, nt> (ggms_extract_cached)",
+                "kernel": "k_gather_rows<16-B chunks, ident-dst, nt> (ggms_extract_cached)",
                 "bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                 "frac": achieved / 8000.0, "traffic": traffic,
-                # same launch with nothing beside it (see roofline_alone): in the pipeline the gather shares HBM with
-                # the sampling kernels of the next batches
+                # the READ side alone, rows * (dim * 4 + 4) / t / 8e12 (a gather also writes every byte
+                # it reads, so this figure cannot exceed half of what the memory system sustains)
+                "hbm_read_frac": rows / args.steps * (row_bytes + 4) / avg_launch_s / 8e12,
+                # same launch with nothing beside it: in the pipeline the gather shares HBM with the sampling kernels
                 "frac_alone": None if serial_us is None else
                 serial_rows * (4 + 2 * row_bytes) / (serial_us * 1e-6) / 1e9 / 8000.0,
+                "hbm_read_frac_alone": None if serial_us is None else
+                serial_rows * (row_bytes + 4) / (serial_us * 1e-6) / 8e12,
                 "algorithmic_bytes_per_row": 4 + 2 * row_bytes,
                 "avg_launch_us": avg_launch_s * 1e6,
+                "avg_launch_us_alone": serial_us,
                 "traffic_source": tr["source"] if tr else None,
             },
-            # the step as a whole against the same roof: profiled HBM bytes of one step (gather, corrected, scaled to
-            # this run's rows + sampler kernels, raw counters = lower bound) / this run's step time
-            "pipeline_hbm": None if not tr or "sampler_hbm_bytes_per_step_raw" not in tr else {
-                "bytes_per_step": tr["hbm_bytes_per_launch"] / tr["rows_per_launch"] * (rows / args.steps)
-                + tr["sampler_hbm_bytes_per_step_raw"],
-                "GBps": (tr["hbm_bytes_per_launch"] / tr["rows_per_launch"] * (rows / args.steps)
-                         + tr["sampler_hbm_bytes_per_step_raw"]) / (elapsed / args.steps) / 1e9,
-                "frac_of_peak": (tr["hbm_bytes_per_launch"] / tr["rows_per_launch"] * (rows / args.steps)
-                                 + tr["sampler_hbm_bytes_per_step_raw"]) / (elapsed / args.steps) / 8e12,
-                "source": tr["source"],
-            },
-            "roofline_alone": None if serial_us is None else {
-                "note": "same kernel, last batch's rows, nothing running beside it (10 launches after the timed region)",
-                "avg_launch_us": serial_us, "achieved": serial_rows * (4 + 2 * row_bytes) / (serial_us * 1e-6) / 1e9,
-                "frac": serial_rows * (4 + 2 * row_bytes) / (serial_us * 1e-6) / 1e9 / 8000.0,
-            },
         }
+        if stores is not None:
+            res["stores"] = stores
+        if host_tier is not None:
+            res["host_tier"] = host_tier
         if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(graph, fanouts, args.batch, dim, args.cpu_seconds)
+            if cpu_feat is None:  # no host copy of the table yet (partial cache: host_feat; else generate it)
+                if host_feat is not None:
+                    cpu_feat = host_feat.numpy()
+                else:
+                    cpu_feat = np.empty((N, dim), np.float32)
+                    feat_rows(torch.arange(N, dtype=torch.int64), torch.from_numpy(cpu_feat))
+            res["cpu_baseline"] = cpu_baseline(graph, fanouts, args.batch, cpu_feat, args.cpu_seconds)
         print(json.dumps(res))
     if world > 1:
         dist.destroy_process_group()

@@ -355,12 +355,39 @@ int ggms_gather_scatter_partition(void *out, const void *const *parts_dev,
 /* One-pass replacement of GetMissCacheIndex + GPUExtractMissData +
  * CombineCacheData (dist_loops.cc:1209-1285): out[i,:] = table[nodes[i]] ==
  * kEmptyKey ? host_feat[nodes[i],:] : parts[slot % P][slot / P,:].
- * num_part == 0 -> single cache array parts_dev[0].  Also counts misses. */
+ * num_part == 0 -> single cache array parts_dev[0].  Also counts misses.
+ * table == NULL: the whole feature table is cached and kept in NODE order (slot = node id):
+ * out[i,:] = parts[node % P][node / P,:] with no table read and no miss tier -- the layout of a full cache
+ * is not observable through the reference's interface, and the gather loses one dependent random read per row.
+ * The same convention holds for ggms_owner_histogram. */
 int ggms_extract_cached(void *out, const ggms_id_t *nodes, size_t num_nodes,
                         const uint64_t *num_nodes_dev, const ggms_id_t *table,
                         const void *const *parts_dev, uint32_t num_part,
                         const void *host_feat, size_t dim, int dtype,
                         uint64_t *num_miss_dev, ggms_stream_t stream);
+
+/* Every tier of the store behind one gather (GGMS across GPUs with hot-row replication):
+ *   slot = table ? table[node] : node            (table NULL: full cache, slot = node id)
+ *   slot == kEmptyKey      host_feat[node]       pinned host DRAM, zero-copy        (GPUExtractMissData :573-625)
+ *   slot <  num_replica    replica[slot]         this GPU's copy of the hottest rows (what PartitionSolver's
+ *                                                replica placement buys on NVLink, dist_graph.cu:40-222)
+ *   else s = slot - num_replica                  parts[s % num_part][s / num_part]: local HBM or a peer's shard
+ *                                                over xGMI (combine_cache_data_for_partition :277-299)
+ * tier_rows_dev (optional, 4 zeroed uint64): rows served by {host, remote shard, local shard, replica} are
+ * ADDED to it -- count_local_cache (:171-207) generalised. */
+typedef struct {
+  const ggms_id_t *table;
+  const void *replica;
+  uint64_t num_replica;
+  const void *const *parts_dev; /* DEVICE array of num_part base pointers */
+  uint32_t num_part;
+  uint32_t my_part;
+  const void *host_feat;
+} ggms_feature_tiers_t;
+int ggms_extract_tiered(void *out, const ggms_id_t *nodes, size_t num_nodes,
+                        const uint64_t *num_nodes_dev,
+                        const ggms_feature_tiers_t *tiers, size_t dim, int dtype,
+                        uint64_t *tier_rows_dev, ggms_stream_t stream);
 
 
 /* ---------------------------------------------------------------------------

@@ -327,6 +327,42 @@ class HashTable:
         return ns[: src.size], nd[: src.size]
 
 
+class CpuHashTable2:
+    """CPUHashTable2 with its OpenMP loops (cpu/cpu_hashtable2.cc:35-191); threads=1 == HashTable."""
+
+    def __init__(self, num_node, threads=1):
+        self.threads = int(threads)
+        lib().orc_cpu_ht2_create.restype = C.c_void_p
+        lib().orc_cpu_ht2_populate.restype = C.c_size_t
+        lib().orc_cpu_ht2_unique.restype = u32p
+        self._h = C.c_void_p(lib().orc_cpu_ht2_create(_sz(num_node), C.c_int(self.threads)))
+        self.num_items = 0
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().orc_cpu_ht2_destroy(self._h)
+            self._h = None
+
+    def reset(self):
+        lib().orc_cpu_ht2_reset(self._h, C.c_int(self.threads))
+        self.num_items = 0
+
+    def fill_with_duplicates(self, inp):
+        inp = _u32(inp)
+        self.num_items = int(lib().orc_cpu_ht2_populate(self._h, _p(inp), _sz(inp.size), C.c_int(self.threads)))
+        return self.num_items
+
+    def unique(self):
+        ptr = lib().orc_cpu_ht2_unique(self._h)
+        return np.ctypeslib.as_array(ptr, shape=(max(self.num_items, 1),))[: self.num_items].copy()
+
+    def map_edges(self, src, dst):
+        src, dst = _u32(src), _u32(dst)
+        ns, nd = np.empty(max(1, src.size), np.uint32), np.empty(max(1, src.size), np.uint32)
+        lib().orc_cpu_ht2_map_edges(self._h, _p(src), _p(dst), _sz(src.size), _p(ns), _p(nd), C.c_int(self.threads))
+        return ns[: src.size], nd[: src.size]
+
+
 class _SampleResult(C.Structure):
     _fields_ = [("num_layer", C.c_size_t), ("num_src", C.POINTER(C.c_size_t)),
                 ("num_dst", C.POINTER(C.c_size_t)), ("num_edge", C.POINTER(C.c_size_t)),

@@ -956,6 +956,105 @@ void orc_ht_map_edges(const orc_hashtable_t *ht, const orc_id_t *src,
   }
 }
 
+/* ----------------------------------------------------------------------- */
+/* CPUHashTable2 with its OpenMP structure (cpu/cpu_hashtable2.cc:35-191): a direct-indexed bucket per node
+ * id {key, local, index, version}; Populate = CAS claim, per-thread count, serial prefix over threads, per-thread
+ * id assignment (static schedule, so a thread's items are a contiguous index range and ids stay ordered by
+ * input index within and across threads); MapEdges / Reset parallel loops.  With one thread this is exactly
+ * orc_ht_fill_with_duplicates; with several the winner among duplicates is whichever CAS lands first, as in the
+ * reference.  Used by bench.py's cpu_baseline so that the dedup/remap leg runs on as many cores as the
+ * sampler and extract legs (the reference's default hash table is this one, run_config.cc:56). */
+typedef struct { orc_id_t key, local, index, version; } orc_bucket2_t;
+struct orc_cpu_ht2 {
+  orc_bucket2_t *o2n;
+  orc_id_t *n2o;
+  size_t num_node, num_items;
+  orc_id_t version;
+};
+
+orc_cpu_ht2_t *orc_cpu_ht2_create(size_t num_node, int threads) {
+  orc_cpu_ht2_t *ht = (orc_cpu_ht2_t *)malloc(sizeof(*ht));
+  ht->o2n = (orc_bucket2_t *)malloc(sizeof(orc_bucket2_t) * (num_node + 1));
+  ht->n2o = (orc_id_t *)malloc(sizeof(orc_id_t) * (num_node + 1));
+  ht->num_node = num_node;
+  ht->num_items = 0;
+  ht->version = 0;
+#pragma omp parallel for num_threads(threads) schedule(static)
+  for (size_t i = 0; i < num_node; ++i) { /* InitTable, :193-203 */
+    ht->o2n[i].key = ORC_EMPTY_KEY;
+    ht->o2n[i].local = ORC_EMPTY_KEY;
+    ht->o2n[i].index = ORC_EMPTY_KEY;
+    ht->o2n[i].version = ORC_EMPTY_KEY;
+  }
+  return ht;
+}
+
+void orc_cpu_ht2_destroy(orc_cpu_ht2_t *ht) {
+  if (!ht) return;
+  free(ht->o2n);
+  free(ht->n2o);
+  free(ht);
+}
+
+void orc_cpu_ht2_reset(orc_cpu_ht2_t *ht, int threads) { /* :183-191 */
+#pragma omp parallel for num_threads(threads) schedule(static)
+  for (size_t i = 0; i < ht->num_items; ++i) ht->o2n[ht->n2o[i]].key = ORC_EMPTY_KEY;
+  ht->num_items = 0;
+  ht->version = 0;
+}
+
+size_t orc_cpu_ht2_populate(orc_cpu_ht2_t *ht, const orc_id_t *input, size_t num_input, int threads) { /* :53-107 */
+  orc_bucket2_t *o2n = ht->o2n;
+  const orc_id_t version = ht->version;
+#pragma omp parallel for num_threads(threads) schedule(static)
+  for (size_t i = 0; i < num_input; ++i) {
+    const orc_id_t id = input[i];
+    const orc_id_t key = __sync_val_compare_and_swap(&o2n[id].key, ORC_EMPTY_KEY, id);
+    if (key == ORC_EMPTY_KEY) {
+      o2n[id].index = (orc_id_t)i;
+      o2n[id].version = version;
+    }
+  }
+  size_t *prefix = (size_t *)calloc((size_t)threads + 1, 16 * sizeof(size_t)); /* one cache line per thread */
+#pragma omp parallel for num_threads(threads) schedule(static)
+  for (size_t i = 0; i < num_input; ++i) {
+    const orc_bucket2_t *b = &o2n[input[i]];
+    if (b->index == (orc_id_t)i && b->version == version) prefix[16 * (size_t)omp_get_thread_num()]++;
+  }
+  size_t sum = 0;
+  for (int t = 0; t <= threads; ++t) {
+    const size_t tmp = prefix[16 * (size_t)t];
+    prefix[16 * (size_t)t] = sum;
+    sum += tmp;
+  }
+  const size_t start = ht->num_items;
+#pragma omp parallel for num_threads(threads) schedule(static)
+  for (size_t i = 0; i < num_input; ++i) {
+    const orc_id_t id = input[i];
+    orc_bucket2_t *b = &o2n[id];
+    if (b->index == (orc_id_t)i && b->version == version) {
+      const size_t new_id = start + prefix[16 * (size_t)omp_get_thread_num()]++;
+      b->local = (orc_id_t)new_id;
+      ht->n2o[new_id] = id;
+    }
+  }
+  ht->num_items += prefix[16 * (size_t)threads];
+  ht->version++;
+  free(prefix);
+  return ht->num_items;
+}
+
+const orc_id_t *orc_cpu_ht2_unique(const orc_cpu_ht2_t *ht) { return ht->n2o; }
+
+void orc_cpu_ht2_map_edges(const orc_cpu_ht2_t *ht, const orc_id_t *src, const orc_id_t *dst, size_t len,
+                           orc_id_t *new_src, orc_id_t *new_dst, int threads) { /* :148-160 */
+#pragma omp parallel for num_threads(threads) schedule(static)
+  for (size_t i = 0; i < len; ++i) {
+    new_src[i] = ht->o2n[src[i]].local;
+    new_dst[i] = ht->o2n[dst[i]].local;
+  }
+}
+
 /* ======================================================================= */
 /* Multi-layer loop: dist_loops.cc:62-368 (GPU), cpu_loops.cc:55-192 (CPU) */
 /* ======================================================================= */

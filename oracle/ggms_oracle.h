@@ -163,6 +163,15 @@ void orc_random_walk_raw(const orc_id_t *indptr, const orc_id_t *indices,
 
 /* ---- ordered hash table (cuda_hashtable.cu / cpu_hashtable2.cc) --------- */
 typedef struct orc_hashtable orc_hashtable_t;
+/* CPUHashTable2 with its OpenMP loops (cpu/cpu_hashtable2.cc:35-191); one thread == orc_ht_* above */
+typedef struct orc_cpu_ht2 orc_cpu_ht2_t;
+orc_cpu_ht2_t *orc_cpu_ht2_create(size_t num_node, int threads);
+void orc_cpu_ht2_destroy(orc_cpu_ht2_t *ht);
+void orc_cpu_ht2_reset(orc_cpu_ht2_t *ht, int threads);
+size_t orc_cpu_ht2_populate(orc_cpu_ht2_t *ht, const orc_id_t *input, size_t num_input, int threads);
+const orc_id_t *orc_cpu_ht2_unique(const orc_cpu_ht2_t *ht);
+void orc_cpu_ht2_map_edges(const orc_cpu_ht2_t *ht, const orc_id_t *src, const orc_id_t *dst, size_t len,
+                           orc_id_t *new_src, orc_id_t *new_dst, int threads);
 orc_hashtable_t *orc_ht_create(size_t max_node_id_plus1, size_t capacity);
 void orc_ht_destroy(orc_hashtable_t *ht);
 void orc_ht_reset(orc_hashtable_t *ht);        /* cuda_hashtable.cu:739-742 */

@@ -31,18 +31,39 @@ def test_single_gpu_line():
                         "--batch", "512", "--cpu-seconds", "1"], capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
     d = _last_json(r.stdout)
-    assert KEYS <= set(d) and "cpu_baseline" in d
+    assert KEYS <= set(d) and "cpu_baseline" in d and "host_tier" in d
     assert d["n_gpus"] == 1 and d["value"] > 0 and d["roofline"]["bound"] == "hbm" and d["config"]["workload"]
+    assert d["rows_verified"] and d["repeats"]["blocks"] == 3 and 0 < d["roofline"]["hbm_read_frac"] < 0.5
+    assert d["host_tier"]["feature_extract_GBps"] > 0 and d["host_tier"]["pinned_h2d_copy_GBps"] > 0
+    cb = d["cpu_baseline"]
+    assert cb["cores"] >= 1 and cb["value"] > 0 and set(cb["seconds"]) == {"sample", "remap", "extract", "total"}
 
 
-@pytest.mark.parametrize("store", ["replica", "peer", "a2a"])
+def test_two_ranks_default_is_the_sharded_store():
+    """--gpus 2 with no --store: the main region runs on GGMS shards (peer), replica + hybrid are measured beside it."""
+    env = dict(os.environ, GGMS_BENCH_DEVICE="0", GGMS_BENCH_BACKEND="gloo")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"),
+                        "--gpus", "2", "--preset", "tiny", "--steps", "4", "--warmup", "1", "--batch", "512"],
+                       capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = _last_json(r.stdout)
+    assert KEYS <= set(d) and d["n_gpus"] == 2 and "feature store: peer" in d["config"]["workload"]
+    st = d["stores"]
+    assert set(st) == {"peer", "replica", "hybrid"}
+    assert 0.3 < st["peer"]["remote_row_fraction"] < 0.7 and st["peer"]["xgmi_bytes_per_step"] > 0
+    assert st["replica"]["remote_row_fraction"] == 0 and st["replica"]["xgmi_bytes_per_step"] == 0
+    assert 0 < st["hybrid"]["remote_row_fraction"] < st["peer"]["remote_row_fraction"]
+
+
+@pytest.mark.parametrize("store", ["replica", "peer", "a2a", "hybrid"])
 def test_two_ranks_one_gpu(store):
     env = dict(os.environ, GGMS_BENCH_DEVICE="0", GGMS_BENCH_BACKEND="gloo")
     port = _free_port()
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                         "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
                         "--gpus", "2", "--preset", "tiny", "--steps", "4", "--warmup", "1", "--batch", "512",
-                        "--store", store, "--cache-ratio", "0.6"],
+                        "--store", store, "--cache-ratio", "0.6", "--other-stores", ""],
                        capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
     assert r.returncode == 0, r.stderr[-3000:]
     d = _last_json(r.stdout)

@@ -43,10 +43,20 @@ def _worker(rank, world, port, mode, q):
     def rows_of(node_ids, out):
         out.copy_(torch.from_numpy(feat[node_ids.numpy()]))
 
-    shard, holder = ggms_store.shard_rows(rows_of, t_rank, num_cached, world, rank, dim, torch.float32, dev,
-                                          shared=(mode == "peer"))
-    store = ggms_store.FeatureShards(shard, t_table, world, rank, mode=mode, dist=dist, host_feat=host_feat)
-    if mode == "peer":
+    # hybrid: the R hottest slots replicated on every GPU, the tail sharded; ident: everything cached, slot = node id
+    R = 4_000 if mode == "hybrid" else 0
+    replica = None
+    if mode == "ident":
+        num_cached, rank_list, t_table = N, np.arange(N, dtype=np.int64), None
+        t_rank = torch.from_numpy(rank_list)
+    if R:
+        replica = torch.from_numpy(feat[rank_list[:R]]).to(dev)
+    peer = mode != "a2a"
+    shard, holder = ggms_store.shard_rows(rows_of, t_rank[R:], num_cached - R, world, rank, dim, torch.float32, dev,
+                                          shared=peer)
+    store = ggms_store.FeatureShards(shard, t_table, world, rank, mode="peer" if peer else "a2a", dist=dist,
+                                     host_feat=host_feat, replica=replica)
+    if peer:
         store.connect_peers(holder)
     ok = True
     for b in range(3):
@@ -54,10 +64,20 @@ def _worker(rank, world, port, mode, q):
         nodes = np.random.RandomState(100 * b + rank).randint(0, N, n).astype(np.uint32)
         t_nodes = torch.from_numpy(nodes.view(np.int32)).to(dev)
         out = torch.zeros((n + 3, dim), dtype=torch.float32, device=dev)
-        store.extract(t_nodes, n, out)
+        counters = torch.zeros(4, dtype=torch.int64, device=dev)
+        if mode in ("hybrid", "ident"):
+            store.extract(t_nodes, n, out, counters=counters)
+        else:
+            store.extract(t_nodes, n, out)
         torch.cuda.synchronize()
         got = out.cpu().numpy()
         ok = ok and got[:n].tobytes() == oracle.extract(feat, nodes).tobytes() and not got[n:].any()
+        if mode in ("hybrid", "ident"):  # rows by tier: host, remote shard, local shard, replica
+            slots = nodes.astype(np.int64) if t_table is None else table[nodes].astype(np.int64)
+            sh = slots >= R
+            want = [int((slots < 0).sum()), int((sh & ((slots - R) % world != rank)).sum()),
+                    int((sh & ((slots - R) % world == rank)).sum()), int(((slots >= 0) & (slots < R)).sum())]
+            ok = ok and counters.cpu().tolist() == want
     dist.barrier()  # nobody unmaps a shard a peer may still be reading
     q.put((rank, ok))
     dist.barrier()
@@ -66,7 +86,7 @@ def _worker(rank, world, port, mode, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("mode", ["peer", "a2a"])
+@pytest.mark.parametrize("mode", ["peer", "a2a", "hybrid", "ident"])
 def test_two_processes_one_gpu(mode):
     world = 2
     ctx = mp.get_context("spawn")

@@ -81,6 +81,79 @@ class _NumpyLeaf:
             out[dst_index.long()] = rows
 
 
+    def gather_tiered(self, out, nodes, num, table, replica, parts, num_part, my_part, host_feat, num_dev=None,
+                      counters=None):
+        """The tier map of ggms_extract_tiered (include/ggms.h) in plain torch; parts = list of every rank's shard."""
+        R = 0 if replica is None else replica.shape[0]
+        for i in range(num):
+            node = int(nodes[i])
+            slot = node if table is None else int(table[node])
+            if slot < 0:
+                out[i], tier = host_feat[node], 0
+            elif slot < R:
+                out[i], tier = replica[slot], 3
+            else:
+                s = slot - R
+                out[i], tier = parts[s % num_part][s // num_part], (2 if s % num_part == my_part else 1)
+            if counters is not None:
+                counters[tier] += 1
+
+
+def _hybrid_worker(rank, world, port, q):
+    """'hybrid' store on two CPU ranks: the R hottest slots replicated on every rank, the tail sharded modulo P."""
+    from xgnn_amd.ggms_store import FeatureShards
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    N, dim, num_cached, R = 400, 5, 300, 77
+    g = torch.Generator().manual_seed(4)
+    feat = torch.randn(N, dim, generator=g)
+    rank_list = torch.randperm(N, generator=g)
+    table = torch.full((N,), -1, dtype=torch.int32)
+    table[rank_list[:num_cached]] = torch.arange(num_cached, dtype=torch.int32)
+    replica = feat[rank_list[:R]].contiguous()
+    shard = feat[rank_list[R + rank:num_cached:world]].contiguous()  # slot s >= R -> rank (s - R) % P, row (s - R) // P
+    shards = [None] * world
+    dist.all_gather_object(shards, shard)  # stands in for the hipIpc mapping of the peers' shards
+    store = FeatureShards(shard, table, world, rank, mode="peer", dist=dist, leaf=_NumpyLeaf(), host_feat=feat,
+                          replica=replica)
+    store.parts_table = shards
+    ok = True
+    for b in range(3):
+        nodes = torch.randint(0, N, (120 + 11 * rank + b,), generator=torch.Generator().manual_seed(7 * b + rank),
+                              dtype=torch.int32)
+        out = torch.zeros(nodes.numel() + 2, dim)
+        counters = torch.zeros(4, dtype=torch.int64)
+        store.extract(nodes, nodes.numel(), out, counters=counters)
+        slots = table[nodes.long()]
+        want = [int((slots < 0).sum()), int(((slots >= R) & ((slots - R) % world != rank)).sum()),
+                int(((slots >= R) & ((slots - R) % world == rank)).sum()), int(((slots >= 0) & (slots < R)).sum())]
+        ok = ok and torch.equal(out[:nodes.numel()], feat[nodes.long()]) and counters.tolist() == want
+    # a peer store without a host tier must refuse a table that has uncached nodes (it would fault on the GPU)
+    try:
+        FeatureShards(shard, table, world, rank, mode="peer", dist=dist, leaf=_NumpyLeaf(), host_feat=None)
+        ok = False
+    except ValueError:
+        pass
+    dist.barrier()
+    q.put((rank, ok))
+    dist.destroy_process_group()
+
+
+def test_two_rank_hybrid_store_tier_map():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_hybrid_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res == [(0, True), (1, True)]
+
+
 def _shard_worker(rank, world, port, q):
     from xgnn_amd.ggms_store import FeatureShards
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))

@@ -26,6 +26,13 @@ class SampleExtra(C.Structure):
                 ("rng_wait", C.c_void_p), ("rng_done", C.c_void_p)]
 
 
+class FeatureTiers(C.Structure):
+    """ggms_feature_tiers_t"""
+    _fields_ = [("table", C.c_void_p), ("replica", C.c_void_p), ("num_replica", C.c_uint64),
+                ("parts_dev", C.c_void_p), ("num_part", C.c_uint32), ("my_part", C.c_uint32),
+                ("host_feat", C.c_void_p)]
+
+
 class HashTable(C.Structure):
     """ggms_hashtable_t"""
     _fields_ = [("o2n", C.c_void_p), ("n2o", C.c_void_p), ("num_items_dev", C.c_void_p),
@@ -84,6 +91,7 @@ SYMBOLS = {
     "ggms_gather_scatter": (_i, [_vp, _vp, _vp, _vp, _sz, _vp, _sz, _i, _vp]),
     "ggms_gather_scatter_partition": (_i, [_vp, _vp, _u32, _vp, _vp, _sz, _vp, _sz, _i, _vp]),
     "ggms_extract_cached": (_i, [_vp, _vp, _sz, _vp, _vp, _vp, _u32, _vp, _sz, _i, _vp, _vp]),
+    "ggms_extract_tiered": (_i, [_vp, _vp, _sz, _vp, C.POINTER(FeatureTiers), _sz, _i, _vp, _vp]),
 }
 
 

@@ -66,7 +66,7 @@ __global__ __launch_bounds__(kBlock) void k_owner_histogram(const uint32_t *__re
     const bool valid = i < n;
     uint32_t owner = 0xffffffffu;
     if (valid) {
-      const uint32_t slot = table[nodes[i]];
+      const uint32_t slot = table ? table[nodes[i]] : nodes[i]; // no table: every node cached at slot = node id
       slots_out[i] = slot;
       owner = owner_of(slot, num_part);
     }
@@ -151,7 +151,7 @@ int ggms_owner_histogram(const ggms_id_t *table, const ggms_id_t *nodes, size_t 
                          ggms_stream_t stream) {
   GGMS_CHECK_ARG(num_part >= 1 && num_part <= 64 && counts_dev);
   if (num_nodes == 0) return GGMS_OK;
-  GGMS_CHECK_ARG(table && nodes && slots_out && num_nodes < (1ull << 32));
+  GGMS_CHECK_ARG(nodes && slots_out && num_nodes < (1ull << 32)); // table == NULL: identity slots (full cache)
   hipLaunchKernelGGL(k_owner_histogram, dim3(grid_for(num_nodes, kBlock)), dim3(kBlock), 0, to_stream(stream), table,
                      nodes, count_of(num_nodes, num_nodes_dev), num_part, slots_out, (unsigned long long *)counts_dev);
   GGMS_LAUNCH_CHECK();

@@ -546,9 +546,18 @@ void Engine::BuildCache() {
     std::mt19937 eg((uint32_t)num_cached_nodes_);
     std::shuffle(rank.begin(), rank.begin() + num_cached_nodes_, eg);
   }
-  std::vector<uint32_t> table(ds.num_node, GGMS_EMPTY_KEY);
-  for (size_t i = 0; i < num_cached_nodes_; ++i) table[rank[i]] = (uint32_t)i; // :197-229
-  cache_table_ = (uint32_t *)dev_upload(table.data(), ds.num_node * 4, stream_);
+  // Everything cached (cache_percentage 1.0; 288 GB of HBM hold every BASELINE feature table): rows stay in NODE
+  // order, slot = node id -- no id -> slot table and no table read per gathered row (ggms_extract_cached with
+  // table == NULL).  The reference ranks and shuffles even then; the layout is not observable through its interface.
+  const bool full_cache = num_cached_nodes_ == ds.num_node;
+  if (full_cache) {
+    for (size_t i = 0; i < ds.num_node; ++i) rank[i] = (uint32_t)i;
+    cache_table_ = nullptr;
+  } else {
+    std::vector<uint32_t> table(ds.num_node, GGMS_EMPTY_KEY);
+    for (size_t i = 0; i < num_cached_nodes_; ++i) table[rank[i]] = (uint32_t)i; // :197-229
+    cache_table_ = (uint32_t *)dev_upload(table.data(), ds.num_node * 4, stream_);
+  }
   // DistGraph::FeatureLoad / _PartitionFeature, dist_graph.cu:493-521: rows rank[i], i == p (mod P)
   const size_t my_rows = num_cached_nodes_ / P + (p < num_cached_nodes_ % P ? 1 : 0);
   std::vector<char> tmp(std::max<size_t>(my_rows * row_bytes, 16));

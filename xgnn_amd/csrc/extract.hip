@@ -33,14 +33,18 @@ template <> struct ChunkT<4> { using type = uint32_t; };
 template <> struct ChunkT<2> { using type = uint16_t; };
 template <> struct ChunkT<1> { using type = uint8_t; };
 
+// which tier served a row (0 = not counted); counters[tier - 1] in ggms_extract_tiered
+constexpr uint32_t kTierHost = 1, kTierRemote = 2, kTierLocal = 3, kTierReplica = 4;
+
 // ---- row locators -----------------------------------------------------------
 // src(i) = index ? index[i] : i ;  row pointer = base + src(i) * row_bytes
 struct PlainRows {
   const char *base;
   const uint32_t *index;
   uint64_t row_bytes;
-  __device__ __forceinline__ const char *row(uint64_t i, bool &miss) const {
-    miss = false;
+  static constexpr bool kTiers = false;
+  __device__ __forceinline__ const char *row(uint64_t i, uint32_t &tier) const {
+    tier = 0;
     const uint64_t s = index ? (uint64_t)index[i] : i;
     return base + s * row_bytes;
   }
@@ -52,8 +56,9 @@ struct PartitionRows {
   const uint32_t *index;
   uint64_t row_bytes;
   uint32_t num_part;
-  __device__ __forceinline__ const char *row(uint64_t i, bool &miss) const {
-    miss = false;
+  static constexpr bool kTiers = false;
+  __device__ __forceinline__ const char *row(uint64_t i, uint32_t &tier) const {
+    tier = 0;
     const uint32_t slot = index[i];
     const uint32_t part = slot % num_part, real = slot / num_part;
     return parts[part] + (uint64_t)real * row_bytes;
@@ -68,13 +73,67 @@ struct CachedRows {
   const char *host;
   uint64_t row_bytes;
   uint32_t num_part; // 0: one cache array parts[0]
-  __device__ __forceinline__ const char *row(uint64_t i, bool &miss) const {
+  static constexpr bool kTiers = false;
+  __device__ __forceinline__ const char *row(uint64_t i, uint32_t &tier) const {
     const uint32_t node = nodes[i];
     const uint32_t slot = table[node];
-    miss = (slot == kEmptyKey);
-    if (miss) return host + (uint64_t)node * row_bytes;
+    tier = (slot == kEmptyKey) ? kTierHost : 0u;
+    if (slot == kEmptyKey) return host + (uint64_t)node * row_bytes;
     if (num_part == 0) return parts[0] + (uint64_t)slot * row_bytes;
     const uint32_t part = slot % num_part, real = slot / num_part;
+    return parts[part] + (uint64_t)real * row_bytes;
+  }
+};
+
+// All tiers of the store in one locator (ggms_extract_tiered): slot = table ? table[node] : node;
+//   kEmptyKey            -> host tier, row `node` of the device-mapped host table      (GPUExtractMissData)
+//   slot <  num_replica  -> this GPU's replica of the hottest rows, row `slot`         (hot-row replication)
+//   else s = slot - num_replica -> shard s % P at row s / P: local HBM or a peer's over xGMI
+//                                                                      (combine_cache_data_for_partition)
+// and says which tier served the row, for the per-tier counters (count_local_cache, :171-207).
+struct TieredRows {
+  const char *const *parts;
+  const uint32_t *nodes;
+  const uint32_t *table;
+  const char *host;
+  const char *replica;
+  uint64_t row_bytes;
+  uint32_t num_replica;
+  uint32_t num_part; // >= 1
+  uint32_t my_part;
+  static constexpr bool kTiers = true;
+  __device__ __forceinline__ const char *row(uint64_t i, uint32_t &tier) const {
+    const uint32_t node = nodes[i];
+    const uint32_t slot = table ? table[node] : node;
+    if (slot == kEmptyKey) {
+      tier = kTierHost;
+      return host + (uint64_t)node * row_bytes;
+    }
+    if (slot < num_replica) {
+      tier = kTierReplica;
+      return replica + (uint64_t)slot * row_bytes;
+    }
+    const uint32_t s = slot - num_replica;
+    const uint32_t part = s % num_part, real = s / num_part;
+    tier = part == my_part ? kTierLocal : kTierRemote;
+    return parts[part] + (uint64_t)real * row_bytes;
+  }
+};
+
+// cache_ratio 1.0, rows kept in NODE order (slot = node id): no table, no miss tier.  The layout of a full cache is
+// not observable through the reference's interface (the batch's rows come out in input-node order either way), and
+// it removes one dependent random 4-byte read (a 64-byte sector of HBM traffic) per gathered row.
+struct IdentRows {
+  const char *const *parts;
+  const uint32_t *nodes;
+  uint64_t row_bytes;
+  uint32_t num_part; // 0: one array parts[0]
+  static constexpr bool kTiers = false;
+  __device__ __forceinline__ const char *row(uint64_t i, uint32_t &tier) const {
+    tier = 0;
+    const uint32_t node = nodes[i];
+    if (num_part == 0) return parts[0] + (uint64_t)node * row_bytes;
+    const uint32_t part = node % num_part, real = node / num_part;
     return parts[part] + (uint64_t)real * row_bytes;
   }
 };
@@ -116,9 +175,9 @@ __global__ __launch_bounds__(kBlock) void k_gather_rows(char *__restrict__ out, 
   const uint64_t num_tiles = (n + kWave - 1) / kWave;
 
   // resolve one row per lane for tile `t`: source pointer (+ destination pointer)
-  auto resolve = [&](uint64_t t, uint64_t &sp, uint64_t &dp, bool &miss) {
+  auto resolve = [&](uint64_t t, uint64_t &sp, uint64_t &dp, uint32_t &miss) {
     const uint64_t my_row = t * kWave + lane;
-    sp = 0; dp = 0; miss = false;
+    sp = 0; dp = 0; miss = 0;
     if (t < num_tiles && my_row < n) {
       sp = (uint64_t)rows.row(my_row, miss);
       if constexpr (!IDENT_DST) dp = (uint64_t)(out + (uint64_t)dst_index[my_row] * row_bytes);
@@ -126,18 +185,25 @@ __global__ __launch_bounds__(kBlock) void k_gather_rows(char *__restrict__ out, 
   };
 
   uint64_t sp, dp;
-  bool miss;
+  uint32_t miss; // tier of my row (kTierHost = a cache miss)
   resolve(wave, sp, dp, miss);
   for (uint64_t tile = wave; tile < num_tiles; tile += num_waves) {
     // software pipeline: the next tile's index -> table -> pointer chain is in flight while this
     // tile's rows stream
     uint64_t sp_n, dp_n;
-    bool miss_n;
+    uint32_t miss_n;
     resolve(tile + num_waves, sp_n, dp_n, miss_n);
 
-    if (miss_count) {
-      const uint64_t m = __ballot(miss);
+    if (miss_count) { // one atomic per wave, tile and tier that occurs
+      const uint64_t m = __ballot(miss == kTierHost);
       if (lane == 0 && m) atomicAdd((unsigned long long *)miss_count, (unsigned long long)__popcll(m));
+      if constexpr (Rows::kTiers) {
+#pragma unroll
+        for (uint32_t k = kTierRemote; k <= kTierReplica; ++k) {
+          const uint64_t mk = __ballot(miss == k);
+          if (lane == 0 && mk) atomicAdd((unsigned long long *)miss_count + (k - 1), (unsigned long long)__popcll(mk));
+        }
+      }
     }
     const uint64_t row0 = tile * kWave;
     const uint32_t rows_here = (n - row0 < (uint64_t)kWave) ? (uint32_t)(n - row0) : (uint32_t)kWave;
@@ -307,12 +373,36 @@ int ggms_extract_cached(void *out, const ggms_id_t *nodes, size_t num_nodes, con
   const size_t es = ggms_dtype_bytes(dtype);
   GGMS_CHECK_ARG(es != 0 && dim != 0);
   if (num_nodes == 0) return GGMS_OK;
-  GGMS_CHECK_ARG(out && nodes && table && parts_dev);
+  GGMS_CHECK_ARG(out && nodes && parts_dev);
   const size_t row_bytes = dim * es;
+  if (!table) { // full cache in node order: slot = node id
+    IdentRows rows{(const char *const *)parts_dev, nodes, row_bytes, num_part};
+    if (num_miss_dev) GGMS_HIP(hipMemsetAsync(num_miss_dev, 0, sizeof(uint64_t), to_stream(stream)));
+    return launch_gather((char *)out, rows, nullptr, num_nodes, count_of(num_nodes, num_nodes_dev), row_bytes,
+                         pick_chunk(row_bytes, (uintptr_t)out), nullptr, to_stream(stream));
+  }
   const int cb = pick_chunk(row_bytes, (uintptr_t)out | (uintptr_t)host_feat);
   CachedRows rows{(const char *const *)parts_dev, nodes, table, (const char *)host_feat, row_bytes, num_part};
   return launch_gather((char *)out, rows, nullptr, num_nodes, count_of(num_nodes, num_nodes_dev), row_bytes,
                        cb, num_miss_dev, to_stream(stream));
+}
+
+int ggms_extract_tiered(void *out, const ggms_id_t *nodes, size_t num_nodes, const uint64_t *num_nodes_dev,
+                        const ggms_feature_tiers_t *tiers, size_t dim, int dtype, uint64_t *tier_rows_dev,
+                        ggms_stream_t stream) {
+  const size_t es = ggms_dtype_bytes(dtype);
+  GGMS_CHECK_ARG(es != 0 && dim != 0 && tiers);
+  if (num_nodes == 0) return GGMS_OK;
+  GGMS_CHECK_ARG(out && nodes && tiers->parts_dev && tiers->num_part >= 1 && tiers->my_part < tiers->num_part);
+  GGMS_CHECK_ARG(tiers->num_replica == 0 || tiers->replica);
+  GGMS_CHECK_ARG(tiers->num_replica < (1ull << 32));
+  const size_t row_bytes = dim * es;
+  const int cb = pick_chunk(row_bytes, (uintptr_t)out | (uintptr_t)tiers->host_feat | (uintptr_t)tiers->replica);
+  TieredRows rows{(const char *const *)tiers->parts_dev, nodes, tiers->table, (const char *)tiers->host_feat,
+                  (const char *)tiers->replica, row_bytes, (uint32_t)tiers->num_replica, tiers->num_part,
+                  tiers->my_part};
+  return launch_gather((char *)out, rows, nullptr, num_nodes, count_of(num_nodes, num_nodes_dev), row_bytes, cb,
+                       tier_rows_dev, to_stream(stream));
 }
 
 } // extern "C"

@@ -51,6 +51,11 @@ class HipLeaf:
         self.ops.extract_cached(out, nodes, table, parts_table, num_part, host_feat, num=num, num_dev=num_dev,
                                 num_miss=num_miss)
 
+    def gather_tiered(self, out, nodes, num, table, replica, parts_table, num_part, my_part, host_feat, num_dev=None,
+                      counters=None):
+        self.ops.extract_tiered(out, nodes, table, replica, parts_table, num_part, my_part, host_feat, num=num,
+                                num_dev=num_dev, tier_rows=counters)
+
 
 def _all_to_all(dist, out, inp, out_splits, in_splits, group=None):
     """all_to_all_single on the tensors' own device with RCCL; through host memory with any other backend
@@ -66,12 +71,20 @@ def _all_to_all(dist, out, inp, out_splits, in_splits, group=None):
 class FeatureShards:
     """This rank's view of the partitioned feature cache."""
 
-    def __init__(self, shard, table, world, rank, mode="peer", dist=None, leaf=None, host_feat=None, group=None):
-        """shard: [ceil((num_cached - rank) / world), dim] rows of this rank (a SharedShard's tensor in peer mode);
-        table: int32[N] node -> slot or -1; host_feat: full table in (device-mapped) host memory for misses."""
+    def __init__(self, shard, table, world, rank, mode="peer", dist=None, leaf=None, host_feat=None, group=None,
+                 replica=None):
+        """shard: [ceil((num_sharded - rank) / world), dim] rows of this rank (a SharedShard's tensor in peer mode);
+        table: int32[N] node -> slot or -1 (None: slot = node id, everything cached); host_feat: full table in
+        (device-mapped) host memory for misses; replica (peer mode, "hybrid" store): this GPU's copy of the R hottest
+        slots -- slot s < R is read from it, slot s >= R from shard (s - R) % world at row (s - R) // world."""
         assert mode in ("peer", "a2a")
+        assert replica is None or mode == "peer", "hot-row replication rides on the peer gather"
         self.shard, self.table, self.world, self.rank, self.mode = shard, table, world, rank, mode
-        self.dist, self.group, self.host_feat = dist, group, host_feat
+        self.dist, self.group, self.host_feat, self.replica = dist, group, host_feat, replica
+        if mode == "peer" and host_feat is None and table is not None:
+            # an uncached node would be read from host row `node` of a NULL table: a GPU memory fault.  Refuse it here.
+            if bool((table == -1).any()):
+                raise ValueError("FeatureShards(peer): the cache table has uncached nodes but no host tier was given")
         self.leaf = leaf if leaf is not None else HipLeaf()
         self.parts_table = None
         self._shared = None
@@ -92,11 +105,16 @@ class FeatureShards:
         return self
 
     # ---- one batch ----------------------------------------------------------------------------------
-    def extract(self, nodes, num, out, num_dev=None, num_miss=None):
-        """out[i, :] = feature row of nodes[i], i < num; with num_dev (device int64[1]) num is an upper bound."""
+    def extract(self, nodes, num, out, num_dev=None, num_miss=None, counters=None):
+        """out[i, :] = feature row of nodes[i], i < num; with num_dev (device int64[1]) num is an upper bound.
+        counters (peer mode): int64[4] on the device, rows served by {host, remote shard, local shard, replica}."""
         if self.mode == "peer":
-            self.leaf.gather_peer(out, nodes, num, self.table, self.parts_table, self.world, self.host_feat,
-                                  **({"num_dev": num_dev, "num_miss": num_miss} if num_dev is not None else {}))
+            if counters is not None or self.replica is not None:
+                self.leaf.gather_tiered(out, nodes, num, self.table, self.replica, self.parts_table, self.world,
+                                        self.rank, self.host_feat, num_dev=num_dev, counters=counters)
+            else:
+                self.leaf.gather_peer(out, nodes, num, self.table, self.parts_table, self.world, self.host_feat,
+                                      **({"num_dev": num_dev, "num_miss": num_miss} if num_dev is not None else {}))
             return out
         return self._extract_a2a(nodes, num, out, num_dev)
 

@@ -323,13 +323,34 @@ def gather_scatter_partition(out, parts_table, num_part, src_index, dst_index, n
 
 
 def extract_cached(out, nodes, table, parts_table, num_part, host_feat, num=None, num_dev=None, num_miss=None):
-    """Fused GetMissCacheIndex + GPUExtractMissData + CombineCacheData (dist_loops.cc:1209-1285)."""
+    """Fused GetMissCacheIndex + GPUExtractMissData + CombineCacheData (dist_loops.cc:1209-1285).
+    table=None: full cache kept in node order (slot = node id), no table read per row."""
     _require_gpu(out)
     if num is None:
         num = nodes.numel()
     check(lib().ggms_extract_cached(_ptr(out), _ptr(nodes), num, _ptr(num_dev), _ptr(table), _ptr(parts_table),
                                     num_part, _ptr(host_feat), _dim_of(out), DTYPE_CODE[out.dtype], _ptr(num_miss),
                                     _stream()), "ggms_extract_cached")
+    return out
+
+
+def extract_tiered(out, nodes, table, replica, parts_table, num_part, my_part, host_feat, num=None, num_dev=None,
+                   tier_rows=None):
+    """Every tier of the GGMS store in one gather (include/ggms.h ggms_extract_tiered): replica of the hottest
+    slots, local / peer shards (slot - |replica| modulo num_part), pinned host rows for uncached nodes.
+    tier_rows: int64[4] device counters {host, remote shard, local shard, replica}, added to."""
+    _require_gpu(out)
+    if num is None:
+        num = nodes.numel()
+    t = _lib.FeatureTiers()
+    t.table = table.data_ptr() if table is not None else None
+    t.replica = replica.data_ptr() if replica is not None else None
+    t.num_replica = replica.shape[0] if replica is not None else 0
+    t.parts_dev = parts_table.data_ptr()
+    t.num_part, t.my_part = num_part, my_part
+    t.host_feat = host_feat.data_ptr() if host_feat is not None else None
+    check(lib().ggms_extract_tiered(_ptr(out), _ptr(nodes), num, _ptr(num_dev), C.byref(t), _dim_of(out),
+                                    DTYPE_CODE[out.dtype], _ptr(tier_rows), _stream()), "ggms_extract_tiered")
     return out
 
 
@@ -493,15 +514,17 @@ class BatchSampler:
             ex.rng_wait = self._events[(b - 1) % K] if b > 0 else None
             ex.rng_done = self._events[pipe]
         ws = self.wss[pipe]
+        # copy_input_nodes: the slot keeps the batch's unique list.  The table's n2o buffer is the caller's
+        # (ggms_hashtable_t is plain data), so the batch simply builds the list IN the slot's buffer -- no copy
+        self._n2o = self.input_nodes[slot] if copy_input_nodes else self.ht.n2o
+        self.ht.c.n2o = self._n2o.data_ptr()
+        self.ht.c.n2o_size = self._n2o.numel()
         check(lib().ggms_sample_batch(self.sample_type, C.byref(self.graph.c), _ptr(seeds), n, self._f, self.L,
                                       C.byref(self.ht.c), _ptr(self.states),
                                       self.states.shape[0] if self.states is not None else 0, self._rows[slot],
                                       self._cols[slot], _ptr(counts), C.byref(ex), _ptr(ws), ws.numel() * 4,
                                       _stream()),
               "ggms_sample_batch")
-        if copy_input_nodes:
-            gather_scatter(self.input_nodes[slot], self.ht.n2o, None, None, num=self.max_unique,
-                           num_dev=counts[3 * self.L:3 * self.L + 1])
 
     def result(self):
         """Sync and slice the outputs (host round trip: for tests and hand-off, not for the hot loop)."""
@@ -514,4 +537,4 @@ class BatchSampler:
             ne = c[3 * i]
             layers.append(dict(row=self.row[i][:ne], col=self.col[i][:ne], num_src=c[3 * i + 1], num_dst=c[3 * i + 2],
                                data=self.data[i][:ne] if self.data is not None else None))
-        return dict(layers=layers, input_nodes=self.ht.n2o[: c[3 * self.L]])
+        return dict(layers=layers, input_nodes=self._n2o[: c[3 * self.L]])
