@@ -52,6 +52,39 @@ def test_xorwow_state_pool(ops):
         assert [int(x) for x in one[1:]] == gold["first_states"][str(seed)]["v"]
 
 
+# ------------------------------------------------- device-side failures are reported, not swallowed
+def test_full_hashed_table_sets_the_status_word(ops):
+    """A hashed dedup table with fewer buckets than keys: the reference would probe forever (its CHECKs assume the
+    PredictNumNodes sizing); here the insert gives up after one full probe cycle and says so."""
+    assert ops.device_status(clear=True) == 0
+    ht = ops.OrderedHashTable(8)  # TableSize(8) = 32 buckets
+    ht.reset()
+    keys = dev(np.arange(1000, 1200, dtype=np.uint32))
+    ht.fill_with_duplicates(keys)
+    assert ops.device_status() & 2  # GGMS_STATUS_TABLE_FULL
+    with pytest.raises(RuntimeError):
+        ops.check_device_status("fill")
+    assert ops.device_status() == 0  # cleared by the check
+
+
+def test_stuck_scan_sets_the_status_word(ops, monkeypatch):
+    """Look-back that can never complete (ticket poisoned so that tile 0 is skipped): bounded spin, status bit 1,
+    no hang and no out-of-range write."""
+    assert ops.device_status(clear=True) == 0
+    N = 50_000
+    ht = ops.OrderedHashTable(N, num_node=N)
+    ht.reset()
+    keys = dev(np.random.RandomState(1).randint(0, N, 10_000).astype(np.uint32))
+    monkeypatch.setenv("GGMS_TEST_POISON_SCAN", "1")
+    ht.fill_with_duplicates(keys)
+    monkeypatch.delenv("GGMS_TEST_POISON_SCAN")
+    assert ops.device_status(clear=True) & 1  # GGMS_STATUS_SCAN_SPIN
+    ht.reset()
+    ht.fill_with_duplicates(keys)  # the same table and a clean scan area work again
+    assert ops.device_status() == 0
+    assert ht.num_items == np.unique(host_u32(keys)).size
+
+
 # -------------------------------------------------------------- extract
 @pytest.mark.parametrize("dtype,dim", [(np.float32, 100), (np.float32, 128), (np.float32, 256), (np.float32, 1),
                                        (np.float64, 5), (np.int16, 7), (np.uint8, 3), (np.uint8, 33),

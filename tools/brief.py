@@ -4,7 +4,6 @@ import sys
 
 d = json.loads(sys.stdin.read().strip().splitlines()[-1])
 r, p = d["roofline"], d["per_gpu"]
-alone = d.get("roofline_alone") or {}
 print(sys.argv[1] if len(sys.argv) > 1 else "", round(d["ms_per_step"], 4), "ms/step", "%.3e" % d["value"], "edges/s |",
-      "extract_us", round(r["avg_launch_us"], 1), "frac", round(r["frac"], 3), "alone", round(alone.get("frac", 0), 3),
+      "extract_us", round(r["avg_launch_us"], 1), "frac", round(r["frac"], 3), "alone", round(r.get("frac_alone") or 0, 3),
       "| sample_ms", round(p["sample_ms_per_step"], 3), flush=True)
