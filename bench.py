@@ -270,10 +270,10 @@ def main():
             "random_walk": ops.RANDOM_WALK}[args.sample_type]
     extra_kw = {}
     if args.sample_type.startswith("weighted_khop"):  # per-edge acceptance probability + alias neighbour (engine.cc:372-384)
-        gen = torch.Generator(device=dev).manual_seed(7)
-        E = indices.numel()
-        extra_kw = dict(prob_table=torch.rand(E, generator=gen, device=dev, dtype=torch.float32),
-                        alias_table=torch.randint(0, N, (E,), generator=gen, device=dev, dtype=torch.int32))
+        # valid alias tables from seeded per-edge weights, as the reference's weight tool builds them
+        prob, alias = datagen.build_alias_tables(graph["indptr"], graph["indices"], datagen.edge_weights(graph, "default", 7),
+                                                 num_threads=usable_cores())
+        extra_kw = dict(prob_table=torch.from_numpy(prob).to(dev), alias_table=to_dev(alias))
     if args.sample_type == "random_walk":  # common_config.py PinSAGE defaults
         extra_kw = dict(random_walk_length=3, random_walk_restart_prob=0.5, num_random_walk=4)
     # batches in flight: K sampling pipelines (own stream, dedup table, workspace; RNG pool consumed in batch

@@ -430,6 +430,24 @@ int ggms_owner_bucket(const ggms_id_t *slots, const ggms_id_t *nodes,
                       ggms_id_t *bucket_row, ggms_id_t *bucket_pos,
                       ggms_stream_t stream);
 
+/* ---------------------------------------------------------------------------
+ * Dataset tools (HOST arrays, no device work): the per-edge tables of the weighted samplers.
+ *   ggms_build_alias_table_host        utility/data-process/toolkit/weight/create_alias_table.cc:105-170:
+ *       per neighbour list Vose's alias method in float arithmetic; prob_table[e] = acceptance probability of
+ *       slot e, alias_table[e] = GLOBAL node id of the donor neighbour (0 where the slot accepts with
+ *       probability 1).  -> prob_table.bin / alias_table.bin
+ *   ggms_build_prob_prefix_table_host  create_prob_prefix_table.cc:94-123: running float sum of the weights per
+ *       list.  -> prob_prefix_table.bin
+ * `weights` is one float per edge (the reference draws them inside the tool; here they are an input).
+ * ------------------------------------------------------------------------- */
+int ggms_build_alias_table_host(const ggms_id_t *indptr, const ggms_id_t *indices,
+                                size_t num_node, const float *weights,
+                                float *prob_table, ggms_id_t *alias_table,
+                                int num_threads);
+int ggms_build_prob_prefix_table_host(const ggms_id_t *indptr, size_t num_node,
+                                      const float *weights,
+                                      float *prob_prefix_table, int num_threads);
+
 #ifdef __cplusplus
 }
 #endif

@@ -327,6 +327,22 @@ class HashTable:
         return ns[: src.size], nd[: src.size]
 
 
+def create_alias_table(indptr, indices, weights):
+    """create_alias_table.cc:105-170 -> (prob_table f32[E], alias_table u32[E])."""
+    ip, ix, w = _u32(indptr), _u32(indices), np.ascontiguousarray(weights, np.float32)
+    prob, alias = np.empty(ix.size, np.float32), np.empty(ix.size, np.uint32)
+    lib().orc_create_alias_table(_p(ip), _p(ix), _sz(ip.size - 1), _p(w), _p(prob), _p(alias))
+    return prob, alias
+
+
+def create_prob_prefix_table(indptr, weights):
+    """create_prob_prefix_table.cc:94-123."""
+    ip, w = _u32(indptr), np.ascontiguousarray(weights, np.float32)
+    out = np.empty(w.size, np.float32)
+    lib().orc_create_prob_prefix_table(_p(ip), _sz(ip.size - 1), _p(w), _p(out))
+    return out
+
+
 class CpuHashTable2:
     """CPUHashTable2 with its OpenMP loops (cpu/cpu_hashtable2.cc:35-191); threads=1 == HashTable."""
 

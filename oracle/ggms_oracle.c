@@ -957,6 +957,58 @@ void orc_ht_map_edges(const orc_hashtable_t *ht, const orc_id_t *src,
 }
 
 /* ----------------------------------------------------------------------- */
+/* Weight tables of the weighted samplers (dataset tools).
+ * utility/data-process/toolkit/weight/create_alias_table.cc:105-170: per list -- float weights normalised to
+ * mean 1 (:131-135), two FIFO work lists (std::queue, :138-147), a small slot takes its own neighbour with
+ * probability w and the front large one's NODE ID otherwise, the large one gives up 1 - w (:149-166), leftovers
+ * accept with probability 1 (:168-180; their alias slot keeps the vector's initial 0, :212).
+ * create_prob_prefix_table.cc:94-123: running float sum per list. */
+void orc_create_alias_table(const orc_id_t *indptr, const orc_id_t *indices, size_t num_node, const float *weights,
+                            float *prob_table, orc_id_t *alias_table) {
+  for (size_t v = 0; v < num_node; ++v) {
+    const uint32_t off = indptr[v], len = indptr[v + 1] - off;
+    float *w = (float *)malloc(sizeof(float) * (len + 1));
+    uint32_t *qs = (uint32_t *)malloc(sizeof(uint32_t) * (2 * (size_t)len + 2)); /* every index enters a queue <= 2 times */
+    uint32_t *ql = (uint32_t *)malloc(sizeof(uint32_t) * (2 * (size_t)len + 2));
+    size_t sh = 0, st = 0, lh = 0, lt = 0;
+    volatile float sum = 0.0f; /* volatile: no reassociation, the tool sums in index order */
+    for (uint32_t i = 0; i < len; ++i) sum = sum + weights[off + i];
+    for (uint32_t i = 0; i < len; ++i) {
+      volatile float x = weights[off + i] / sum;
+      x = x * (float)len;
+      w[i] = x;
+      alias_table[off + i] = 0;
+    }
+    for (uint32_t i = 0; i < len; ++i) {
+      if (w[i] < 1.0f) qs[st++] = i; else ql[lt++] = i;
+    }
+    while (sh < st && lh < lt) {
+      const uint32_t s = qs[sh++], l = ql[lh++];
+      prob_table[off + s] = w[s];
+      alias_table[off + s] = indices[off + l];
+      volatile float give = 1.0f - w[s];
+      volatile float rest = w[l] - give;
+      w[l] = rest;
+      if (w[l] < 1.0f) qs[st++] = l; else ql[lt++] = l;
+    }
+    while (lh < lt) prob_table[off + ql[lh++]] = 1.0f;
+    while (sh < st) prob_table[off + qs[sh++]] = 1.0f;
+    free(w); free(qs); free(ql);
+  }
+}
+
+void orc_create_prob_prefix_table(const orc_id_t *indptr, size_t num_node, const float *weights, float *prefix) {
+  for (size_t v = 0; v < num_node; ++v) {
+    const uint32_t off = indptr[v], len = indptr[v + 1] - off;
+    volatile float sum = 0.0f;
+    for (uint32_t i = 0; i < len; ++i) {
+      sum = sum + weights[off + i];
+      prefix[off + i] = sum;
+    }
+  }
+}
+
+/* ----------------------------------------------------------------------- */
 /* CPUHashTable2 with its OpenMP structure (cpu/cpu_hashtable2.cc:35-191): a direct-indexed bucket per node
  * id {key, local, index, version}; Populate = CAS claim, per-thread count, serial prefix over threads, per-thread
  * id assignment (static schedule, so a thread's items are a contiguous index range and ids stay ordered by

@@ -163,6 +163,11 @@ void orc_random_walk_raw(const orc_id_t *indptr, const orc_id_t *indices,
 
 /* ---- ordered hash table (cuda_hashtable.cu / cpu_hashtable2.cc) --------- */
 typedef struct orc_hashtable orc_hashtable_t;
+/* dataset tools: create_alias_table.cc:105-170, create_prob_prefix_table.cc:94-123 */
+void orc_create_alias_table(const orc_id_t *indptr, const orc_id_t *indices, size_t num_node, const float *weights,
+                            float *prob_table, orc_id_t *alias_table);
+void orc_create_prob_prefix_table(const orc_id_t *indptr, size_t num_node, const float *weights, float *prefix);
+
 /* CPUHashTable2 with its OpenMP loops (cpu/cpu_hashtable2.cc:35-191); one thread == orc_ht_* above */
 typedef struct orc_cpu_ht2 orc_cpu_ht2_t;
 orc_cpu_ht2_t *orc_cpu_ht2_create(size_t num_node, int threads);

@@ -136,14 +136,17 @@ def test_arch1_end_to_end(tmp_path, pipelined, sample_type, table):
 def test_arch1_weighted_and_random_walk(tmp_path):
     """PinSAGE (random walk, train_pinsage.py defaults) and weighted sampling through the engine."""
     d = make_dataset(tmp_path / "ds")
-    rng = np.random.RandomState(3)
-    prob = rng.random_sample(d["ix"].size).astype(np.float32)
-    alias = rng.randint(0, d["ip"].size - 1, d["ix"].size).astype(np.uint32)
-    from graphgen import prefix_sums
-    pre = prefix_sums(d["ip"], (rng.random_sample(d["ix"].size) + 0.01).astype(np.float32))
-    prob.tofile(os.path.join(d["path"], "prob_table.bin"))
-    alias.tofile(os.path.join(d["path"], "alias_table.bin"))
-    pre.tofile(os.path.join(d["path"], "prob_prefix_table.bin"))
+    from xgnn_amd import datagen
+    # VALID tables, built from per-edge weights the way the reference's weight tools build them
+    # (create_alias_table.cc:105-170, create_prob_prefix_table.cc:94-123) and written by write_dataset
+    g = dict(indptr=d["ip"], indices=d["ix"], train_set=d["train"], meta=dict(feat_dim=d["feat"].shape[1], num_class=13))
+    weights = datagen.edge_weights(g, "default", seed=3)
+    datagen.write_dataset(d["path"], g, feat=d["feat"], label=d["label"], weights=weights)
+    prob = np.fromfile(os.path.join(d["path"], "prob_table.bin"), np.float32)
+    alias = np.fromfile(os.path.join(d["path"], "alias_table.bin"), np.uint32)
+    pre = np.fromfile(os.path.join(d["path"], "prob_prefix_table.bin"), np.float32)
+    po, ao = oracle.create_alias_table(d["ip"], d["ix"], weights)
+    assert prob.tobytes() == po.tobytes() and np.array_equal(alias, ao)
     for stype, fan, kw in [("weighted_khop", [5, 4], dict(prob=prob, alias=alias)),
                            ("weighted_khop_prefix", [5, 4], dict(prob=pre)),
                            ("weighted_khop_hash_dedup", [5, 4], dict(prob=prob, alias=alias)),

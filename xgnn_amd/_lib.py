@@ -91,6 +91,8 @@ SYMBOLS = {
     "ggms_gather_scatter": (_i, [_vp, _vp, _vp, _vp, _sz, _vp, _sz, _i, _vp]),
     "ggms_gather_scatter_partition": (_i, [_vp, _vp, _u32, _vp, _vp, _sz, _vp, _sz, _i, _vp]),
     "ggms_extract_cached": (_i, [_vp, _vp, _sz, _vp, _vp, _vp, _u32, _vp, _sz, _i, _vp, _vp]),
+    "ggms_build_alias_table_host": (_i, [_vp, _vp, _sz, _vp, _vp, _vp, _i]),
+    "ggms_build_prob_prefix_table_host": (_i, [_vp, _sz, _vp, _vp, _i]),
     "ggms_extract_tiered": (_i, [_vp, _vp, _sz, _vp, C.POINTER(FeatureTiers), _sz, _i, _vp, _vp]),
 }
 

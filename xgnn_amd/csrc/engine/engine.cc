@@ -288,11 +288,14 @@ void Engine::Reshuffle() {
     std::uniform_int_distribution<size_t> d(i, num_data_ - 1);
     std::swap(data[i], data[d(g)]);
   }
+  // the previous epoch's batches may still be copying their seeds out of shuf_dev_ on the pipeline streams
+  for (auto &P : pipes_)
+    if (P.stream) SAM_HIP(hipStreamSynchronize(P.stream));
   SAM_HIP(hipMemcpyAsync(shuf_dev_, data + global_data_offset_, num_local_data_ * 4, hipMemcpyHostToDevice, stream_));
   SAM_HIP(hipStreamSynchronize(stream_));
 }
 
-bool Engine::ShufflerNext(Batch *b) {
+bool Engine::ShufflerNext(Batch *b, hipStream_t copy_stream) {
   cur_step_++;
   if (cur_step_ >= num_local_step_) Reshuffle();
   if (cur_epoch_ >= cfg.num_epoch) return false;
@@ -305,7 +308,7 @@ bool Engine::ShufflerNext(Batch *b) {
   }
   b->num_seeds = size;
   b->key = BatchKey(cur_epoch_, global_step_offset_ + cur_step_);
-  SAM_HIP(hipMemcpyAsync(b->output_nodes, shuf_dev_ + offset, size * 4, hipMemcpyDeviceToDevice, stream_)); // Copy1D
+  SAM_HIP(hipMemcpyAsync(b->output_nodes, shuf_dev_ + offset, size * 4, hipMemcpyDeviceToDevice, copy_stream)); // Copy1D
   return true;
 }
 
@@ -641,7 +644,7 @@ void Engine::Shutdown() {
 }
 
 // ------------------------------------------------------------------ hot loop
-Batch *Engine::AcquireSlot() {
+Batch *Engine::AcquireSlot(bool background) {
   for (;;) {
     {
       std::lock_guard<std::mutex> lk(pool_mu_);
@@ -651,7 +654,7 @@ Batch *Engine::AcquireSlot() {
     if (bg_stop_) return nullptr;
     // GraphPool full (cuda_loops_arch1.cc:45-48): the foreground call returns without sampling,
     // the background thread backs off and retries
-    if (!bg_.joinable()) return nullptr;
+    if (!background) return nullptr;
     std::this_thread::sleep_for(std::chrono::microseconds(20));
   }
 }
@@ -659,38 +662,38 @@ Batch *Engine::AcquireSlot() {
 // samgraph_sample_once: the batches come out in shuffler order whoever asks, so the foreground call keeps
 // `lookahead` more of them enqueued than it was asked for -- batch k+1 samples while batch k's rows are gathered and
 // while the caller trains on batch k.  The pool hands them out in the same order (GetNextBatch).
-void Engine::RunSampleOnce() {
-  if (bg_.joinable() && std::this_thread::get_id() == bg_.get_id()) { // background loop: one per iteration
-    (void)EnqueueOne();
+void Engine::RunSampleOnce(bool background) {
+  // the role is an argument, never inferred from the std::thread member (the new thread would read it while
+  // ExtractStart is still assigning it)
+  if (background) { // background loop: one per iteration
+    (void)EnqueueOne(true);
     return;
   }
   ++fg_calls_;
-  while (fg_enqueued_ < fg_calls_ + cfg.lookahead && EnqueueOne()) ++fg_enqueued_;
+  while (fg_enqueued_ < fg_calls_ + cfg.lookahead && EnqueueOne(false)) ++fg_enqueued_;
   // a call that found the pool full (cuda_loops_arch1.cc:45-48) stays owed: a later call catches up
 }
 
 // RunArch1LoopsOnce (cuda/cuda_loops_arch1.cc:43-86) / RunArch6LoopsOnce (dist/dist_loops_arch6.cc:236-243):
 // shuffle -> sample -> extract, all enqueued with no host round trip.  false: no free slot, or training finished.
-bool Engine::EnqueueOne() {
+bool Engine::EnqueueOne(bool background) {
   SAM_CHECK(train_ready_, "engine not initialised");
   SAM_HIP(hipSetDevice(device_));
-  Batch *b = AcquireSlot();
+  Batch *b = AcquireSlot(background);
   if (!b) return false;
-  if (!ShufflerNext(b)) { // training finished
+  // Consecutive batches go to the sampling pipelines round-robin; a batch's seeds are copied on ITS pipeline's
+  // stream (not behind another pipeline's queued sampling).
+  Pipe &P = pipes_[enq_count_ % pipes_.size()];
+  hipStream_t ss = P.stream;
+  if (!ShufflerNext(b, ss)) { // training finished
     std::lock_guard<std::mutex> lk(pool_mu_);
     b->in_use = false;
     return false;
   }
   const uint32_t L = (uint32_t)cfg.fanout.size();
-  // Consecutive batches go to the sampling pipelines round-robin.  The seeds were copied on stream_ (the one
-  // stream that touches the shuffled train set); the RNG pool -- and khop2's CSR -- is handed from batch to
-  // batch through rng_wait / rng_done, so the results are those of the one-batch-at-a-time loop.
-  Pipe &P = pipes_[enq_count_++ % pipes_.size()];
-  hipStream_t ss = P.stream;
-  if (ss != stream_) {
-    SAM_HIP(hipEventRecord(b->ev_seeds, stream_));
-    SAM_HIP(hipStreamWaitEvent(ss, b->ev_seeds, 0));
-  }
+  // The RNG pool -- and khop2's CSR -- is handed from batch to batch through rng_wait / rng_done, so the results
+  // are those of the one-batch-at-a-time loop.
+  ++enq_count_;
   SAM_HIP(hipEventRecord(b->ev_start, ss));
   ggms_sample_extra_t extra = extra_;
   extra.data = b->data.data();
@@ -779,7 +782,7 @@ uint64_t Engine::GetNextBatch() { // operation.cc:366-378 + GraphPool::GetGraphB
   Batch *b = nullptr;
   {
     std::unique_lock<std::mutex> lk(pool_mu_);
-    if (pool_.empty() && !bg_.joinable())
+    if (pool_.empty() && !bg_running_.load())
       fatal(__FILE__, __LINE__, "get_next_batch with nothing sampled: call sample_once() or extract_start() first");
     pool_cv_.wait(lk, [&] { return !pool_.empty() || bg_stop_.load(); });
     if (pool_.empty()) fatal(__FILE__, __LINE__, "engine shut down while waiting for a batch");
@@ -793,12 +796,13 @@ uint64_t Engine::GetNextBatch() { // operation.cc:366-378 + GraphPool::GetGraphB
 
 void Engine::ExtractStart(int count) { // dist_engine.cc StartExtract: one background sample+extract thread
   (void)count;
-  SAM_CHECK(!bg_.joinable(), "extract thread already running");
+  SAM_CHECK(!bg_running_.load(), "extract thread already running");
+  bg_running_ = true; // set before the thread exists: nothing the thread runs looks at bg_ itself
   bg_ = std::thread([this] {
     SAM_HIP(hipSetDevice(device_));
     while (!bg_stop_) {
       const size_t before_epoch = cur_epoch_;
-      RunSampleOnce();
+      RunSampleOnce(true);
       if (cur_epoch_ >= cfg.num_epoch && before_epoch >= cfg.num_epoch) break;
       if (cur_epoch_ >= cfg.num_epoch) break;
     }
@@ -813,6 +817,8 @@ Batch *Engine::Current(uint64_t key) {
 
 void Engine::Retain(uint64_t key) { Current(key)->refs.fetch_add(1); }
 
+// batch keys are unique over a run (epoch * steps + step), and a slot is only reused once its refs are back to 0,
+// so a key names at most one live slot
 void Engine::Release(uint64_t key) {
   for (auto &b : slots_)
     if (b->key == key && b->refs.load() > 0) { b->refs.fetch_sub(1); return; }

@@ -70,7 +70,9 @@ struct RunConfig {
   uint64_t seed = 0;
   bool direct_table = true;
   size_t lookahead = 2; // batches sample_once() keeps enqueued beyond the one it was asked for (config key `lookahead`)
-  size_t pipelines = 2; // batches the sampler itself has in flight: own stream + dedup table + workspace each (`pipelines`)
+  size_t pipelines = 1; // batches the sampler itself has in flight: own stream + dedup table + workspace each (`pipelines`);
+                        // measured on papers100M-shaped GCN: a second pipeline loses 2-3 % (the step is bound by the memory
+                        // fabric, not by sampler latency) and costs a second 8 B x num_node table
   size_t presample_epoch = 0;
   bool UsePresample() const { return UseGPUCache() && (cache_policy == 2 /*kCacheByPreSample*/); }
   bool UseGPUCache() const { return cache_percentage > 0 && arch != kArch1; } // run_config.h:124-126
@@ -151,8 +153,8 @@ class Engine {
   void Init();                                        // arch1: all three
   void Start();
   void Shutdown();
-  void RunSampleOnce();
-  bool EnqueueOne();
+  void RunSampleOnce(bool background = false);
+  bool EnqueueOne(bool background);
   uint64_t GetNextBatch();
   void ExtractStart(int count);
   Batch *Current(uint64_t key);
@@ -172,13 +174,13 @@ class Engine {
   HostArray MapFile(const std::string &name, size_t bytes, bool to_shared_anon);
   // shuffler (cuda/cuda_shuffler.cc, dist/dist_shuffler_aligned.cc)
   void ShufflerInit();
-  bool ShufflerNext(Batch *b); // false at end of training
+  bool ShufflerNext(Batch *b, hipStream_t copy_stream); // false at end of training
   void Reshuffle();
   // GGMS
   void UploadGraph();
   void Presample();
   void BuildCache();
-  Batch *AcquireSlot();
+  Batch *AcquireSlot(bool background);
   void Finish(Batch *b);
 
   bool data_ready_ = false, sample_ready_ = false, train_ready_ = false, shutdown_ = false;
@@ -235,6 +237,7 @@ class Engine {
   std::thread bg_;
   size_t fg_calls_ = 0, fg_enqueued_ = 0; // foreground sample_once() calls / batches enqueued for them
   std::atomic<bool> bg_stop_{false};
+  std::atomic<bool> bg_running_{false};
   // shared (arch6): control block inherited through fork
   struct Shared;
   Shared *shared_ = nullptr;

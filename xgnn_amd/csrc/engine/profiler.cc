@@ -4,6 +4,7 @@
 // item codes are the reference's enum values (profiler.h:30-163).
 #include <chrono>
 #include <cstdio>
+#include <cstdlib>
 
 #include "engine.h"
 
@@ -50,7 +51,9 @@ void Profiler::Trace(uint64_t key, int item, uint64_t ts, bool begin) {
   }
 }
 
-void Profiler::DumpTrace() { // Chrome trace events, profiler.cc:349-380
+void Profiler::DumpTrace() { // Chrome trace events to stderr, as samgraph_dump_trace does (operation.cc:502-505,
+  // profiler.cc:349-380); only when SAMGRAPH_DUMP_TRACE is set (run_config.cc:130-132)
+  if (!getenv("SAMGRAPH_DUMP_TRACE")) return;
   std::lock_guard<std::mutex> lk(mu_);
   std::fprintf(stderr, "[");
   bool first = true;

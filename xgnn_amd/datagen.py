@@ -63,10 +63,56 @@ def degree_rank(indptr):
     return np.argsort(-deg, kind="stable").astype(np.uint32)
 
 
-def write_dataset(path, graph, feat=None, label=None, valid_frac=0.02, test_frac=0.05, feat_dtype="F32"):
+def edge_weights(graph, policy="default", seed=0):
+    """Per-edge weights in the spirit of the reference's weight tool (create_alias_table.cc:36-60,75-92), seeded:
+    'default' = integers 1..10, 'inverse_src_degree' = 1 / out-degree of the neighbour, 'src_suffix' = 100 for
+    neighbours with out-degree < 10 else 1."""
+    ip, ix = graph["indptr"], graph["indices"]
+    if policy == "default":
+        return np.random.RandomState(seed).randint(1, 11, size=ix.size).astype(np.float32)
+    out_deg = np.bincount(ix, minlength=ip.size - 1).astype(np.int64)
+    if policy == "inverse_src_degree":
+        return (1.0 / out_deg[ix]).astype(np.float32)
+    if policy == "src_suffix":
+        return np.where(out_deg[ix] < 10, 100.0, 1.0).astype(np.float32)
+    raise ValueError(policy)
+
+
+def build_alias_tables(indptr, indices, weights, num_threads=8):
+    """prob_table / alias_table of the alias-method samplers from per-edge weights (create_alias_table.cc:105-170);
+    the alias slot holds the GLOBAL node id of the donor neighbour.  Host-only entry point of the library."""
+    import ctypes as C
+    from ._lib import check, lib
+    ip = np.ascontiguousarray(indptr, np.uint32)
+    ix = np.ascontiguousarray(indices, np.uint32)
+    w = np.ascontiguousarray(weights, np.float32)
+    assert w.size == ix.size
+    prob, alias = np.empty(ix.size, np.float32), np.empty(ix.size, np.uint32)
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+    check(lib().ggms_build_alias_table_host(vp(ip), vp(ix), ip.size - 1, vp(w), vp(prob), vp(alias), num_threads),
+          "ggms_build_alias_table_host")
+    return prob, alias
+
+
+def build_prob_prefix_table(indptr, weights, num_threads=8):
+    """prob_prefix_table of the inverse-CDF sampler: running float sum per neighbour list
+    (create_prob_prefix_table.cc:94-123)."""
+    import ctypes as C
+    from ._lib import check, lib
+    ip = np.ascontiguousarray(indptr, np.uint32)
+    w = np.ascontiguousarray(weights, np.float32)
+    out = np.empty(w.size, np.float32)
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+    check(lib().ggms_build_prob_prefix_table_host(vp(ip), ip.size - 1, vp(w), vp(out), num_threads),
+          "ggms_build_prob_prefix_table_host")
+    return out
+
+
+def write_dataset(path, graph, feat=None, label=None, valid_frac=0.02, test_frac=0.05, feat_dtype="F32", weights=None):
     """Write a dataset directory in the reference's on-disk format (datagen/README.md:37-51,
     samgraph/common/constant.cc:23-51, engine.cc:109-443): meta.txt (tab separated) + raw little-endian
-    arrays: indptr/indices/train_set/test_set/valid_set/cache_by_* uint32, feat row-major, label int64."""
+    arrays: indptr/indices/train_set/test_set/valid_set/cache_by_* uint32, feat row-major, label int64;
+    weights (one float per edge) adds prob_table.bin / alias_table.bin / prob_prefix_table.bin."""
     import os
     os.makedirs(path, exist_ok=True)
     ip, ix, train, meta = graph["indptr"], graph["indices"], graph["train_set"], graph["meta"]
@@ -85,6 +131,11 @@ def write_dataset(path, graph, feat=None, label=None, valid_frac=0.02, test_frac
         np.ascontiguousarray(feat).tofile(os.path.join(path, "feat.bin"))
     if label is not None:
         np.ascontiguousarray(label, dtype=np.int64).tofile(os.path.join(path, "label.bin"))
+    if weights is not None:  # tables of the weighted samplers (engine.cc:372-384 loads them by these names)
+        prob, alias = build_alias_tables(ip, ix, weights)
+        prob.tofile(os.path.join(path, "prob_table.bin"))
+        alias.tofile(os.path.join(path, "alias_table.bin"))
+        build_prob_prefix_table(ip, weights).tofile(os.path.join(path, "prob_prefix_table.bin"))
     degree_rank(ip).tofile(os.path.join(path, "cache_by_degree.bin"))
     np.random.RandomState(11).permutation(n).astype(np.uint32).tofile(os.path.join(path, "cache_by_random.bin"))
     with open(os.path.join(path, "meta.txt"), "w") as f:
