@@ -266,6 +266,9 @@ int ggms_map_edges(const ggms_hashtable_t *ht, const ggms_id_t *global_src,
  * (TrainGraph, dist_loops.cc:303-322).  row/col are HOST arrays of L device
  * pointers with the capacities ggms_sample_batch_capacity reports; fanouts is
  * a host array indexed by layer id.
+ * The table is CONSUMED by the batch: with the direct layout its words hold the
+ * index of each key's first occurrence, not local ids (the ids are in row / n2o),
+ * so ggms_map_edges on it is meaningless until the next fill after a reset.
  * ------------------------------------------------------------------------- */
 /* per-sample-type extras of ggms_sample_batch (NULL for khop0/khop3) */
 typedef struct {

@@ -1,13 +1,13 @@
 """Turn the raw rocprofv3 output of tools/collect_profiles.sh into the summaries kept under profiles/.
 
-    python tools/summarize_profiles.py gpurun_out/profiles_<tag> profiles/<round>   [steps+warmup, default 23]
+    python tools/summarize_profiles.py gpurun_out/profiles_<tag> profiles/<round>   [steps of the main region, default 63]
 
 writes
     <round>_kernel_stats.csv        rocprofv3's own --stats table, ggms kernels + copies only
     <round>_kernel_timeline.csv     per kernel: launches per step, avg/min/max us, and per HSA queue the
                                     busy / idle time between the first and the last ggms launch
     <round>_pmc_hbm_traffic.csv     FETCH_SIZE / WRITE_SIZE per kernel (raw KB, separate passes)
-    <round>_extract_traffic.json    the gather kernel's HBM bytes per launch, corrected as
+    <round>_extract_traffic_<preset>.json   the gather kernel's HBM bytes per launch, corrected as
                                     /opt/skills/guides/MI355X_MICROARCH.md (HBM section) prescribes;
                                     bench.py reads it for roofline.traffic
 """
@@ -28,7 +28,7 @@ def one(pattern):
 
 def main():
     src, dst = sys.argv[1], sys.argv[2]
-    launches = int(sys.argv[3]) if len(sys.argv) > 3 else 23
+    launches = int(sys.argv[3]) if len(sys.argv) > 3 else 63  # steps of the main region (warm-up 3 + 3 blocks x 20)
     os.makedirs(os.path.dirname(dst) or ".", exist_ok=True)
 
     # ---- rocprofv3 --stats table, filtered
@@ -80,13 +80,15 @@ def main():
         for (k, c), v in sorted(pmc.items(), key=lambda kv: -sum(kv[1])):
             w.writerow([k, c, len(v), sum(v) / len(v), max(v)])
 
-    # ---- the gather kernel of the bench (CachedRows): bytes per launch
+    # ---- the gather kernel of the main timed region (IdentRows: full cache in node order): bytes per launch
     bench = json.loads(open(f"{src}/bench_trace.json").read().strip().splitlines()[-1])
+    preset = bench["config"]["workload"].split("-shaped")[0]
     rows_per_launch = bench["per_gpu"]["rows_per_step"]
     row_bytes = bench["roofline"]["algorithmic_bytes_per_row"]
-    gk = [k for (k, c) in pmc if "k_gather_rows" in k and "CachedRows" in k and c == "FETCH_SIZE"]
+    is_main = lambda k: "k_gather_rows" in k and ("IdentRows" in k or "CachedRows" in k)  # noqa: E731
+    gk = [k for (k, c) in pmc if is_main(k) and c == "FETCH_SIZE"]
     out = {"kernel": gk[0] if gk else None,
-           "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE -- python bench.py --steps 20 --warmup 3 --no-cpu-baseline",
+           "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE -- python bench.py [--no-cpu-baseline]  (separate passes)",
            "rows_per_launch": rows_per_launch}
     if gk:
         fetch = pmc[(gk[0], "FETCH_SIZE")]
@@ -97,26 +99,21 @@ def main():
                                    "64 B for 16-B/lane loads)")
         out["hbm_bytes_per_launch"] = (2 * out["FETCH_SIZE_KB_raw"] + out["WRITE_SIZE_KB"]) * 1024
         out["algorithmic_bytes_per_launch"] = rows_per_launch * row_bytes
-    # every other ggms kernel of a step (the sampler): raw counter bytes per step.  Their accesses are random 4/8-B
-    # words, for which the guide gives no FETCH_SIZE calibration, so this is a lower bound
-    other = 0.0
-    for (k, c), v in pmc.items():
-        if gk and k == gk[0]:
-            continue
-        other += sum(v) * 1024 / launches
-    out["sampler_hbm_bytes_per_step_raw"] = other
-    # the same kernel's durations in the kernel trace: the bench launches it `launches` times inside the pipeline
-    # (warm-up + timed steps) and then 10 times with nothing beside it (roofline_alone)
+        out["traffic_over_algorithmic"] = out["hbm_bytes_per_launch"] / out["algorithmic_bytes_per_launch"]
+    # the same kernel's durations in the kernel trace: warm-up + repeats x steps launches inside the pipeline, then
+    # 10 launches with nothing beside it (roofline.frac_alone)
     g = [(int(r["Start_Timestamp"]), (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3) for r in tr
-         if "k_gather_rows" in r["Kernel_Name"] and "CachedRows" in r["Kernel_Name"]]
+         if is_main(r["Kernel_Name"])]
     g.sort()
     durs = [d for _, d in g]
-    if len(durs) > launches:
-        timed = durs[launches - bench["steps"]:launches]
+    in_pipe = bench["warmup"] + bench["steps"] * bench["repeats"]["blocks"]
+    if len(durs) >= in_pipe + 10:
+        timed = durs[bench["warmup"]:in_pipe]
         out["rocprof_avg_us_timed_steps"] = sum(timed) / len(timed)
-        out["rocprof_avg_us_alone"] = sum(durs[launches:]) / len(durs[launches:])
+        out["rocprof_avg_us_alone"] = sum(durs[in_pipe:in_pipe + 10]) / 10
         out["bench_avg_launch_us_same_run"] = bench["roofline"]["avg_launch_us"]
-    with open(f"{dst}_extract_traffic.json", "w") as f:
+        out["bench_avg_launch_us_alone_same_run"] = bench["roofline"]["avg_launch_us_alone"]
+    with open(f"{dst}_extract_traffic_{preset}.json", "w") as f:
         json.dump(out, f, indent=1)
     print(json.dumps(out, indent=1))
     print(open(f"{dst}_kernel_timeline.csv").read())

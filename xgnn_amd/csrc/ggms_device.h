@@ -163,25 +163,54 @@ __host__ __device__ __forceinline__ unsigned long long make_w1(uint32_t version,
   return (hi << 32) | value;
 }
 
-// Who owns a key without re-reading the table: instance e enters {pending, e} with ONE returning atomicMin.
+// Who owns a key without re-reading the table: instance e enters {pending, base + e} with ONE returning atomicMin.
 //   old < mine : an earlier instance or an assigned id is there  -> e cannot own the key   (cand[e] = 0)
 //   old > mine : e is the smallest so far                         -> candidate              (cand[e] = 1);
-//                if old is a pending word of THIS fill, its instance old.value has just been beaten: the
-//                thief says so in lost[old.value] (each candidate is beaten at most once -- by the next smaller
-//                arrival -- and only thieves write `lost`, only e writes cand[e]: no word has two writers).
-// After the fill (kernel boundary): e owns its key  <=>  cand[e] && lost[e] != tag.  `tag` is a 64-bit launch
+//                if old is a pending word of THIS fill, its instance has just been beaten: the thief says so in
+//                lost[that instance] (each candidate is beaten at most once -- by the next smaller arrival -- and
+//                only thieves write `lost`, only e writes cand[e]: no word has two writers).
+// After the fill (kernel boundary): e owns its key  <=>  cand[e] == 1 && lost[e] != tag.  `tag` is a 64-bit launch
 // counter started from a random nonce, so `lost` never needs clearing (a stale or foreign word cannot match).
+//
+// Two modes.  LEAF (the table API, ggms_hashtable_*): base = 0, the owner scan then rewrites the word as
+// {assigned, local id} -- what SearchO2N / ggms_map_edges read, and what makes later fills lose to it.
+// BATCH (ggms_sample_batch): every fill of the batch draws its indices from ONE index space -- seeds [0, S), then
+// the layers in processing order -- so an earlier fill's word is simply SMALLER than anything a later fill
+// offers and the table is never rewritten (one random 8-byte store per unique node saved).  The local id of the
+// instance with index idx lives where the owner scan put it: IdxMap::local_of(idx) = that fill's output array.
+// An instance that loses to an EARLIER fill knows its local id at once (cand[e] = 2 + id); one that loses inside
+// its own fill is resolved at the end of the batch (table word -> index -> IdxMap).
+struct IdxMap {
+  uint32_t base[17];        // first index of segment s, ascending; segment 0 = the seeds
+  const uint32_t *arr[17];  // local ids of segment s, by index - base[s] (seed_local / the layer's row)
+  uint32_t n;
+  __device__ __forceinline__ uint32_t local_of(uint32_t idx) const {
+    uint32_t s = 0;
+#pragma unroll
+    for (uint32_t k = 1; k < 17; ++k) s = (k < n && idx >= base[k]) ? k : s;
+    return arr[s][idx - base[s]];
+  }
+};
+
 struct DedupInsert {
   unsigned long long *w; // table words, indexed by node id
   uint32_t version;
   uint32_t *cand;
   unsigned long long *lost;
   unsigned long long tag;
+  uint32_t base;  // index of this fill's item 0 (0 in leaf mode)
+  uint32_t batch; // 1: batch mode, `map` holds the fills before this one
+  IdxMap map;
   __device__ __forceinline__ void enter(uint32_t key, uint32_t e) const {
-    const unsigned long long mine = make_w1(version, 1u, e);
+    const unsigned long long mine = make_w1(version, 1u, base + e);
     const unsigned long long old = atomicMin(w + key, mine);
-    cand[e] = old > mine ? 1u : 0u;
-    if (old > mine && (old >> 32) == (mine >> 32)) lost[(uint32_t)old] = tag;
+    if (old > mine) {
+      cand[e] = 1u;
+      if ((old >> 32) == (mine >> 32)) lost[(uint32_t)old - base] = tag; // a pending word of this fill: beaten
+    } else {
+      const uint32_t idx = (uint32_t)old;
+      cand[e] = (batch && idx < base) ? 2u + map.local_of(idx) : 0u;
+    }
   }
 };
 unsigned long long next_dedup_tag(); // common.hip

@@ -67,17 +67,20 @@ struct MapRestJobs {
   const uint64_t *num[16];
 };
 int launch_map_rest_all(const ggms_hashtable_t *ht, const MapRestJobs &jobs, uint32_t num_jobs, size_t max_items,
-                        uint64_t *status_out, hipStream_t s);
+                        const IdxMap &map, uint64_t *status_out, hipStream_t s);
 size_t owner_scan_tiles(size_t n_max);
-// insert + ordered local-id assignment.  item_pos: n_max words (hashed layout: bucket of input[i]; direct layout:
-// the insert's `cand` flags); lost: n_max 64-bit words (direct layout).
+// insert + ordered local-id assignment (see DedupInsert in ggms_device.h for the two modes).
+// di: cand (n_max words; hashed layout: bucket positions) + lost (n_max 64-bit words), and in batch mode the index
+//     base of this fill + the IdxMap of the fills before it; w / version / tag are filled in here.
+// inserted: the producer of `input` already entered every item with exactly this `di` (fused sampler).
 // mirror_a/b (optional): 64-bit device slots that also receive the new item count.
-// mapped (optional): mapped[i] = local id of input[i] (the dst half of GPUMapEdges, fused); with defer_rest the
-// instances that do not own their key keep kEmptyKey for the caller's launch_map_rest_all.
-// pre (direct layout): the producer of `input` already entered every item (fused sampler).
-int ht_fill_impl(const ggms_hashtable_t *ht, const uint32_t *input, size_t n_max, Count n, uint32_t *item_pos,
-                 unsigned long long *lost, ScanArea scan, uint64_t *mirror_a, uint64_t *mirror_b, hipStream_t s,
-                 uint32_t *mapped = nullptr, const BatchPrologue *prologue = nullptr, const DedupInsert *pre = nullptr,
-                 bool defer_rest = false);
+// mapped (optional): mapped[i] = local id of input[i] (the dst half of GPUMapEdges, fused).
+// rest: kRestNow resolves the instances that do not own their key here (batch mode: needs n_dev_for_rest, a device
+//       copy of the item count, and di.map must already include this fill); kRestDefer leaves kEmptyKey for the
+//       caller's launch_map_rest_all at the end of the batch.
+constexpr int kRestNow = 0, kRestDefer = 1;
+int ht_fill_impl(const ggms_hashtable_t *ht, const uint32_t *input, size_t n_max, Count n, DedupInsert di,
+                 bool inserted, ScanArea scan, uint64_t *mirror_a, uint64_t *mirror_b, hipStream_t s, uint32_t *mapped,
+                 const BatchPrologue *prologue, int rest, const uint64_t *n_dev_for_rest);
 
 } // namespace ggms

@@ -191,11 +191,11 @@ __global__ __launch_bounds__(kBlock) void k_map_rest(Table t, const uint32_t *__
     }
 }
 
-// Same for every layer of a batch in ONE launch (blockIdx.y = layer): an assigned word never changes within a
-// batch, so the look-ups of all layers can wait until the last fill is done.  Also hands the device status word
-// to the batch's counts (counts_dev[3 L + 1]).
+// Batch mode, every layer in ONE launch (blockIdx.y = job): the instances that lost to another instance of their
+// own fill.  A key's word is final once its fill is over, so the look-ups of all layers can wait until the last
+// fill is done.  Also hands the device status word to the batch's counts (counts_dev[3 L + 1]).
 __global__ __launch_bounds__(kBlock) void k_map_rest_all(const unsigned long long *__restrict__ w, MapRestJobs jobs,
-                                                         const uint32_t *status, uint64_t *status_out) {
+                                                         IdxMap map, const uint32_t *status, uint64_t *status_out) {
   if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && status_out) *status_out = status ? *status : 0u;
   const uint32_t l = blockIdx.y;
   uint32_t *__restrict__ row = jobs.row[l];
@@ -214,13 +214,14 @@ __global__ __launch_bounds__(kBlock) void k_map_rest_all(const unsigned long lon
     if (r.y == kEmptyKey) w1 = w[k.y];
     if (r.z == kEmptyKey) w2 = w[k.z];
     if (r.w == kEmptyKey) w3 = w[k.w];
-    if (r.x == kEmptyKey) row[4 * q + 0] = (uint32_t)w0;
-    if (r.y == kEmptyKey) row[4 * q + 1] = (uint32_t)w1;
-    if (r.z == kEmptyKey) row[4 * q + 2] = (uint32_t)w2;
-    if (r.w == kEmptyKey) row[4 * q + 3] = (uint32_t)w3;
+    // the word holds the INDEX of the key's owner (batch mode); the owner's entry of its fill's output is its local id
+    if (r.x == kEmptyKey) row[4 * q + 0] = map.local_of((uint32_t)w0);
+    if (r.y == kEmptyKey) row[4 * q + 1] = map.local_of((uint32_t)w1);
+    if (r.z == kEmptyKey) row[4 * q + 2] = map.local_of((uint32_t)w2);
+    if (r.w == kEmptyKey) row[4 * q + 3] = map.local_of((uint32_t)w3);
   }
   for (uint64_t i = 4 * n4 + (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (uint64_t)gridDim.x * kBlock)
-    if (row[i] == kEmptyKey) row[i] = (uint32_t)w[key[i]];
+    if (row[i] == kEmptyKey) row[i] = map.local_of((uint32_t)w[key[i]]);
 }
 
 // ---- direct layout: owners -> local ids, one launch -----------------------------------------------------------
@@ -231,6 +232,7 @@ __global__ __launch_bounds__(kBlock) void k_map_rest_all(const unsigned long lon
 // decoupled look-back (tile_scan.h).  mapped[i] = local id for the owners, kEmptyKey for the rest (looked up later).
 constexpr uint32_t kOwnItems = 8, kOwnTile = kOwnItems * kBlock;
 
+template <bool BATCH>
 __global__ __launch_bounds__(kBlock) void k_owner_scan(unsigned long long *__restrict__ w, uint32_t version,
                                                        uint32_t *__restrict__ n2o,
                                                        const uint32_t *__restrict__ items,
@@ -254,7 +256,7 @@ __global__ __launch_bounds__(kBlock) void k_owner_scan(unsigned long long *__res
     const uint64_t tile = s_tile;
     if (tile >= num_tiles) break;
     const uint64_t i0 = tile * kOwnTile + (uint64_t)threadIdx.x * kOwnItems;
-    uint32_t key[kOwnItems], flag[kOwnItems];
+    uint32_t key[kOwnItems], flag[kOwnItems], cnd[kOwnItems];
     if (vec_ok && i0 + kOwnItems <= n) {
       const uint4 c0 = *reinterpret_cast<const uint4 *>(cand + i0), c1 = *reinterpret_cast<const uint4 *>(cand + i0 + 4);
       const uint4 k0 = *reinterpret_cast<const uint4 *>(items + i0), k1 = *reinterpret_cast<const uint4 *>(items + i0 + 4);
@@ -263,15 +265,17 @@ __global__ __launch_bounds__(kBlock) void k_owner_scan(unsigned long long *__res
       const ulonglong2 l2 = *reinterpret_cast<const ulonglong2 *>(lost + i0 + 4);
       const ulonglong2 l3 = *reinterpret_cast<const ulonglong2 *>(lost + i0 + 6);
       key[0] = k0.x; key[1] = k0.y; key[2] = k0.z; key[3] = k0.w; key[4] = k1.x; key[5] = k1.y; key[6] = k1.z; key[7] = k1.w;
-      flag[0] = c0.x && l0.x != tag; flag[1] = c0.y && l0.y != tag; flag[2] = c0.z && l1.x != tag;
-      flag[3] = c0.w && l1.y != tag; flag[4] = c1.x && l2.x != tag; flag[5] = c1.y && l2.y != tag;
-      flag[6] = c1.z && l3.x != tag; flag[7] = c1.w && l3.y != tag;
+      cnd[0] = c0.x; cnd[1] = c0.y; cnd[2] = c0.z; cnd[3] = c0.w; cnd[4] = c1.x; cnd[5] = c1.y; cnd[6] = c1.z; cnd[7] = c1.w;
+      flag[0] = c0.x == 1u && l0.x != tag; flag[1] = c0.y == 1u && l0.y != tag; flag[2] = c0.z == 1u && l1.x != tag;
+      flag[3] = c0.w == 1u && l1.y != tag; flag[4] = c1.x == 1u && l2.x != tag; flag[5] = c1.y == 1u && l2.y != tag;
+      flag[6] = c1.z == 1u && l3.x != tag; flag[7] = c1.w == 1u && l3.y != tag;
     } else {
 #pragma unroll
       for (uint32_t k = 0; k < kOwnItems; ++k) {
         const uint64_t i = i0 + k;
         key[k] = i < n ? items[i] : 0u;
-        flag[k] = (i < n && cand[i] && lost[i] != tag) ? 1u : 0u;
+        cnd[k] = i < n ? cand[i] : 0u;
+        flag[k] = (i < n && cnd[k] == 1u && lost[i] != tag) ? 1u : 0u;
       }
     }
     uint32_t mine = 0;
@@ -308,9 +312,12 @@ __global__ __launch_bounds__(kBlock) void k_owner_scan(unsigned long long *__res
     uint32_t out[kOwnItems];
 #pragma unroll
     for (uint32_t k = 0; k < kOwnItems; ++k) {
-      out[k] = kEmptyKey;
+      // batch mode: an instance that lost to an earlier fill carries its local id in cand (2 + id), and the
+      // table is not rewritten (the owner's index stays there: IdxMap); leaf mode: the owner's word becomes
+      // {assigned, local id}
+      out[k] = (BATCH && cnd[k] >= 2u) ? cnd[k] - 2u : kEmptyKey;
       if (flag[k]) {
-        w[key[k]] = make_w1(version, 0u, local);
+        if (!BATCH) w[key[k]] = make_w1(version, 0u, local);
         n2o[local] = key[k];
         out[k] = local++;
       }
@@ -355,27 +362,29 @@ __global__ void k_status_copy(const uint32_t *status, uint64_t *status_out) {
 }
 
 int launch_map_rest_all(const ggms_hashtable_t *ht, const MapRestJobs &jobs, uint32_t num_jobs, size_t max_items,
-                        uint64_t *status_out, hipStream_t s) {
+                        const IdxMap &map, uint64_t *status_out, hipStream_t s) {
   if (num_jobs == 0) { // nothing deferred (hashed layout, or no layer could sample): only the status word
+    if (!status_out) return GGMS_OK;
     hipLaunchKernelGGL(k_status_copy, dim3(1), dim3(64), 0, s, (const uint32_t *)device_status_word(), status_out);
     GGMS_LAUNCH_CHECK();
     return GGMS_OK;
   }
   const int gx = grid_for(max_items ? max_items : 1, kBlock);
-  hipLaunchKernelGGL(k_map_rest_all, dim3(gx, num_jobs), dim3(kBlock), 0, s, (const unsigned long long *)ht->o2n, jobs,
-                     (const uint32_t *)device_status_word(), status_out);
+  hipLaunchKernelGGL(k_map_rest_all, dim3(gx, num_jobs), dim3(kBlock), 0, s, (const unsigned long long *)ht->o2n, jobs, map,
+                     (const uint32_t *)(status_out ? device_status_word() : nullptr), status_out);
   GGMS_LAUNCH_CHECK();
   return GGMS_OK;
 }
 
 // mapped != NULL: also produce the local id of every input instance (FillWithDuplicates + the dst half of
-// GPUMapEdges in one go): owners write theirs while assigning, the rest is looked up afterwards -- here
-// (k_map_rest) or, with defer_rest, by the caller's k_map_rest_all at the end of the batch (direct layout only).
+// GPUMapEdges in one go): owners write theirs while assigning, the rest is looked up afterwards.
 // prologue: this is the first kernel of a batch -- it also zeroes the shared scan area's control words.
-// pre (direct layout): the producer of `input` already entered every item with these cand / lost / tag.
-int ht_fill_impl(const ggms_hashtable_t *ht, const uint32_t *input, size_t n_max, Count n, uint32_t *item_pos,
-                 unsigned long long *lost, ScanArea scratch, uint64_t *mirror_a, uint64_t *mirror_b, hipStream_t s,
-                 uint32_t *mapped, const BatchPrologue *prologue, const DedupInsert *pre, bool defer_rest) {
+// Direct layout: `di` carries cand / lost (and, in batch mode, the index base + IdxMap of the earlier fills);
+// inserted = the producer of `input` already entered every item with exactly this `di` (fused sampler).
+// rest: kRestNow = resolve the non-owners here; kRestDefer (batch mode) = the caller's launch_map_rest_all does.
+int ht_fill_impl(const ggms_hashtable_t *ht, const uint32_t *input, size_t n_max, Count n, DedupInsert di,
+                 bool inserted, ScanArea scratch, uint64_t *mirror_a, uint64_t *mirror_b, hipStream_t s,
+                 uint32_t *mapped, const BatchPrologue *prologue, int rest, const uint64_t *n_dev_for_rest) {
   BatchPrologue pro{nullptr, 0, nullptr, nullptr};
   if (prologue) pro = *prologue;
   if (n_max == 0) { // no kernel to ride on
@@ -387,47 +396,52 @@ int ht_fill_impl(const ggms_hashtable_t *ht, const uint32_t *input, size_t n_max
   Table t = table_of(ht);
   uint32_t *err = device_status_word();
   const int grid = grid_for(n_max, kBlock);
-  int rc;
-  if (ht->direct) {
-    DedupInsert di{(unsigned long long *)ht->o2n, ht->version, item_pos, lost, 0ull};
-    if (pre) {
-      di = *pre;
-    } else {
-      di.tag = next_dedup_tag();
-      hipLaunchKernelGGL(k_ht_insert<true>, dim3(grid), dim3(kBlock), 0, s, t, input, n, item_pos, pro, di, err);
-      GGMS_LAUNCH_CHECK();
-    }
-    uint32_t *ctl = scan_align(scratch.words);
-    unsigned long long *desc = reinterpret_cast<unsigned long long *>(ctl + 8);
-    if (!scratch.cleared) {
-      GGMS_HIP(hipMemsetAsync(ctl, 0, (8 + 2 * (owner_scan_tiles(n_max) + 1)) * sizeof(uint32_t), s));
-      // test hook (tests/test_gpu_parity.py): start the ticket at 1, so tile 0 is never processed and every later
-      // tile's look-back runs into its bound -- the failure the status word exists for
-      if (getenv("GGMS_TEST_POISON_SCAN")) GGMS_HIP(hipMemsetD32Async((hipDeviceptr_t)ctl, 1, 1, s));
-    }
-    // Fewer workgroups than tiles on purpose: a workgroup takes tiles from the ticket one after the other, so by the
-    // time tile t is taken the tiles before t - grid have finished and the look-back finds a published prefix in
-    // its first window; with one workgroup per tile every tile starts at once and tile t walks t / 64 windows.
-    const int oscan_grid = (int)std::min<size_t>(grid_for(owner_scan_tiles(n_max), 1), owner_scan_grid_cap());
-    hipLaunchKernelGGL(k_owner_scan, dim3(oscan_grid), dim3(kBlock), 0, s, di.w, di.version,
-                       ht->n2o, input, di.cand, di.lost, di.tag, mapped, n, ctl, desc, next_scan_epoch(),
-                       ht->num_items_dev, mirror_a, mirror_b, err);
+  uint32_t *item_pos = di.cand; // hashed layout: bucket positions
+  if (!ht->direct) {
+    hipLaunchKernelGGL(k_ht_insert<false>, dim3(grid), dim3(kBlock), 0, s, t, input, n, item_pos, pro, di, err);
     GGMS_LAUNCH_CHECK();
-    rc = GGMS_OK;
-  } else {
-    hipLaunchKernelGGL(k_ht_insert<false>, dim3(grid), dim3(kBlock), 0, s, t, input, n, item_pos, pro,
-                       DedupInsert{nullptr, 0, nullptr, nullptr, 0ull}, err);
-    GGMS_LAUNCH_CHECK();
-    rc = tile_scan(OwnerFlag<false>{t, item_pos}, AssignLocal<false>{t, input, item_pos, mapped}, n_max, n, scratch,
-                   ht->num_items_dev, ht->num_items_dev, nullptr, s, mirror_a, mirror_b);
-  }
-  if (rc != GGMS_OK || !mapped) return rc;
-  if (ht->direct) {
-    if (defer_rest) return GGMS_OK;
-    hipLaunchKernelGGL(k_map_rest<true>, dim3(grid), dim3(kBlock), 0, s, t, input, n, mapped);
-  } else {
+    int rc = tile_scan(OwnerFlag<false>{t, item_pos}, AssignLocal<false>{t, input, item_pos, mapped}, n_max, n, scratch,
+                       ht->num_items_dev, ht->num_items_dev, nullptr, s, mirror_a, mirror_b);
+    if (rc != GGMS_OK || !mapped) return rc;
     hipLaunchKernelGGL(k_map_rest<false>, dim3(grid), dim3(kBlock), 0, s, t, item_pos, n, mapped);
+    GGMS_LAUNCH_CHECK();
+    return GGMS_OK;
   }
+  di.w = (unsigned long long *)ht->o2n;
+  di.version = ht->version;
+  if (!inserted) {
+    di.tag = next_dedup_tag();
+    hipLaunchKernelGGL(k_ht_insert<true>, dim3(grid), dim3(kBlock), 0, s, t, input, n, item_pos, pro, di, err);
+    GGMS_LAUNCH_CHECK();
+  }
+  uint32_t *ctl = scan_align(scratch.words);
+  unsigned long long *desc = reinterpret_cast<unsigned long long *>(ctl + 8);
+  if (!scratch.cleared) {
+    GGMS_HIP(hipMemsetAsync(ctl, 0, (8 + 2 * (owner_scan_tiles(n_max) + 1)) * sizeof(uint32_t), s));
+    // test hook (tests/test_gpu_parity.py): start the ticket at 1, so tile 0 is never processed and every later
+    // tile's look-back runs into its bound -- the failure the status word exists for
+    if (getenv("GGMS_TEST_POISON_SCAN")) GGMS_HIP(hipMemsetD32Async((hipDeviceptr_t)ctl, 1, 1, s));
+  }
+  // Fewer workgroups than tiles on purpose: a workgroup takes tiles from the ticket one after the other, so by the
+  // time tile t is taken the tiles before t - grid have finished and the look-back finds a published prefix in
+  // its first window; with one workgroup per tile every tile starts at once and tile t walks t / 64 windows.
+  const int oscan_grid = (int)std::min<size_t>(grid_for(owner_scan_tiles(n_max), 1), owner_scan_grid_cap());
+  if (di.batch)
+    hipLaunchKernelGGL(k_owner_scan<true>, dim3(oscan_grid), dim3(kBlock), 0, s, di.w, di.version, ht->n2o, input, di.cand,
+                       di.lost, di.tag, mapped, n, ctl, desc, next_scan_epoch(), ht->num_items_dev, mirror_a, mirror_b, err);
+  else
+    hipLaunchKernelGGL(k_owner_scan<false>, dim3(oscan_grid), dim3(kBlock), 0, s, di.w, di.version, ht->n2o, input, di.cand,
+                       di.lost, di.tag, mapped, n, ctl, desc, next_scan_epoch(), ht->num_items_dev, mirror_a, mirror_b, err);
+  GGMS_LAUNCH_CHECK();
+  if (!mapped || rest == kRestDefer) return GGMS_OK;
+  if (di.batch) { // this fill's own non-owners, now: the map must already hold this fill's segment
+    MapRestJobs jobs{};
+    jobs.row[0] = mapped;
+    jobs.key[0] = input;
+    jobs.num[0] = n_dev_for_rest;
+    return launch_map_rest_all(ht, jobs, 1, n_max, di.map, nullptr, s);
+  }
+  hipLaunchKernelGGL(k_map_rest<true>, dim3(grid), dim3(kBlock), 0, s, t, input, n, mapped);
   GGMS_LAUNCH_CHECK();
   return GGMS_OK;
 }
@@ -487,8 +501,11 @@ int ggms_hashtable_fill_with_duplicates(ggms_hashtable_t *ht, const ggms_id_t *i
     uint32_t *item_pos = (uint32_t *)workspace;
     unsigned long long *lost = (unsigned long long *)(((uintptr_t)(item_pos + num_input) + 15) & ~(uintptr_t)15);
     uint32_t *scan_words = (uint32_t *)(lost + num_input);
-    int rc = ht_fill_impl(ht, input, num_input, count_of(num_input), item_pos, lost, ScanArea{scan_words, false},
-                          nullptr, nullptr, s, nullptr, nullptr, nullptr, false);
+    DedupInsert di{};
+    di.cand = item_pos;
+    di.lost = lost; // leaf mode: base 0, the owners' words are rewritten as {assigned, local id}
+    int rc = ht_fill_impl(ht, input, num_input, count_of(num_input), di, false, ScanArea{scan_words, false}, nullptr,
+                          nullptr, s, nullptr, nullptr, kRestNow, nullptr);
     if (rc != GGMS_OK) return rc;
   }
   if (unique_out) {

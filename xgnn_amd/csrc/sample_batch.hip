@@ -168,7 +168,7 @@ int ggms_sample_batch(int sample_type, const ggms_graph_t *graph, const ggms_id_
   hipStream_t s = to_stream(stream);
   const BatchCaps c = caps_of(num_seeds, fanouts, num_layer);
   GGMS_CHECK_ARG(c.max_input[0] + c.max_edges[0] <= ht->n2o_size);
-  GGMS_CHECK_ARG(c.max_input[0] + c.max_edges[0] < (1ull << 32));
+  GGMS_CHECK_ARG(c.max_input[0] + c.max_edges[0] < (1ull << 32) - 4); // indices and 2 + local id fit 32 bits
   if (sample_type == GGMS_WEIGHTED_KHOP_HASH_DEDUP) GGMS_CHECK_ARG((c.max_in_all + 1023) / 1024 * 256 <= num_states);
   if (sample_type == GGMS_KHOP2) { // unsharded CSR, mutated in place (dist_loops.cc:217-224)
     GGMS_CHECK_ARG(graph->num_part == 0 && graph->indptr && graph->indices);
@@ -202,9 +202,19 @@ int ggms_sample_batch(int sample_type, const ggms_graph_t *graph, const ggms_id_
   const size_t clear_words = scan_mode() == 1 ? 8 + 2 * (num_tiles_for(std::max(c.max_e_all, c.max_in_all)) + 1) : 0;
   const BatchPrologue pro{scan_align(scan.words), (uint32_t)std::max<size_t>(8 + 2 * lay.scan_tiles, clear_words),
                           ht->num_items_dev, counts_dev + 3 * (num_layer - 1) + 2};
-  int rc = ht_fill_impl(ht, seeds, num_seeds, count_of(num_seeds), item_pos, lost, scan, nullptr, nullptr, s,
-                        seed_local, &pro);
+  // direct table = batch mode of the dedup protocol (ggms_device.h): one index space for the whole batch, seeds first
+  DedupInsert di{};
+  di.cand = item_pos;
+  di.lost = lost;
+  di.batch = ht->direct ? 1u : 0u;
+  di.base = 0;
+  di.map.n = 1;
+  di.map.base[0] = 0;
+  di.map.arr[0] = seed_local;
+  int rc = ht_fill_impl(ht, seeds, num_seeds, count_of(num_seeds), di, false, scan, nullptr, nullptr, s, seed_local, &pro,
+                        kRestNow, pro.record_n);
   if (rc != GGMS_OK) return rc;
+  uint32_t next_base = (uint32_t)num_seeds;
 
   MapRestJobs jobs{};
   uint32_t num_jobs = 0;
@@ -222,15 +232,17 @@ int ggms_sample_batch(int sample_type, const ggms_graph_t *graph, const ggms_id_
     // batch order on the shared RNG pool (and on khop2's CSR): only the sampler kernels are ordered
     if (first && extra && extra->rng_wait) GGMS_HIP(hipStreamWaitEvent(s, (hipEvent_t)extra->rng_wait, 0));
     // direct table + khop3: the sampler enters its output into the table itself (DedupInsert)
-    DedupInsert pre{(unsigned long long *)ht->o2n, ht->version, item_pos, lost, 0ull};
+    di.base = next_base; // this layer's edges take the indices [base, base + e_max)
+    di.w = (unsigned long long *)ht->o2n;
+    di.version = ht->version;
     bool inserted = false;
     if (n_max == 0) {
       GGMS_HIP(hipMemsetAsync(num_edge, 0, sizeof(uint64_t), s));
     } else if (sample_type == GGMS_KHOP3) {
       inserted = ht->direct != 0 && e_max != 0;
-      if (inserted) pre.tag = next_dedup_tag();
+      if (inserted) di.tag = next_dedup_tag();
       rc = sample_khop3_impl(g, input, n_max, n, (uint32_t)fanouts[i], col[i], tmp_dst, num_edge, (uint32_t *)states,
-                             samp_ws, first ? seed_local : nullptr, 1, s, &scan, inserted ? &pre : nullptr);
+                             samp_ws, first ? seed_local : nullptr, 1, s, &scan, inserted ? &di : nullptr);
     } else if (sample_type == GGMS_KHOP0) {
       rc = sample_khop0_impl(g, input, n_max, n, (uint32_t)fanouts[i], col[i], tmp_dst, num_edge, samp_ws,
                              first ? seed_local : nullptr, 1, s, &scan);
@@ -271,10 +283,14 @@ int ggms_sample_batch(int sample_type, const ggms_graph_t *graph, const ggms_id_
     }
     // FillWithDuplicates (:279) + the dst half of GPUMapEdges (:296): row[i] = local id of every sampled neighbour
     // (direct table: the instances that do not own their key are resolved for all layers at once, below)
-    rc = ht_fill_impl(ht, tmp_dst, e_max, ne, item_pos, lost, scan, num_src, next_dst, s, row[i], nullptr,
-                      inserted ? &pre : nullptr, ht->direct != 0);
+    rc = ht_fill_impl(ht, tmp_dst, e_max, ne, di, inserted, scan, num_src, next_dst, s, row[i], nullptr,
+                      ht->direct ? kRestDefer : kRestNow, nullptr);
     if (rc != GGMS_OK) return rc;
     if (ht->direct) {
+      di.map.base[di.map.n] = next_base; // later fills (and the final look-ups) find this layer's local ids in row[i]
+      di.map.arr[di.map.n] = row[i];
+      ++di.map.n;
+      next_base += (uint32_t)e_max;
       jobs.row[num_jobs] = row[i];
       jobs.key[num_jobs] = tmp_dst;
       jobs.num[num_jobs] = num_edge;
@@ -283,7 +299,7 @@ int ggms_sample_batch(int sample_type, const ggms_graph_t *graph, const ggms_id_
     }
   }
   // the rest of GPUMapEdges' dst half for every layer + the batch's status word (counts_dev[3 L + 1])
-  return launch_map_rest_all(ht, jobs, num_jobs, job_items, counts_dev + 3 * num_layer + 1, s);
+  return launch_map_rest_all(ht, jobs, num_jobs, job_items, di.map, counts_dev + 3 * num_layer + 1, s);
 }
 
 } // extern "C"

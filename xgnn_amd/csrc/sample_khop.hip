@@ -595,7 +595,7 @@ int sample_khop3_impl(GraphView g, const uint32_t *input, size_t n_max, Count n,
   const int gpw = khop3_groups_per_wave(tiles);
   const int grid = grid_for(tiles, 1);
   const size_t lds = 128 * (size_t)fanout * sizeof(uint32_t);
-  const DedupInsert none{nullptr, 0, nullptr, nullptr, 0ull};
+  const DedupInsert none{};
   if (insert) {
     if (gpw == 1) launch_khop3_fused<1, true>(grid, lds, s, g, input, n, fanout, out_src, out_dst, sm, states, set_mask, fs, *insert);
     else if (gpw == 2) launch_khop3_fused<2, true>(grid, lds, s, g, input, n, fanout, out_src, out_dst, sm, states, set_mask, fs, *insert);
