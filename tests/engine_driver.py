@@ -1,6 +1,6 @@
 """Runs the samgraph_* engine like a reference example script would and dumps every batch to .npz.
 
-    python tests/engine_driver.py <dataset_dir> <out_prefix> <arch1|arch6> [num_worker] [extra k=v ...]
+    python tests/engine_driver.py <dataset_dir> <out_prefix> <arch0|arch1|arch6> [num_worker] [extra k=v ...]
 
 arch6 follows example/samgraph/sgnn/train_graphsage.py:106-108,397-412: config + data_init in the parent, one
 forked worker per GPU (os.fork before anything touches the GPU), each worker sample_init/train_init and
@@ -38,7 +38,8 @@ def run_worker(sam, worker_id, num_layers, out_prefix, pipelined):
         rec["num_sample"] = sam.get_log_step_value_by_key(key, sam.kLogL1NumSample)
         for k, v in rec.items():
             batches[f"{key}:{k}"] = v
-    torch.cuda.synchronize()
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()
     np.savez(f"{out_prefix}.w{worker_id}.npz", **batches)
     sam.shutdown()
 
@@ -55,12 +56,19 @@ def main():
            "batch_size": int(extra.pop("batch_size", 64)), "num_epoch": int(extra.pop("num_epoch", 2)),
            "_cache_policy": sam.cache_policies[extra.pop("cache_policy", "degree")],
            "cache_percentage": float(extra.pop("cache_percentage", 0.0)), "max_sampling_jobs": 10,
-           "max_copying_jobs": 2, "omp_thread_num": 4, "num_layer": len(fanout), "num_hidden": 256, "lr": 0.003,
+           "max_copying_jobs": 2, "omp_thread_num": int(extra.pop("omp_thread_num", 4)), "num_layer": len(fanout), "num_hidden": 256, "lr": 0.003,
            "dropout": 0.5, "num_fanout": len(fanout), "fanout": fanout, "seed": int(extra.pop("seed", 1234))}
     if cfg["_sample_type"] == sam.kRandomWalk:  # operation.cc:164-175: no fanout keys, num_neighbor per layer
         cfg.pop("num_fanout"), cfg.pop("fanout")
         cfg.update(random_walk_length=3, random_walk_restart_prob=0.5, num_random_walk=4, num_neighbor=5)
     cfg.update(extra)
+    if arch == "arch0":  # CPU sampler + extractor (cpu_engine.cc); trainer_ctx=cpu:0 keeps the batch on the host
+        cfg["sampler_ctx"] = "cpu:0"
+        cfg.setdefault("trainer_ctx", "cuda:0")
+        sam.config(cfg)
+        sam.init()
+        run_worker(sam, 0, len(fanout), out_prefix, pipelined)
+        return
     if arch == "arch1":
         cfg.update(sampler_ctx="cuda:0", trainer_ctx="cuda:0")
         sam.config(cfg)

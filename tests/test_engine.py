@@ -57,6 +57,105 @@ sam.config({{'dataset_path': '/nonexistent', '_arch': 1}})
     assert "missing config key" in out.stderr
 
 
+def _replay_arch0(d, batch_size, num_epoch, fanouts, seed, sample_type, sampler, extract):
+    """CPUEngine semantics (cpu_loops.cc:41-228): CPUShuffler (no padding, shuffled in place epoch after epoch), then
+    per batch the CPU sampler + first-occurrence dedup/remap + CPUExtract.  `sampler` / `extract` are the leaves under
+    test: the oracle's ports or the reference's own objects (oracle/_ref); the caller resets their RNG first."""
+    data = d["train"].copy()
+    n_step = (data.size + batch_size - 1) // batch_size
+    ix = d["ix"].copy()  # khop2 permutes the lists
+    out = {}
+    for ep in range(num_epoch):
+        data = oracle.shuffle_minstd0(data, seed + ep)
+        for st in range(n_step):
+            seeds = data[st * batch_size:(st + 1) * batch_size]
+            ht = oracle.HashTable(d["ip"].size - 1, oracle.predict_num_nodes(seeds.size, fanouts, len(fanouts)) + 1)
+            ht.fill_with_duplicates(seeds)
+            cur, layers = seeds, [None] * len(fanouts)
+            for i in range(len(fanouts) - 1, -1, -1):
+                src, dst = sampler(d["ip"], ix, cur, fanouts[i])
+                ht.fill_with_duplicates(dst)
+                col, row = ht.map_edges(src, dst)
+                layers[i] = dict(row=row, col=col, num_src=ht.num_items, num_dst=cur.size, data=None)
+                cur = ht.unique()
+            out[ep * n_step + st] = dict(res=dict(layers=layers, input_nodes=cur), seeds=seeds,
+                                         feat=extract(d["feat"], cur), label=d["label"][seeds])
+    return out
+
+
+@pytest.mark.parametrize("sample_type", ["khop0", "khop2"])
+def test_arch0_cpu_engine_end_to_end(tmp_path, sample_type):
+    """BASELINE configs[0]: the CPU deployment (cpu_engine.cc) through the samgraph_* ABI, trainer on the host, one
+    sampling thread -- against the oracle's ports AND, where oracle/_ref is built, against the reference's own
+    CPUSampleKHop0/2 + CPUExtract objects run in the same call order (default-seeded thread_local mt19937)."""
+    d = make_dataset(tmp_path / "ds")
+    prefix = str(tmp_path / "out")
+    r = subprocess.run([sys.executable, DRIVER, d["path"], prefix, "arch0", "1", f"sample_type={sample_type}", "seed=7",
+                        "batch_size=64", "fanout=5 4", "trainer_ctx=cpu:0", "omp_thread_num=1", "num_epoch=2"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    got = np.load(prefix + ".w0.npz")
+    port = {"khop0": oracle.cpu_sample_khop0, "khop2": oracle.cpu_sample_khop2}[sample_type]
+    oracle.cpu_random_reset()
+    _check(got, _replay_arch0(d, 64, 2, [5, 4], 7, sample_type, port, oracle.extract), 2)
+    if oracle.ref_lib() is not None:  # the reference's objects keep their RNG per process: replay in a fresh one
+        code = f"""
+import sys, pickle; sys.path.insert(0, {ROOT!r}); sys.path.insert(0, {os.path.join(ROOT, 'tests')!r})
+import numpy as np, oracle, test_engine
+d = pickle.load(open({str(tmp_path / 'd.pkl')!r}, 'rb'))
+ref = {{'khop0': oracle.ref_cpu_sample_khop0, 'khop2': oracle.ref_cpu_sample_khop2}}[{sample_type!r}]
+want = test_engine._replay_arch0(d, 64, 2, [5, 4], 7, {sample_type!r}, ref, oracle.ref_cpu_extract)
+test_engine._check(np.load({prefix + '.w0.npz'!r}), want, 2)
+print('ref-ok')
+"""
+        import pickle
+        pickle.dump(d, open(str(tmp_path / "d.pkl"), "wb"))
+        rr = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+        assert rr.returncode == 0 and "ref-ok" in rr.stdout, rr.stderr[-2000:]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("pipelined", [0, 1])
+def test_arch0_gpu_trainer(tmp_path, pipelined):
+    """arch0 as the reference runs it: CPU sampler + extractor, batch copied to the trainer GPU (DoGraphCopy /
+    DoFeatureCopy, cpu_loops.cc:230-299); also through the background thread (extract_start)."""
+    d = make_dataset(tmp_path / "ds")
+    prefix = str(tmp_path / "out")
+    r = subprocess.run([sys.executable, DRIVER, d["path"], prefix, "arch0", "1", "sample_type=khop0", "seed=7",
+                        "batch_size=64", "fanout=5 4", "trainer_ctx=cuda:0", "omp_thread_num=1", "num_epoch=2",
+                        f"pipelined={pipelined}"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    oracle.cpu_random_reset()
+    _check(np.load(prefix + ".w0.npz"), _replay_arch0(d, 64, 2, [5, 4], 7, "khop0", oracle.cpu_sample_khop0, oracle.extract), 2)
+
+
+def test_arch0_threads_keep_the_structure(tmp_path):
+    """Four sampling threads (static blocks, a generator per thread): draws differ from the one-thread run, the
+    structure may not -- every seed keeps min(deg, fanout) distinct neighbours of its own list, ids are dense, rows
+    are the right feature rows."""
+    d = make_dataset(tmp_path / "ds")
+    prefix = str(tmp_path / "out")
+    r = subprocess.run([sys.executable, DRIVER, d["path"], prefix, "arch0", "1", "sample_type=khop0", "seed=7",
+                        "batch_size=64", "fanout=5 4", "trainer_ctx=cpu:0", "omp_thread_num=4", "num_epoch=1"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    got = np.load(prefix + ".w0.npz")
+    ip, ix = d["ip"], d["ix"]
+    deg = ip[1:].astype(np.int64) - ip[:-1]
+    keys = sorted({int(k.split(":")[0]) for k in got.files})
+    assert len(keys) == (d["train"].size + 63) // 64
+    for key in keys:
+        inp = got[f"{key}:input_nodes"].view(np.uint32)
+        assert np.unique(inp).size == inp.size
+        for i, f in ((1, 4), (0, 5)):
+            row, col = got[f"{key}:row{i}"].view(np.uint32), got[f"{key}:col{i}"].view(np.uint32)
+            nd = int(got[f"{key}:num_dst{i}"])
+            assert np.array_equal(np.bincount(col, minlength=nd), np.minimum(deg[inp[:nd]], f))
+            for e in range(0, row.size, 7):
+                assert inp[row[e]] in ix[ip[inp[col[e]]]:ip[inp[col[e]] + 1]]
+        assert got[f"{key}:feat"].tobytes() == oracle.extract(d["feat"], inp).astype(np.float32).tobytes()
+
+
 def _oracle_batches(d, worker_id, num_worker, batch_size, num_epoch, fanouts, seed, arch6, sample_type="khop3",
                     nstates=None, states=None, **kw):
     """Replays shuffler + sampler + extract on the CPU exactly as the engine is specified to."""

@@ -80,12 +80,19 @@ void Engine::Configure(const std::unordered_map<std::string, std::string> &kv_in
       cfg.trainer_device = parse_device(kv["trainer_ctx"]);
       cfg.num_worker = 1;
       break;
+    case kArch0: // CPU sampler + extractor, trainer on a GPU or (plumbing runs) on the host
+      SAM_CHECK(kv.count("sampler_ctx") && kv.count("trainer_ctx"), "arch0 needs sampler_ctx/trainer_ctx");
+      cfg.trainer_on_host = kv["trainer_ctx"].rfind("cpu", 0) == 0;
+      cfg.trainer_device = parse_device(kv["trainer_ctx"]);
+      cfg.omp_thread_num = std::max<size_t>(1, std::stoull(kv["omp_thread_num"]));
+      cfg.num_worker = 1;
+      break;
     case kArch6:
       SAM_CHECK(kv.count("num_worker"), "arch6 needs num_worker");
       cfg.num_worker = std::stoull(kv["num_worker"]);
       break;
     default:
-      fatal(__FILE__, __LINE__, "only arch1 (standalone) and arch6 (SGNN/XGNN) are built; see DESIGN.md");
+      fatal(__FILE__, __LINE__, "only arch0 (CPU), arch1 (standalone) and arch6 (SGNN/XGNN) are built; see DESIGN.md");
   }
   if (cfg.sample_type != GGMS_RANDOM_WALK) { // operation.cc:150-163
     SAM_CHECK(kv.count("num_fanout") && kv.count("fanout"), "khop sampling needs num_fanout/fanout");
@@ -624,6 +631,10 @@ void Engine::TrainInit(int worker_id, const std::string &ctx) {
 }
 
 void Engine::Init() { // samgraph_init, single process
+  if (cfg.arch == kArch0) {
+    CpuInit();
+    return;
+  }
   DataInit();
   const std::string ctx = "cuda:" + std::to_string(cfg.sampler_device);
   SampleInit(0, ctx);
@@ -637,6 +648,7 @@ void Engine::Shutdown() {
   bg_stop_ = true;
   pool_cv_.notify_all();
   if (bg_.joinable()) bg_.join();
+  if (cfg.arch == kArch0) CpuShutdown();
   for (auto &P : pipes_)
     if (P.stream) (void)hipStreamSynchronize(P.stream);
   if (stream_) (void)hipStreamSynchronize(stream_);
@@ -677,6 +689,7 @@ void Engine::RunSampleOnce(bool background) {
 // RunArch1LoopsOnce (cuda/cuda_loops_arch1.cc:43-86) / RunArch6LoopsOnce (dist/dist_loops_arch6.cc:236-243):
 // shuffle -> sample -> extract, all enqueued with no host round trip.  false: no free slot, or training finished.
 bool Engine::EnqueueOne(bool background) {
+  if (cfg.arch == kArch0) return CpuEnqueueOne(background);
   SAM_CHECK(train_ready_, "engine not initialised");
   SAM_HIP(hipSetDevice(device_));
   Batch *b = AcquireSlot(background);
@@ -739,6 +752,7 @@ bool Engine::EnqueueOne(bool background) {
 
 // block until the batch is complete, publish sizes, log the items the scripts read
 void Engine::Finish(Batch *b) {
+  if (cfg.arch == kArch0) return; // complete (and logged) when it was enqueued
   SAM_HIP(hipEventSynchronize(b->ev_done));
   const uint32_t L = (uint32_t)cfg.fanout.size();
   b->num_input = b->counts[3 * L];

@@ -61,6 +61,8 @@ struct RunConfig {
   double random_walk_restart_prob = 0.0;
   size_t num_worker = 1;
   int sampler_device = 0, trainer_device = 0;
+  bool trainer_on_host = false; // arch0 with trainer_ctx = cpu:N (host-only plumbing runs)
+  size_t omp_thread_num = 1;    // arch0: threads of the sampling / extract loops (RunConfig::omp_thread_num)
   bool use_dist_graph = false;
   double dist_graph_percentage = 0.0;
   bool part_cache = false, gpu_extract = false;
@@ -126,6 +128,7 @@ struct Batch {
   int slot = -1;
   std::atomic<int> refs{0};
   bool in_use = false;
+  bool host = false; // arch0 with a host trainer: the buffers below are host memory, complete when enqueued
   // device buffers, allocated once at their upper bounds
   std::vector<uint32_t *> row, col, data;
   uint32_t *input_nodes = nullptr, *output_nodes = nullptr;
@@ -142,6 +145,8 @@ struct Batch {
 class Engine {
  public:
   static Engine &Get();
+  Engine();
+  ~Engine();
   RunConfig cfg;
   Dataset ds;
   Profiler prof;
@@ -166,6 +171,7 @@ class Engine {
   size_t NumLocalStep() const { return num_local_step_; }
   uint64_t BatchKey(uint64_t epoch, uint64_t step) const { return epoch * num_global_step_ + step; }
   int trainer_device() const { return device_; }
+  int batch_device_type() const { return (cfg.arch == kArch0 && cfg.trainer_on_host) ? 0 : 2; } // DeviceType, common.h:48
   void Barrier();
 
  private:
@@ -181,6 +187,12 @@ class Engine {
   void Presample();
   void BuildCache();
   Batch *AcquireSlot(bool background);
+  // arch0 (cpu_engine.cc): sampler + extractor on the host cores
+  struct CpuPath;
+  std::unique_ptr<CpuPath> cpu_;
+  void CpuInit();
+  bool CpuEnqueueOne(bool background);
+  void CpuShutdown();
   void Finish(Batch *b);
 
   bool data_ready_ = false, sample_ready_ = false, train_ready_ = false, shutdown_ = false;

@@ -86,27 +86,27 @@ void samgraph_dump_trace(void) { Engine::Get().prof.DumpTrace(); }
 void samgraph_get_graph_feat(uint64_t key, samgraph_tensor_t *out) {
   auto &E = Engine::Get();
   auto *b = E.Current(key);
-  fill(out, b->feat, (int64_t)b->num_input, (int64_t)E.ds.feat_dim, 2, E.ds.feat_dtype, 2, E.trainer_device());
+  fill(out, b->feat, (int64_t)b->num_input, (int64_t)E.ds.feat_dim, 2, E.ds.feat_dtype, E.batch_device_type(), E.trainer_device());
 }
 void samgraph_get_graph_label(uint64_t key, samgraph_tensor_t *out) {
   auto &E = Engine::Get();
   auto *b = E.Current(key);
-  fill(out, b->label, (int64_t)b->num_seeds, 1, 1, GGMS_I64, 2, E.trainer_device());
+  fill(out, b->label, (int64_t)b->num_seeds, 1, 1, GGMS_I64, E.batch_device_type(), E.trainer_device());
 }
 void samgraph_get_graph_row(uint64_t key, int l, samgraph_tensor_t *out) {
   auto &E = Engine::Get();
   auto *b = E.Current(key);
-  fill(out, b->row[l], (int64_t)b->counts[3 * l], 1, 1, GGMS_I32, 2, E.trainer_device());
+  fill(out, b->row[l], (int64_t)b->counts[3 * l], 1, 1, GGMS_I32, E.batch_device_type(), E.trainer_device());
 }
 void samgraph_get_graph_col(uint64_t key, int l, samgraph_tensor_t *out) {
   auto &E = Engine::Get();
   auto *b = E.Current(key);
-  fill(out, b->col[l], (int64_t)b->counts[3 * l], 1, 1, GGMS_I32, 2, E.trainer_device());
+  fill(out, b->col[l], (int64_t)b->counts[3 * l], 1, 1, GGMS_I32, E.batch_device_type(), E.trainer_device());
 }
 void samgraph_get_graph_data(uint64_t key, int l, samgraph_tensor_t *out) {
   auto &E = Engine::Get();
   auto *b = E.Current(key);
-  fill(out, b->data[l], b->data[l] ? (int64_t)b->counts[3 * l] : 0, 1, 1, GGMS_I32, 2, E.trainer_device());
+  fill(out, b->data[l], b->data[l] ? (int64_t)b->counts[3 * l] : 0, 1, 1, GGMS_I32, E.batch_device_type(), E.trainer_device());
 }
 void samgraph_get_dataset_feat(samgraph_tensor_t *out) {
   auto &E = Engine::Get();
@@ -119,12 +119,12 @@ void samgraph_get_dataset_label(samgraph_tensor_t *out) {
 void samgraph_get_graph_input_nodes(uint64_t key, samgraph_tensor_t *out) {
   auto &E = Engine::Get();
   auto *b = E.Current(key);
-  fill(out, b->input_nodes, (int64_t)b->num_input, 1, 1, GGMS_I32, 2, E.trainer_device());
+  fill(out, b->input_nodes, (int64_t)b->num_input, 1, 1, GGMS_I32, E.batch_device_type(), E.trainer_device());
 }
 void samgraph_get_graph_output_nodes(uint64_t key, samgraph_tensor_t *out) {
   auto &E = Engine::Get();
   auto *b = E.Current(key);
-  fill(out, b->output_nodes, (int64_t)b->num_seeds, 1, 1, GGMS_I32, 2, E.trainer_device());
+  fill(out, b->output_nodes, (int64_t)b->num_seeds, 1, 1, GGMS_I32, E.batch_device_type(), E.trainer_device());
 }
 void samgraph_batch_retain(uint64_t key) { Engine::Get().Retain(key); }
 void samgraph_batch_release(uint64_t key) { Engine::Get().Release(key); }

@@ -57,8 +57,13 @@ def _wrap(t, key):
         return torch.as_tensor(_DeviceView(t, key), device=dev)
     # host memory: numpy view over the mapped dataset file (GetDatasetFeature, adapter.cc:136-152)
     shape = tuple(int(t.shape[i]) for i in range(t.ndim))
+    if n == 0 or not t.data:
+        return torch.empty(shape, dtype=_DT[t.dtype][1])
     buf = (C.c_char * (n * np.dtype(_DT[t.dtype][0]).itemsize)).from_address(t.data)
-    return torch.from_numpy(np.frombuffer(buf, dtype=_DT[t.dtype][0]).reshape(shape))
+    a = np.frombuffer(buf, dtype=_DT[t.dtype][0]).reshape(shape)
+    # a batch of the CPU deployment (arch0, host trainer) lives in a slot the engine reuses: hand out a copy;
+    # the dataset tensors (key None) stay zero-copy views of the mapped files
+    return torch.from_numpy(a.copy() if key is not None else a)
 
 
 def _get(fn, key, *args):
