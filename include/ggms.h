@@ -318,6 +318,19 @@ int ggms_extract(void *dst, const void *src, const ggms_id_t *index,
                  size_t num_index, size_t dim, int dtype,
                  ggms_stream_t stream);
 
+/* GPUMockExtract, cuda/cuda_extraction.cu:51-70,119-160 (SAMGRAPH_EMPTY_FEAT = k: the feature table is a
+ * 2^k-row stand-in, engine.cc:198-235): dst[i, :] = src[index[i] & (2^mock_bits - 1), :].
+ * ggms_gather_scatter_masked is the general form (device count, optional scatter), as the miss extract of the
+ * cache manager uses it (cuda_cache_manager_host.cc:47-48). */
+int ggms_mock_extract(void *dst, const void *src, const ggms_id_t *index,
+                      size_t num_index, size_t dim, int dtype,
+                      uint32_t mock_bits, ggms_stream_t stream);
+int ggms_gather_scatter_masked(void *out, const void *src,
+                               const ggms_id_t *src_index,
+                               const ggms_id_t *dst_index, size_t num,
+                               const uint64_t *num_dev, size_t dim, int dtype,
+                               uint32_t src_row_mask, ggms_stream_t stream);
+
 /* ---------------------------------------------------------------------------
  * Feature cache -- GPUCacheManager, cuda/cuda_cache_manager_device.cu.
  * table[node] = cache slot or kEmptyKey.
@@ -386,6 +399,8 @@ typedef struct {
   uint32_t num_part;
   uint32_t my_part;
   const void *host_feat;
+  uint32_t host_row_mask; /* 0 = none; else host row = node & mask (mock table, SAMGRAPH_EMPTY_FEAT) */
+  uint32_t _pad;
 } ggms_feature_tiers_t;
 int ggms_extract_tiered(void *out, const ggms_id_t *nodes, size_t num_nodes,
                         const uint64_t *num_nodes_dev,

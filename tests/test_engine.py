@@ -129,6 +129,58 @@ def test_arch0_gpu_trainer(tmp_path, pipelined):
     _check(np.load(prefix + ".w0.npz"), _replay_arch0(d, 64, 2, [5, 4], 7, "khop0", oracle.cpu_sample_khop0, oracle.extract), 2)
 
 
+def test_arch0_empty_feat_mock_table(tmp_path):
+    """SAMGRAPH_EMPTY_FEAT = k (engine.cc:198-235, cpu_extraction.cc:47-62): the feature table is a 2^k-row stand-in
+    and node v reads row v & (2^k - 1); ours starts as the first 2^k rows of feat.bin, so the rows can be checked."""
+    d = make_dataset(tmp_path / "ds")
+    prefix = str(tmp_path / "out")
+    r = subprocess.run([sys.executable, DRIVER, d["path"], prefix, "arch0", "1", "sample_type=khop0", "seed=7",
+                        "batch_size=64", "fanout=5 4", "trainer_ctx=cpu:0", "omp_thread_num=1", "num_epoch=1"],
+                       capture_output=True, text=True, timeout=600, env=dict(os.environ, SAMGRAPH_EMPTY_FEAT="5"))
+    assert r.returncode == 0, r.stderr[-2000:]
+    got = np.load(prefix + ".w0.npz")
+    for key in sorted({int(k.split(":")[0]) for k in got.files}):
+        inp = got[f"{key}:input_nodes"].view(np.uint32)
+        assert got[f"{key}:feat"].tobytes() == d["feat"][inp & 31].astype(np.float32).tobytes()
+
+
+@pytest.mark.gpu
+def test_arch1_debug_aids(tmp_path):
+    """SAMGRAPH_EMPTY_FEAT (GPUMockExtract), SAMGRAPH_SANITY_CHECK (per-batch checks) and the node access report on
+    the GPU engine; sampling is unaffected (same COO as the oracle replay)."""
+    d = make_dataset(tmp_path / "ds")
+    prefix = str(tmp_path / "out")
+    env = dict(os.environ, SAMGRAPH_EMPTY_FEAT="6", SAMGRAPH_SANITY_CHECK="1", SAMGRAPH_LOG_NODE_ACCESS_SIMPLE="1")
+    code = f"""
+import sys, os; sys.path.insert(0, {ROOT!r}); os.chdir({str(tmp_path)!r})
+import numpy as np, samgraph.torch as sam
+sam.config({{'dataset_path': {d['path']!r}, '_arch': 1, '_sample_type': 7, 'batch_size': 64, 'num_epoch': 2,
+  '_cache_policy': 0, 'cache_percentage': 0.0, 'max_sampling_jobs': 1, 'max_copying_jobs': 1, 'omp_thread_num': 1,
+  'num_layer': 2, 'num_hidden': 8, 'lr': 0.1, 'dropout': 0.5, 'sampler_ctx': 'cuda:0', 'trainer_ctx': 'cuda:0',
+  'num_fanout': 2, 'fanout': [5, 4], 'seed': 3}})
+sam.init()
+visits = np.zeros({d['ip'].size - 1}, np.int64)
+ok = True
+for _ in range(sam.num_epoch() * sam.num_local_step()):
+    sam.sample_once(); key = sam.get_next_batch()
+    inp = sam.get_graph_input_nodes(key).cpu().numpy().view(np.uint32)
+    feat = sam.get_graph_feat(key).cpu().numpy()
+    full = np.fromfile(os.path.join({d['path']!r}, 'feat.bin'), np.float32).reshape(-1, feat.shape[1])
+    ok = ok and feat.tobytes() == full[inp & 63].tobytes()
+    visits[inp] += 1
+sam.report_node_access()
+sam.shutdown()
+import glob
+ranked = np.fromfile(glob.glob('node_access_optimal_cache_bin*.txt')[0], np.uint32)
+freq = np.fromfile(glob.glob('node_access_optimal_cache_freq_bin*.txt')[0], np.float32)
+ok = ok and ranked.size == visits.size and np.array_equal(freq * 2, visits[ranked].astype(np.float32))
+ok = ok and (np.diff(freq) <= 0).all() and len(open(glob.glob('node_access_optimal_cache_hit*.txt')[0]).read().splitlines()) == 101
+print('aids-ok' if ok else 'aids-bad')
+"""
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and "aids-ok" in r.stdout, (r.stdout[-500:], r.stderr[-2000:])
+
+
 def test_arch0_threads_keep_the_structure(tmp_path):
     """Four sampling threads (static blocks, a generator per thread): draws differ from the one-thread run, the
     structure may not -- every seed keeps min(deg, fanout) distinct neighbours of its own list, ids are dense, rows

@@ -101,6 +101,16 @@ def test_extract(ops, dtype, dim, n):
     assert got.cpu().numpy().tobytes() == want.tobytes()
 
 
+@pytest.mark.parametrize("bits", [1, 7, 13])
+def test_mock_extract(ops, bits):
+    """GPUMockExtract (cuda_extraction.cu:51-70): rows of a 2^k-row stand-in table, index & (2^k - 1)."""
+    rng = np.random.RandomState(bits)
+    table = exact_features(1 << bits, 100, np.float32)
+    idx = rng.randint(0, 2 ** 31, 5000).astype(np.uint32)
+    got = ops.mock_extract(dev(table), dev(idx), bits)
+    assert got.cpu().numpy().tobytes() == table[idx & ((1 << bits) - 1)].tobytes()
+
+
 def test_extract_row_size_limits(ops):
     """Rows up to 8191 chunks of 16 B (131 056 B) go through the gather; wider rows are refused, not mangled."""
     rng = np.random.RandomState(4)

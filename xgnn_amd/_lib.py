@@ -30,7 +30,7 @@ class FeatureTiers(C.Structure):
     """ggms_feature_tiers_t"""
     _fields_ = [("table", C.c_void_p), ("replica", C.c_void_p), ("num_replica", C.c_uint64),
                 ("parts_dev", C.c_void_p), ("num_part", C.c_uint32), ("my_part", C.c_uint32),
-                ("host_feat", C.c_void_p)]
+                ("host_feat", C.c_void_p), ("host_row_mask", C.c_uint32), ("_pad", C.c_uint32)]
 
 
 class HashTable(C.Structure):
@@ -93,6 +93,8 @@ SYMBOLS = {
     "ggms_extract_cached": (_i, [_vp, _vp, _sz, _vp, _vp, _vp, _u32, _vp, _sz, _i, _vp, _vp]),
     "ggms_build_alias_table_host": (_i, [_vp, _vp, _sz, _vp, _vp, _vp, _i]),
     "ggms_build_prob_prefix_table_host": (_i, [_vp, _sz, _vp, _vp, _i]),
+    "ggms_mock_extract": (_i, [_vp, _vp, _vp, _sz, _sz, _i, _u32, _vp]),
+    "ggms_gather_scatter_masked": (_i, [_vp, _vp, _vp, _vp, _sz, _vp, _sz, _i, _u32, _vp]),
     "ggms_extract_tiered": (_i, [_vp, _vp, _sz, _vp, C.POINTER(FeatureTiers), _sz, _i, _vp, _vp]),
 }
 

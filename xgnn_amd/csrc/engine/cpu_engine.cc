@@ -231,10 +231,12 @@ class NodeTable {
 };
 
 // CPUExtract: out[i, :] = src[index[i], :], rows of any element type as bytes
-void Extract(Team &team, void *dst, const void *src, const uint32_t *index, size_t n, size_t row_bytes) {
+// mask: CPUMockExtract (cpu_extraction.cc:47-62), the 2^k-row stand-in table of SAMGRAPH_EMPTY_FEAT
+void Extract(Team &team, void *dst, const void *src, const uint32_t *index, size_t n, size_t row_bytes,
+             uint32_t mask = 0xffffffffu) {
   team.ParallelFor(n, [&](size_t lo, size_t hi, int) {
     for (size_t i = lo; i < hi; ++i)
-      std::memcpy((char *)dst + i * row_bytes, (const char *)src + (size_t)index[i] * row_bytes, row_bytes);
+      std::memcpy((char *)dst + i * row_bytes, (const char *)src + (size_t)(index[i] & mask) * row_bytes, row_bytes);
   });
 }
 
@@ -416,7 +418,7 @@ bool Engine::CpuEnqueueOne(bool background) {
   const size_t row_bytes = ds.feat_dim * ggms_dtype_bytes(ds.feat_dtype);
   void *feat = gpu ? (void *)S->feat.data() : b->feat;
   int64_t *label = gpu ? S->label.data() : b->label;
-  Extract(C.team, feat, ds.feat.ptr, input_nodes, b->num_input, row_bytes);
+  Extract(C.team, feat, ds.feat.ptr, input_nodes, b->num_input, row_bytes, ds.feat_mask);
   Extract(C.team, label, ds.label.ptr, seeds, num_seeds, 8);
   if (gpu) {
     SAM_HIP(hipSetDevice(device_));

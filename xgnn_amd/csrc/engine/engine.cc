@@ -194,7 +194,26 @@ void Engine::LoadDataset() {
   if (const char *e = getenv("SAMGRAPH_FAKE_FEAT_DIM")) fake_dim = std::strtoull(e, nullptr, 10);
   if (fake_dim) ds.feat_dim = fake_dim;
   const size_t row_bytes = ds.feat_dim * ggms_dtype_bytes(ds.feat_dtype);
-  if (!fake_dim && file_exists(cfg.dataset_path + "feat.bin")) {
+  ds.feat_rows = ds.num_node;
+  size_t empty_bits = 0; // SAMGRAPH_EMPTY_FEAT = k (run_config.cc:137-139, engine.cc:205-207): a 2^k-row stand-in table,
+                         // node v reads row v & (2^k - 1) (gpu_mock_extract / cpu_mock_extract)
+  if (const char *e = getenv("SAMGRAPH_EMPTY_FEAT")) empty_bits = std::strtoull(e, nullptr, 10);
+  if (empty_bits) {
+    SAM_CHECK(empty_bits < 32, "SAMGRAPH_EMPTY_FEAT out of range");
+    ds.feat_rows = (size_t)1 << empty_bits;
+    ds.feat_mask = (uint32_t)(ds.feat_rows - 1);
+    ds.feat.bytes = ds.feat_rows * row_bytes;
+    ds.feat.ptr = mmap(nullptr, ds.feat.bytes, PROT_READ | PROT_WRITE, MAP_SHARED | MAP_ANONYMOUS, -1, 0);
+    SAM_CHECK(ds.feat.ptr != MAP_FAILED, "feature mmap failed");
+    ds.feat.shared_anon = true;
+    ds.feat_is_fake = true;
+    // the reference leaves the stand-in uninitialised; ours starts as the first 2^k rows of feat.bin where that file
+    // exists (any content is as valid, and this one can be checked), zeros otherwise
+    if (!fake_dim && file_exists(cfg.dataset_path + "feat.bin")) {
+      HostArray f = MapFile("feat.bin", std::min(ds.feat_rows, ds.num_node) * row_bytes, false);
+      std::memcpy(ds.feat.ptr, f.ptr, f.bytes);
+    }
+  } else if (!fake_dim && file_exists(cfg.dataset_path + "feat.bin")) {
     ds.feat = MapFile("feat.bin", ds.num_node * row_bytes, share);
   } else { // engine.cc:199-235: datasets without feat.bin get an (uninitialised) table; ours is zero-filled
     ds.feat.bytes = ds.num_node * row_bytes;
@@ -302,6 +321,18 @@ void Engine::Reshuffle() {
   SAM_HIP(hipStreamSynchronize(stream_));
 }
 
+// SAMGRAPH_SANITY_CHECK (cuda_shuffler.cc:147-154): no invalid id in the batch (GPUSanityCheckList) and no train node
+// handed out twice within an epoch (GPUBatchSanityCheck).  The shuffled train set has a host copy, so the check
+// runs there; a violation is fatal, as the device-side asserts of the reference are.
+void Engine::SanityCheckBatch(const uint32_t *seeds, size_t n) {
+  if (cur_step_ == 0) sanity_seen_.assign(ds.num_node, false);
+  for (size_t i = 0; i < n; ++i) {
+    SAM_CHECK(seeds[i] != GGMS_EMPTY_KEY && seeds[i] < ds.num_node, "sanity check: invalid node id in a batch");
+    SAM_CHECK(!sanity_seen_[seeds[i]], "sanity check: a train node was handed out twice in one epoch");
+    sanity_seen_[seeds[i]] = true;
+  }
+}
+
 bool Engine::ShufflerNext(Batch *b, hipStream_t copy_stream) {
   cur_step_++;
   if (cur_step_ >= num_local_step_) Reshuffle();
@@ -315,6 +346,8 @@ bool Engine::ShufflerNext(Batch *b, hipStream_t copy_stream) {
   }
   b->num_seeds = size;
   b->key = BatchKey(cur_epoch_, global_step_offset_ + cur_step_);
+  static const bool sanity = getenv("SAMGRAPH_SANITY_CHECK") != nullptr; // run_config.cc:126-128
+  if (sanity && cfg.arch == kArch1) SanityCheckBatch(shuf_host_.data() + global_data_offset_ + offset, size);
   SAM_HIP(hipMemcpyAsync(b->output_nodes, shuf_dev_ + offset, size * 4, hipMemcpyDeviceToDevice, copy_stream)); // Copy1D
   return true;
 }
@@ -572,7 +605,8 @@ void Engine::BuildCache() {
   const size_t my_rows = num_cached_nodes_ / P + (p < num_cached_nodes_ % P ? 1 : 0);
   std::vector<char> tmp(std::max<size_t>(my_rows * row_bytes, 16));
   size_t c = 0;
-  for (size_t i = p; i < num_cached_nodes_; i += P, ++c) std::memcpy(&tmp[c * row_bytes], feat + (size_t)rank[i] * row_bytes, row_bytes);
+  for (size_t i = p; i < num_cached_nodes_; i += P, ++c)
+    std::memcpy(&tmp[c * row_bytes], feat + (size_t)(rank[i] & ds.feat_mask) * row_bytes, row_bytes);
   cache_parts_.assign(P, nullptr);
   cache_parts_[p] = dev_upload(tmp.data(), my_rows * row_bytes, stream_);
   SAM_HIP(hipStreamSynchronize(stream_));
@@ -598,6 +632,10 @@ void Engine::TrainInit(int worker_id, const std::string &ctx) {
   auto t0 = std::chrono::steady_clock::now();
   BuildCache();
   prof.LogInit(/*kLogInitL2BuildCache*/ 10, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+  if (getenv("SAMGRAPH_LOG_NODE_ACCESS") || getenv("SAMGRAPH_LOG_NODE_ACCESS_SIMPLE")) { // run_config.cc:118-124
+    SAM_HIP(hipMalloc((void **)&node_access_dev_, ds.num_node * 4));
+    SAM_HIP(hipMemset(node_access_dev_, 0, ds.num_node * 4));
+  }
   // batch slots (GraphPool(max_copying_jobs), cuda_engine.cc:151): buffers sized once at their bounds
   const uint32_t L = (uint32_t)cfg.fanout.size();
   const size_t row_bytes = ds.feat_dim * ggms_dtype_bytes(ds.feat_dtype);
@@ -728,16 +766,31 @@ bool Engine::EnqueueOne(bool background) {
   // extract overlaps batch k+1's sampling (the reference serialises them, dist_loops_arch6.cc:248-251)
   hipStream_t xs = stream_extract_;
   SAM_HIP(hipStreamWaitEvent(xs, b->ev_sampled, 0));
-  if (cfg.UseGPUCache()) {
+  const bool mock = ds.feat_mask != 0xffffffffu; // SAMGRAPH_EMPTY_FEAT: host rows are node & mask
+  if (cfg.UseGPUCache() && mock) {
+    ggms_feature_tiers_t tiers{};
+    tiers.table = cache_table_;
+    tiers.parts_dev = (const void *const *)d_cache_parts_tab_;
+    tiers.num_part = std::max<uint32_t>(1, num_cache_part_);
+    tiers.my_part = cfg.part_cache ? (uint32_t)worker_id_ : 0;
+    tiers.host_feat = feat_src_;
+    tiers.host_row_mask = ds.feat_mask;
+    SAM_GGMS(ggms_extract_tiered(b->feat, b->input_nodes, max_unique_, n_in, &tiers, ds.feat_dim, ds.feat_dtype, n_miss, xs));
+  } else if (cfg.UseGPUCache()) {
     // DoArch6GetCacheMissIndex + DoArch6GPUCacheFeatureCopy (dist_loops.cc:1015-1285) in one pass
     SAM_GGMS(ggms_extract_cached(b->feat, b->input_nodes, max_unique_, n_in, cache_table_,
                                  (const void *const *)d_cache_parts_tab_, num_cache_part_, feat_src_, ds.feat_dim,
                                  ds.feat_dtype, n_miss, xs));
+  } else if (mock) { // GPUMockExtract, cuda_loops.cc:692-700 / dist_loops.cc:608-616
+    SAM_GGMS(ggms_gather_scatter_masked(b->feat, feat_src_, b->input_nodes, nullptr, max_unique_, n_in, ds.feat_dim,
+                                        ds.feat_dtype, ds.feat_mask, xs));
   } else {
     // DoGPUFeatureExtract (cuda/cuda_loops.cc, dist_loops.cc:585-634)
     SAM_GGMS(ggms_gather_scatter(b->feat, feat_src_, b->input_nodes, nullptr, max_unique_, n_in, ds.feat_dim,
                                  ds.feat_dtype, xs));
   }
+  if (node_access_dev_) // Profiler::LogNodeAccess (profiler.cc:570-575): visits per node, counted on the device
+    SAM_GGMS(ggms_count_nodes(node_access_dev_, b->input_nodes, max_unique_, n_in, xs));
   // DoGPULabelExtract, dist_loops.cc:938-974
   SAM_GGMS(ggms_extract(b->label, label_src_, b->output_nodes, b->num_seeds, 1, GGMS_I64, xs));
   SAM_HIP(hipMemcpyAsync(b->counts, b->counts_dev, (3 * L + 4) * 8, hipMemcpyDeviceToHost, xs));
@@ -821,6 +874,43 @@ void Engine::ExtractStart(int count) { // dist_engine.cc StartExtract: one backg
       if (cur_epoch_ >= cfg.num_epoch) break;
     }
   });
+}
+
+// samgraph_report_node_access, the _SIMPLE report (profiler.cc:795-860): nodes by visit count, descending --
+//   node_access_optimal_cache_bin<t>.txt       u32 node ids in that order (usable as a cache rank file)
+//   node_access_optimal_cache_freq_bin<t>.txt  f32 visits per epoch, same order
+//   node_access_frequency<t>.txt               "rate\tvisits per epoch of the node at that percentile"
+//   node_access_optimal_cache_hit<t>.txt       "rate\thit rate of a cache holding the top rate % of the nodes"
+void Engine::ReportNodeAccess() {
+  if (!node_access_dev_) return;
+  SAM_HIP(hipDeviceSynchronize());
+  std::vector<uint32_t> freq(ds.num_node);
+  SAM_HIP(hipMemcpy(freq.data(), node_access_dev_, ds.num_node * 4, hipMemcpyDeviceToHost));
+  std::vector<std::pair<uint64_t, uint32_t>> rec(ds.num_node);
+  for (uint32_t v = 0; v < ds.num_node; ++v) rec[v] = {freq[v], v};
+  std::sort(rec.begin(), rec.end(), std::greater<std::pair<uint64_t, uint32_t>>());
+  const std::string t = std::to_string((unsigned long long)std::chrono::system_clock::now().time_since_epoch().count());
+  FILE *f_freq = fopen(("node_access_frequency" + t + ".txt").c_str(), "w");
+  FILE *f_bin = fopen(("node_access_optimal_cache_bin" + t + ".txt").c_str(), "wb");
+  FILE *f_hit = fopen(("node_access_optimal_cache_hit" + t + ".txt").c_str(), "w");
+  FILE *f_fbin = fopen(("node_access_optimal_cache_freq_bin" + t + ".txt").c_str(), "wb");
+  SAM_CHECK(f_freq && f_bin && f_hit && f_fbin, "cannot write the node access files");
+  const double epochs = (double)std::max<size_t>(1, cfg.num_epoch);
+  uint64_t sum = 0;
+  for (auto &p : rec) {
+    const float avg = (float)(p.first / epochs);
+    fwrite(&p.second, 4, 1, f_bin);
+    fwrite(&avg, 4, 1, f_fbin);
+    sum += p.first;
+    p.first = sum; // running sum, as the reference keeps it
+  }
+  const size_t n = rec.size();
+  for (int rate = 0; rate <= 100; ++rate) {
+    size_t idx = rate == 0 ? 0 : ((uint64_t)rate * n - 1) / 100;
+    fprintf(f_freq, "%d\t%g\n", rate, idx == 0 ? 0.0 : (double)(rec[idx].first - rec[idx - 1].first) / epochs);
+    fprintf(f_hit, "%d\t%g\n", rate, idx == 0 || sum == 0 ? 0.0 : (double)rec[idx].first / (double)sum);
+  }
+  fclose(f_freq); fclose(f_bin); fclose(f_hit); fclose(f_fbin);
 }
 
 Batch *Engine::Current(uint64_t key) {

@@ -92,6 +92,9 @@ struct Dataset {
   size_t num_train = 0, num_valid = 0, num_test = 0;
   HostArray indptr, indices, feat, label, train_set, valid_set, test_set, ranking_nodes, prob_table, alias_table;
   bool feat_is_fake = false;
+  // SAMGRAPH_EMPTY_FEAT = k (engine.cc:198-235): the feature table is a 2^k-row stand-in, row of node v = v & mask
+  uint32_t feat_mask = 0xffffffffu;
+  size_t feat_rows = 0; // rows of ds.feat (num_node, or 2^k)
 };
 
 // ---- Profiler log store: profiler.h:166-215 ------------------------------------
@@ -187,6 +190,12 @@ class Engine {
   void Presample();
   void BuildCache();
   Batch *AcquireSlot(bool background);
+  void SanityCheckBatch(const uint32_t *seeds, size_t n); // SAMGRAPH_SANITY_CHECK
+  std::vector<bool> sanity_seen_;
+  uint32_t *node_access_dev_ = nullptr; // SAMGRAPH_LOG_NODE_ACCESS[_SIMPLE]: visits per node (input nodes of every batch)
+ public:
+  void ReportNodeAccess();
+ private:
   // arch0 (cpu_engine.cc): sampler + extractor on the host cores
   struct CpuPath;
   std::unique_ptr<CpuPath> cpu_;

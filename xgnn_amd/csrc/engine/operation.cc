@@ -75,7 +75,7 @@ void samgraph_report_step(uint64_t e, uint64_t s) { Engine::Get().prof.ReportSte
 void samgraph_report_step_average(uint64_t e, uint64_t s) { Engine::Get().prof.ReportStep(e, s); std::fflush(stdout); }
 void samgraph_report_epoch(uint64_t e) { Engine::Get().prof.ReportEpoch(e); }
 void samgraph_report_epoch_average(uint64_t e) { Engine::Get().prof.ReportEpoch(e); std::fflush(stdout); }
-void samgraph_report_node_access(void) {}
+void samgraph_report_node_access(void) { Engine::Get().ReportNodeAccess(); } // operation.cc:472-480
 void samgraph_trace_step_begin(uint64_t key, int item, uint64_t ts) { Engine::Get().prof.Trace(key, item, ts, true); }
 void samgraph_trace_step_end(uint64_t key, int item, uint64_t ts) { Engine::Get().prof.Trace(key, item, ts, false); }
 void samgraph_trace_step_begin_now(uint64_t key, int item) { Engine::Get().prof.Trace(key, item, now_us(), true); }
@@ -110,7 +110,7 @@ void samgraph_get_graph_data(uint64_t key, int l, samgraph_tensor_t *out) {
 }
 void samgraph_get_dataset_feat(samgraph_tensor_t *out) {
   auto &E = Engine::Get();
-  fill(out, E.ds.feat.ptr, (int64_t)E.ds.num_node, (int64_t)E.ds.feat_dim, 2, E.ds.feat_dtype, 0, 0);
+  fill(out, E.ds.feat.ptr, (int64_t)E.ds.feat_rows, (int64_t)E.ds.feat_dim, 2, E.ds.feat_dtype, 0, 0);
 }
 void samgraph_get_dataset_label(samgraph_tensor_t *out) {
   auto &E = Engine::Get();

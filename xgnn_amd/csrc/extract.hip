@@ -42,10 +42,11 @@ struct PlainRows {
   const char *base;
   const uint32_t *index;
   uint64_t row_bytes;
+  uint32_t mask = 0xffffffffu; // gpu_mock_extract (cuda_extraction.cu:51-70): rows of a 2^k-row mock table, index & mask
   static constexpr bool kTiers = false;
   __device__ __forceinline__ const char *row(uint64_t i, uint32_t &tier) const {
     tier = 0;
-    const uint64_t s = index ? (uint64_t)index[i] : i;
+    const uint64_t s = index ? (uint64_t)(index[i] & mask) : i;
     return base + s * row_bytes;
   }
 };
@@ -101,13 +102,14 @@ struct TieredRows {
   uint32_t num_replica;
   uint32_t num_part; // >= 1
   uint32_t my_part;
+  uint32_t host_mask; // host tier row = node & host_mask (mock table of SAMGRAPH_EMPTY_FEAT; else all ones)
   static constexpr bool kTiers = true;
   __device__ __forceinline__ const char *row(uint64_t i, uint32_t &tier) const {
     const uint32_t node = nodes[i];
     const uint32_t slot = table ? table[node] : node;
     if (slot == kEmptyKey) {
       tier = kTierHost;
-      return host + (uint64_t)node * row_bytes;
+      return host + (uint64_t)(node & host_mask) * row_bytes;
     }
     if (slot < num_replica) {
       tier = kTierReplica;
@@ -351,6 +353,30 @@ int ggms_gather_scatter(void *out, const void *src, const ggms_id_t *src_index, 
                        to_stream(stream));
 }
 
+// ggms_gather_scatter with the source row taken as src_index[i] & src_row_mask: gpu_mock_extract
+// (cuda_extraction.cu:51-70) and the mock-table forms of the miss extract (cuda_cache_manager_host.cc:47-48)
+int ggms_gather_scatter_masked(void *out, const void *src, const ggms_id_t *src_index, const ggms_id_t *dst_index,
+                               size_t num, const uint64_t *num_dev, size_t dim, int dtype, uint32_t src_row_mask,
+                               ggms_stream_t stream) {
+  const size_t es = ggms_dtype_bytes(dtype);
+  GGMS_CHECK_ARG(es != 0 && dim != 0);
+  if (num == 0) return GGMS_OK;
+  GGMS_CHECK_ARG(out && src && src_index);
+  const size_t row_bytes = dim * es;
+  const int cb = pick_chunk(row_bytes, (uintptr_t)out | (uintptr_t)src);
+  PlainRows rows{(const char *)src, src_index, row_bytes, src_row_mask};
+  return launch_gather((char *)out, rows, dst_index, num, count_of(num, num_dev), row_bytes, cb, nullptr,
+                       to_stream(stream));
+}
+
+// GPUMockExtract (cuda_extraction.cu:119-160): dst[i, :] = src[index[i] & (2^mock_bits - 1), :]
+int ggms_mock_extract(void *dst, const void *src, const ggms_id_t *index, size_t num_index, size_t dim, int dtype,
+                      uint32_t mock_bits, ggms_stream_t stream) {
+  GGMS_CHECK_ARG(mock_bits >= 1 && mock_bits <= 32);
+  const uint32_t mask = mock_bits == 32 ? 0xffffffffu : ((1u << mock_bits) - 1u);
+  return ggms_gather_scatter_masked(dst, src, index, nullptr, num_index, nullptr, dim, dtype, mask, stream);
+}
+
 int ggms_gather_scatter_partition(void *out, const void *const *parts_dev, uint32_t num_part,
                                   const ggms_id_t *src_index, const ggms_id_t *dst_index, size_t num,
                                   const uint64_t *num_dev, size_t dim, int dtype, ggms_stream_t stream) {
@@ -400,7 +426,7 @@ int ggms_extract_tiered(void *out, const ggms_id_t *nodes, size_t num_nodes, con
   const int cb = pick_chunk(row_bytes, (uintptr_t)out | (uintptr_t)tiers->host_feat | (uintptr_t)tiers->replica);
   TieredRows rows{(const char *const *)tiers->parts_dev, nodes, tiers->table, (const char *)tiers->host_feat,
                   (const char *)tiers->replica, row_bytes, (uint32_t)tiers->num_replica, tiers->num_part,
-                  tiers->my_part};
+                  tiers->my_part, tiers->host_row_mask ? tiers->host_row_mask : 0xffffffffu};
   return launch_gather((char *)out, rows, nullptr, num_nodes, count_of(num_nodes, num_nodes_dev), row_bytes, cb,
                        tier_rows_dev, to_stream(stream));
 }

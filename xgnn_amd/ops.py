@@ -281,6 +281,18 @@ def extract(src, index, out=None):
     return out
 
 
+def mock_extract(src, index, mock_bits, out=None):
+    """GPUMockExtract (cuda_extraction.cu:119-160): out[i, :] = src[index[i] & (2**mock_bits - 1), :]."""
+    _require_gpu(index)
+    _i32(index)
+    n = index.numel()
+    if out is None:
+        out = torch.empty((n,) + tuple(src.shape[1:]), dtype=src.dtype, device=index.device)
+    check(lib().ggms_mock_extract(_ptr(out), _ptr(src), _ptr(index), n, _dim_of(src), DTYPE_CODE[src.dtype], mock_bits,
+                                  _stream()), "ggms_mock_extract")
+    return out
+
+
 def get_miss_cache_index(table, nodes):
     """GetMissCacheIndex (cuda_cache_manager_device.cu:355-441).  Counts stay on the device."""
     _require_gpu(nodes)
