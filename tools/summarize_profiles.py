@@ -42,10 +42,17 @@ def main():
 
     # ---- timeline: per-kernel durations + queue gaps over the region that holds the ggms launches
     tr = list(csv.DictReader(open(one(f"{src}/trace/*/*_kernel_trace.csv"))))
+    # the main timed region ends where the host-tier sub-record starts: its gather (PlainRows, 16-byte chunks) reads
+    # pinned host memory and takes milliseconds -- keep the timeline to what happens before the first such launch
+    host_tier = [int(r["Start_Timestamp"]) for r in tr if "k_gather_rows<16, ggms::PlainRows" in r["Kernel_Name"]
+                 and int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) > 2_000_000]
+    t_end = min(host_tier) if host_tier else None
     per = collections.OrderedDict()
     queues = collections.defaultdict(list)
     for r in tr:
         if "ggms" not in r["Kernel_Name"]:
+            continue
+        if t_end is not None and int(r["Start_Timestamp"]) >= t_end:
             continue
         s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
         per.setdefault(r["Kernel_Name"], []).append((e - s) / 1e3)
