@@ -753,14 +753,17 @@ bool Engine::EnqueueOne(bool background) {
     extra.rng_done = P.rng_done;
     last_rng_done_ = P.rng_done;
   }
-  SAM_GGMS(ggms_sample_batch(cfg.sample_type, &graph_, b->output_nodes, b->num_seeds, cfg.fanout.data(), L, &P.ht,
+  // input nodes = the table's unique list (task->input_nodes, dist_loops.cc:357).  The table struct is plain data and
+  // its n2o buffer the caller's: the batch builds the list directly in its slot (a later batch uses another slot)
+  ggms_hashtable_t ht = P.ht;
+  ht.n2o = b->input_nodes;
+  ht.n2o_size = max_unique_;
+  SAM_GGMS(ggms_sample_batch(cfg.sample_type, &graph_, b->output_nodes, b->num_seeds, cfg.fanout.data(), L, &ht,
                              states_, num_states_, b->row.data(), b->col.data(), b->counts_dev, &extra, P.ws, ws_bytes_,
                              ss));
+  P.ht.version = ht.version; // the batch bumped the table's version stamp
   uint64_t *n_in = b->counts_dev + 3 * L, *n_miss = b->counts_dev + 3 * L + 2; // [3L + 1] = the batch's status word
   SAM_HIP(hipMemsetAsync(n_miss, 0, 8, ss));
-  // input nodes = the table's unique list (task->input_nodes, dist_loops.cc:357); a later batch's sampling
-  // overwrites it, so the slot keeps its own copy and the gather below reads that copy
-  SAM_GGMS(ggms_gather_scatter(b->input_nodes, P.ht.n2o, nullptr, nullptr, max_unique_, n_in, 1, GGMS_I32, ss));
   SAM_HIP(hipEventRecord(b->ev_sampled, ss));
   // The gather is HBM-bound, the sampler latency-bound: they run on separate streams so that batch k's
   // extract overlaps batch k+1's sampling (the reference serialises them, dist_loops_arch6.cc:248-251)
