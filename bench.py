@@ -184,11 +184,21 @@ def main():
 
     from xgnn_amd import datagen, ggms_store, ops, parallel
 
+    t_start = time.perf_counter()
+    if os.environ.get("GGMS_BENCH_VERBOSE"):  # where is a stuck rank?  Python stacks every 2 minutes
+        import faulthandler
+        faulthandler.dump_traceback_later(120, repeat=True, file=sys.stderr)
+
+    def log(msg):  # GGMS_BENCH_VERBOSE=1: phase marks on stderr (which phase a slow or stuck run is in)
+        if os.environ.get("GGMS_BENCH_VERBOSE"):
+            print(f"[bench r{rank} +{time.perf_counter() - t_start:7.1f}s] {msg}", file=sys.stderr, flush=True)
+
     if args.fanout is None:
         args.fanout = "25,10" if args.preset in ("products", "tiny") else "5,10,15"
     fanouts = [int(x) for x in args.fanout.split(",")]
     main_store = (args.store or "peer") if world > 1 else "local"
     graph = datagen.make_graph(args.preset, seed=42)
+    log("graph generated")
     meta = graph["meta"]
     N, dim = meta["num_node"], meta["feat_dim"]
     row_bytes = dim * 4
@@ -222,6 +232,7 @@ def main():
 
     def build_store(kind):
         """-> (extract(nodes, num_max, out, num_dev, counters), what it keeps alive) for one store kind."""
+        log(f"building store {kind}")
         keep = {}
         if kind in ("local", "replica"):
             if full:
@@ -257,8 +268,10 @@ def main():
                                               dev, shared=(kind != "a2a"))
         st = ggms_store.FeatureShards(shard, table, world, rank, mode="a2a" if kind == "a2a" else "peer", dist=dist,
                                       host_feat=host_feat, replica=replica)
+        log(f"store {kind}: shard filled")
         if kind != "a2a":
             st.connect_peers(holder)
+        log(f"store {kind}: peers connected")
         keep.update(store=st, holder=holder, table=table, replica=replica)
 
         def extract(nodes, num_max, out, num_dev, counters):
@@ -359,8 +372,11 @@ def main():
         counters = torch.zeros(4, dtype=torch.int64, device=dev)
         acc = torch.zeros(3 * L + 2, dtype=torch.int64, device=dev)
         run_step = make_step(extract_fn, counters, acc, lambda s: seeds_all[s])
+        log(f"measure: {warmup} warm-up + {repeats} x {steps} steps")
         for s in range(warmup):
             run_step(s)
+        barrier()
+        log("warm-up done")
         blocks = []
         for r in range(repeats):
             ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(steps)]
@@ -399,6 +415,7 @@ def main():
     repeats = max(1, args.repeats)
     extract_main, keep_main = build_store(main_store)
     blocks, next_step = measure(extract_main, args.steps, args.warmup, repeats)
+    log("main region done")
     blk = median_block(blocks)
     elapsed, edges_all = blk["elapsed"], blk["edges_all"]
     edges, rows = blk["edges"], blk["rows"]

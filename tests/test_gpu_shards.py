@@ -100,3 +100,46 @@ def test_two_processes_one_gpu(mode):
         p.join(timeout=120)
         assert p.exitcode == 0
     assert res == [(0, True), (1, True)]
+
+
+def _big_shard_worker(rank, world, port, q):
+    from xgnn_amd import ops
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    rows = 3000 * (1 << 20) // 512  # 3000 MiB: bit 31 of the byte size is set
+    sh = ops.SharedShard((rows, 128), torch.float32, torch.device("cuda", 0))
+    sh.tensor[:4] = float(rank + 1)
+    sh.tensor[-4:] = float(10 * (rank + 1))
+    torch.cuda.synchronize()
+    handles = [None] * world
+    dist.all_gather_object(handles, sh.export_handle())
+    p = sh.import_peer(handles[1 - rank])
+    peer = torch.as_tensor(ops._RawDevice(p, (rows, 128), "<f4"), device="cuda:0")
+    ok = float(peer[0, 0].item()) == float(2 - rank) and float(peer[-1, -1].item()) == float(10 * (2 - rank))
+    dist.barrier()
+    q.put((rank, ok))
+    dist.barrier()
+    sh.close()
+    dist.destroy_process_group()
+
+
+def test_shard_size_with_bit31_set_can_be_opened():
+    """ROCm 7.2: hipIpcOpenMemHandle never returns for an allocation whose byte size has bit 31 set (3000 MiB, 7.1 GB,
+    28.4 GB -- the papers100M shards at 8 and 2 GPUs); ggms_device_alloc sizes shards around that (include/ggms.h
+    ggms_ipc_safe_bytes).  Would hang (and time out) without it."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_big_shard_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    try:
+        res = sorted(q.get(timeout=120) for _ in range(world))
+    finally:
+        for p in procs:
+            p.join(timeout=30)
+            if p.is_alive():
+                p.kill()
+    assert res == [(0, True), (1, True)]

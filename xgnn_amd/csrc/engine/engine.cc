@@ -355,7 +355,8 @@ bool Engine::ShufflerNext(Batch *b, hipStream_t copy_stream) {
 // ------------------------------------------------------------------ device graph (GGMS topology)
 static void *dev_upload(const void *host, size_t bytes, hipStream_t s) {
   void *d = nullptr;
-  SAM_HIP(hipMalloc(&d, std::max<size_t>(bytes, 16)));
+  // shards are published to the other workers with hipIpc: sized so that a peer can open them (include/ggms.h)
+  SAM_HIP(hipMalloc(&d, ggms_ipc_safe_bytes(std::max<size_t>(bytes, 16))));
   if (bytes) SAM_HIP(hipMemcpyAsync(d, host, bytes, hipMemcpyHostToDevice, s));
   return d;
 }

@@ -94,6 +94,10 @@ class FeatureShards:
         """Exchange hipIpc handles (all_gather of 64-byte blobs) and build the device pointer table."""
         assert self.mode == "peer"
         self._shared = shared_shard
+        # the shard must be COMPLETE before a peer may read it: drain this device's queue before publishing (the
+        # fill kernels are asynchronous), and meet the peers again once everybody has mapped everybody (below)
+        if shared_shard.tensor.is_cuda:
+            torch.cuda.synchronize(shared_shard.tensor.device)
         mine = shared_shard.export_handle()
         if self.world == 1:
             handles = [mine]
@@ -102,6 +106,8 @@ class FeatureShards:
             self.dist.all_gather_object(handles, mine, group=self.group)
         ptrs = [shared_shard.ptr if r == self.rank else shared_shard.import_peer(handles[r]) for r in range(self.world)]
         self.parts_table = torch.tensor(ptrs, dtype=torch.int64, device=self.shard.device)
+        if self.world > 1:
+            self.dist.barrier(group=self.group)
         return self
 
     # ---- one batch ----------------------------------------------------------------------------------
