@@ -422,9 +422,7 @@ int ggms_extract_tiered(void *out, const ggms_id_t *nodes, size_t num_nodes,
  * (tools/ipc_probe3.py): hipIpcOpenMemHandle never returns when the exporter's allocation size has bit 31 set
  * (size mod 2^32 >= 2^31: 3000 MiB, 12000 MiB, 20000 MiB, 28000 MiB hang; 1500, 6000, 17408, 20480, 28672 MiB
  * open in a millisecond).  Such sizes are rounded up to the next multiple of 4 GiB; ggms_device_alloc applies it. */
-static inline size_t ggms_ipc_safe_bytes(size_t bytes) {
-  return (bytes & 0x80000000ull) ? ((bytes | 0xffffffffull) + 1ull) : bytes;
-}
+size_t ggms_ipc_safe_bytes(size_t bytes); /* host arithmetic only */
 int ggms_device_alloc(void **ptr, size_t bytes);
 int ggms_device_free(void *ptr);
 int ggms_ipc_export(const void *ptr, void *handle);

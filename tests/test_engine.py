@@ -329,6 +329,10 @@ def test_arch1_feature_dtypes(tmp_path, dtype):
     dict(cache_percentage="0.4", part_cache="True", gpu_extract="True", use_dist_graph="1.0"),
     dict(cache_percentage="0.25", gpu_extract="True", use_dist_graph="0.5"),
     dict(cache_percentage="0", gpu_extract="True"),
+    # `gpu_extract` off = the reference's SGNN mode: miss rows gathered by the host threads into pinned memory and
+    # copied down asynchronously (dist_loops.cc:1076-1207), hits from the (partitioned) cache
+    dict(cache_percentage="0.3"),
+    dict(cache_percentage="0.3", part_cache="True", use_dist_graph="1.0"),
 ])
 def test_arch6_two_workers_one_gpu(tmp_path, opts):
     """XGNN mode: topology shards + partitioned feature cache shared through hipIpc, two forked workers

@@ -95,6 +95,7 @@ SYMBOLS = {
     "ggms_build_prob_prefix_table_host": (_i, [_vp, _sz, _vp, _vp, _i]),
     "ggms_mock_extract": (_i, [_vp, _vp, _vp, _sz, _sz, _i, _u32, _vp]),
     "ggms_gather_scatter_masked": (_i, [_vp, _vp, _vp, _vp, _sz, _vp, _sz, _i, _u32, _vp]),
+    "ggms_ipc_safe_bytes": (_sz, [_sz]),
     "ggms_extract_tiered": (_i, [_vp, _vp, _sz, _vp, C.POINTER(FeatureTiers), _sz, _i, _vp, _vp]),
 }
 

@@ -172,6 +172,10 @@ int ggms_owner_bucket(const ggms_id_t *slots, const ggms_id_t *nodes, size_t num
 }
 
 // ---- shards across processes: cuda/dist_graph.cu:228-272 ----
+size_t ggms_ipc_safe_bytes(size_t bytes) {
+  return (bytes & 0x80000000ull) ? ((bytes | 0xffffffffull) + 1ull) : bytes;
+}
+
 int ggms_device_alloc(void **ptr, size_t bytes) {
   GGMS_CHECK_ARG(ptr && bytes > 0);
   GGMS_HIP(hipMalloc(ptr, ggms_ipc_safe_bytes(bytes))); // a size the peers can open (include/ggms.h)

@@ -1,6 +1,7 @@
 // engine.cc -- host orchestration (see engine.h).  Citations are relative to
 // /root/reference/samgraph/common/.
 #include "engine.h"
+#include "team.h"
 
 #include <fcntl.h>
 #include <pthread.h>
@@ -658,6 +659,13 @@ void Engine::TrainInit(int worker_id, const std::string &ctx) {
     SAM_HIP(hipMalloc((void **)&b->label, max_seeds_ * 8));
     SAM_HIP(hipMalloc((void **)&b->counts_dev, (3 * L + 4) * 8));
     SAM_HIP(hipMemset(b->counts_dev, 0, (3 * L + 4) * 8));
+    if (StagedHostTier()) { // index arrays of GetMissCacheIndex + pinned / device staging of the miss rows
+      for (uint32_t **p : {&b->miss_src, &b->miss_dst, &b->hit_src, &b->hit_dst}) SAM_HIP(hipMalloc((void **)p, max_unique_ * 4));
+      SAM_HIP(hipMalloc(&b->idx_ws, ggms_cache_index_workspace_bytes(max_unique_)));
+      SAM_HIP(hipMalloc(&b->miss_rows_dev, max_unique_ * row_bytes));
+      SAM_HIP(hipHostMalloc(&b->miss_rows_host, max_unique_ * row_bytes));
+      SAM_HIP(hipHostMalloc((void **)&b->miss_ids_host, max_unique_ * 4));
+    }
     SAM_HIP(hipHostMalloc((void **)&b->counts, (3 * L + 4) * 8));
     std::memset(b->counts, 0, (3 * L + 4) * 8);
     SAM_HIP(hipEventCreateWithFlags(&b->ev_seeds, hipEventDisableTiming));
@@ -771,7 +779,9 @@ bool Engine::EnqueueOne(bool background) {
   hipStream_t xs = stream_extract_;
   SAM_HIP(hipStreamWaitEvent(xs, b->ev_sampled, 0));
   const bool mock = ds.feat_mask != 0xffffffffu; // SAMGRAPH_EMPTY_FEAT: host rows are node & mask
-  if (cfg.UseGPUCache() && mock) {
+  if (StagedHostTier()) {
+    StagedExtract(b, xs);
+  } else if (cfg.UseGPUCache() && mock) {
     ggms_feature_tiers_t tiers{};
     tiers.table = cache_table_;
     tiers.parts_dev = (const void *const *)d_cache_parts_tab_;
@@ -805,6 +815,52 @@ bool Engine::EnqueueOne(bool background) {
   }
   pool_cv_.notify_all();
   return true;
+}
+
+// arch6 without `gpu_extract` (the reference's SGNN mode): DoArch6GetCacheMissIndex + DoCacheIdCopyToCPU +
+// DoArch6CacheFeatureCopy (dist_loops.cc:1015-1207) -- split the input nodes into hits and misses on the GPU, bring
+// the miss ids to the host, gather their rows with the host threads into PINNED memory (hipHostMalloc), send them
+// down with ONE asynchronous copy, scatter them (combine_miss_data) and gather the hits from the cache shards
+// (combine_cache_data[_for_partition]).  Two short host waits per batch (counts, miss ids), as in the reference;
+// the zero-copy gather (`gpu_extract` on) needs none and reads pinned memory at 0.94-0.96 of the copy rate.
+void Engine::StagedExtract(Batch *b, hipStream_t xs) {
+  const uint32_t L = (uint32_t)cfg.fanout.size();
+  const size_t row_bytes = ds.feat_dim * ggms_dtype_bytes(ds.feat_dtype);
+  if (!host_team_) host_team_ = std::make_unique<Team>((int)std::max<size_t>(1, cfg.omp_thread_num));
+  uint64_t *n_in = b->counts_dev + 3 * L, *n_miss = b->counts_dev + 3 * L + 2, *n_hit = b->counts_dev + 3 * L + 3;
+  SAM_HIP(hipMemcpyAsync(b->counts, b->counts_dev, (3 * L + 4) * 8, hipMemcpyDeviceToHost, xs));
+  SAM_HIP(hipStreamSynchronize(xs)); // the batch is sampled: its size is known on the host
+  const size_t num_input = b->counts[3 * L];
+  (void)n_in;
+  if (num_input == 0) return;
+  SAM_GGMS(ggms_get_miss_cache_index(cache_table_, b->input_nodes, num_input, b->miss_src, b->miss_dst, n_miss, b->hit_src,
+                                     b->hit_dst, n_hit, b->idx_ws, ggms_cache_index_workspace_bytes(max_unique_), xs));
+  SAM_HIP(hipMemcpyAsync(b->counts + 3 * L + 2, n_miss, 16, hipMemcpyDeviceToHost, xs));
+  SAM_HIP(hipStreamSynchronize(xs));
+  const size_t num_miss = b->counts[3 * L + 2], num_hit = b->counts[3 * L + 3];
+  SAM_CHECK(num_miss + num_hit == num_input, "CHECK_EQ(num_miss + num_cache, num_input), dist_loops.cc:1047");
+  if (num_miss) {
+    SAM_HIP(hipMemcpyAsync(b->miss_ids_host, b->miss_src, num_miss * 4, hipMemcpyDeviceToHost, xs)); // DoCacheIdCopyToCPU
+    SAM_HIP(hipStreamSynchronize(xs));
+    const char *feat = (const char *)ds.feat.ptr;
+    char *rows = (char *)b->miss_rows_host;
+    const uint32_t *ids = b->miss_ids_host;
+    const uint32_t mask = ds.feat_mask;
+    host_team_->ParallelFor(num_miss, [&](size_t lo, size_t hi, int) { // ExtractMissData on the CPU, _host.cc:268-300
+      for (size_t i = lo; i < hi; ++i) std::memcpy(rows + i * row_bytes, feat + (size_t)(ids[i] & mask) * row_bytes, row_bytes);
+    });
+    SAM_HIP(hipMemcpyAsync(b->miss_rows_dev, rows, num_miss * row_bytes, hipMemcpyHostToDevice, xs));
+    SAM_GGMS(ggms_gather_scatter(b->feat, b->miss_rows_dev, nullptr, b->miss_dst, num_miss, nullptr, ds.feat_dim,
+                                 ds.feat_dtype, xs)); // CombineMissData
+  }
+  if (num_hit) { // CombineCacheData
+    if (num_cache_part_ == 0)
+      SAM_GGMS(ggms_gather_scatter(b->feat, cache_parts_[0], b->hit_src, b->hit_dst, num_hit, nullptr, ds.feat_dim,
+                                   ds.feat_dtype, xs));
+    else
+      SAM_GGMS(ggms_gather_scatter_partition(b->feat, (const void *const *)d_cache_parts_tab_, num_cache_part_, b->hit_src,
+                                             b->hit_dst, num_hit, nullptr, ds.feat_dim, ds.feat_dtype, xs));
+  }
 }
 
 // block until the batch is complete, publish sizes, log the items the scripts read

@@ -143,6 +143,11 @@ struct Batch {
   size_t num_seeds = 0, num_input = 0;
   uint64_t num_miss = 0;
   hipEvent_t ev_seeds = nullptr, ev_start = nullptr, ev_sampled = nullptr, ev_done = nullptr;
+  // arch6 with `gpu_extract` off: the host-staged miss path (dist_loops.cc:1015-1207)
+  uint32_t *miss_src = nullptr, *miss_dst = nullptr, *hit_src = nullptr, *hit_dst = nullptr;
+  void *idx_ws = nullptr, *miss_rows_dev = nullptr;
+  void *miss_rows_host = nullptr;   // hipHostMalloc (pinned): CPU-gathered miss rows, then one async H2D copy
+  uint32_t *miss_ids_host = nullptr; // hipHostMalloc
 };
 
 class Engine {
@@ -190,6 +195,10 @@ class Engine {
   void Presample();
   void BuildCache();
   Batch *AcquireSlot(bool background);
+  // `gpu_extract` off (SGNN mode of arch6): miss ids -> host, CPU gather into pinned memory, async H2D, combine
+  bool StagedHostTier() const { return cfg.arch == kArch6 && cfg.UseGPUCache() && !cfg.gpu_extract && cache_table_ != nullptr; }
+  void StagedExtract(Batch *b, hipStream_t xs);
+  std::unique_ptr<class Team> host_team_;
   void SanityCheckBatch(const uint32_t *seeds, size_t n); // SAMGRAPH_SANITY_CHECK
   std::vector<bool> sanity_seen_;
   uint32_t *node_access_dev_ = nullptr; // SAMGRAPH_LOG_NODE_ACCESS[_SIMPLE]: visits per node (input nodes of every batch)
