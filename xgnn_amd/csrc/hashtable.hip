@@ -22,6 +22,14 @@
 //   so insertion is {CAS on w0 if needed, one atomicMin on w1}; there is no
 //   per-bucket initialisation that could race with a concurrent duplicate.
 // Probing is the reference's: pos = key mod size, then pos = (pos + delta++) mod size.
+//
+// Direct layout, who owns a key: the insert is a RETURNING atomicMin and its return value already says it
+// (DedupInsert in ggms_device.h: cand / lost), so the owner scan reads no table word.  Two modes:
+//   leaf  (ggms_hashtable_fill_with_duplicates / ggms_map_edges): the owner scan rewrites the owners' words as
+//         {assigned, local id}, which is what SearchO2N reads and what makes later fills lose to them;
+//   batch (ggms_sample_batch): one index space for the whole batch, the table is never rewritten, local ids live in
+//         the fills' own outputs (IdxMap) -- k_owner_scan<true>, k_map_rest_all.
+// The hashed layout keeps the reference's sizing (TableSize) and the re-read form (OwnerFlag / AssignLocal).
 #include <algorithm>
 
 #include "ggms_internal.h"

@@ -20,11 +20,14 @@
 //     GPUMapEdges' src half (cuda_mapping.cu:57-60) reduce to none (n lookups
 //     for the first layer, whose input is the raw seed list);
 //   * `row` (local id of the sampled neighbour) is produced by the table fill itself:
-//     the instance that owns a key writes its id while assigning it, the other ~30 %
-//     are looked up afterwards (k_map_rest) -- the dst half of GPUMapEdges without a
-//     pass over all E edges;
-//   * with the direct table layout khop3's neighbour gather also enters the neighbour
-//     into the table (one atomicMin), so FillWithDuplicates starts at the owner scan;
+//     the instance that owns a key gets its id in the owner scan, an instance that
+//     loses to an EARLIER layer resolves its id inside the sampler, and the few that
+//     lose inside their own layer are looked up for all layers at once at the end
+//     (k_map_rest_all) -- the dst half of GPUMapEdges without a pass of random reads
+//     over all E edges, and without rewriting the table (batch mode, ggms_device.h);
+//   * with the direct table layout khop3's fused launch also enters the neighbours
+//     into the table (one returning atomicMin each), so FillWithDuplicates is only
+//     the owner scan: 3 + 2 L + 1 launches per batch in all;
 //   * the batch prologue (scan-area clear, item-count reset, |seeds| record) rides on
 //     the first kernel of the batch instead of three tiny launches.
 // Several batches may be in flight on different streams (own table + workspace each):
