@@ -333,6 +333,10 @@ def test_arch1_feature_dtypes(tmp_path, dtype):
     # copied down asynchronously (dist_loops.cc:1076-1207), hits from the (partitioned) cache
     dict(cache_percentage="0.3"),
     dict(cache_percentage="0.3", part_cache="True", use_dist_graph="1.0"),
+    # hybrid store: the hotter half of the cached slots on every GPU, the rest sharded (replica + shards + host rows
+    # behind one gather, ggms_extract_tiered)
+    dict(cache_percentage="0.4", part_cache="True", gpu_extract="True", use_dist_graph="1.0", replicate_percentage="0.5"),
+    dict(cache_percentage="1.0", part_cache="True", gpu_extract="True", replicate_percentage="0.25"),
 ])
 def test_arch6_two_workers_one_gpu(tmp_path, opts):
     """XGNN mode: topology shards + partitioned feature cache shared through hipIpc, two forked workers

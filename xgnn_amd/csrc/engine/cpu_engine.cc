@@ -251,7 +251,7 @@ void Engine::CpuInit() { // CPUEngine::Init, cpu_engine.cc:50-110
     b->output_nodes = (uint32_t *)alloc(max_seeds_ * 4);
     b->feat = alloc(max_unique_ * row_bytes);
     b->label = (int64_t *)alloc(max_seeds_ * 8);
-    b->counts = (uint64_t *)std::calloc(3 * L + 4, 8);
+    b->counts = (uint64_t *)std::calloc(3 * L + 8, 8);
     if (gpu) {
       auto &S = C.staging[s];
       S.row.resize(L); S.col.resize(L);

@@ -116,6 +116,9 @@ void Engine::Configure(const std::unordered_map<std::string, std::string> &kv_in
     cfg.part_cache = true;
   }
   if (kv.count("gpu_extract") && kv["gpu_extract"] == "True") cfg.gpu_extract = (cfg.arch == kArch6); // :229-235
+  // extension: the hottest fraction of the CACHED slots is kept on every GPU instead of being sharded (what the
+  // reference's PartitionSolver buys with replica placement on NVLink, dist_graph.cu:40-222); 0 = pure modulo shards
+  if (kv.count("replicate_percentage")) cfg.replicate_percentage = std::stod(kv["replicate_percentage"]);
   if (kv.count("presample_epoch")) cfg.presample_epoch = std::stoull(kv["presample_epoch"]); // operation.cc:184-189
   if (kv.count("seed")) { cfg.has_seed = true; cfg.seed = std::stoull(kv["seed"]); }
   if (kv.count("hash_table")) cfg.direct_table = kv["hash_table"] != "hashed";
@@ -526,7 +529,7 @@ void Engine::Presample() {
   uint64_t *d_counts = nullptr;
   SAM_HIP(hipMalloc((void **)&d_train, std::max<size_t>(n_train, 1) * 4));
   SAM_HIP(hipMalloc((void **)&d_freq, ds.num_node * 4));
-  SAM_HIP(hipMalloc((void **)&d_counts, (3 * L + 4) * 8));
+  SAM_HIP(hipMalloc((void **)&d_counts, (3 * L + 8) * 8));
   SAM_HIP(hipMemsetAsync(d_freq, 0, ds.num_node * 4, stream_));
   std::vector<uint32_t *> row(L), col(L), dat(L, nullptr);
   for (uint32_t i = 0; i < L; ++i) {
@@ -587,14 +590,18 @@ void Engine::BuildCache() {
   num_cached_nodes_ = (size_t)(ds.num_node * cfg.cache_percentage);
   std::vector<uint32_t> rank(rank_in, rank_in + ds.num_node);
   const uint32_t P = cfg.part_cache ? (uint32_t)cfg.num_worker : 1, p = cfg.part_cache ? (uint32_t)worker_id_ : 0;
-  if (cfg.part_cache) { // load balance across shards: :169-171
+  // hybrid store: slots [0, R) = the hottest cached nodes, a copy on every GPU; slots [R, num_cached) sharded
+  num_replica_ = cfg.part_cache ? (size_t)(num_cached_nodes_ * cfg.replicate_percentage) : 0;
+  SAM_CHECK(num_replica_ == 0 || cfg.gpu_extract, "replicate_percentage needs gpu_extract (one fused gather over all tiers)");
+  const size_t R = num_replica_;
+  if (cfg.part_cache) { // load balance across shards: :169-171 (the replicated prefix keeps its rank order)
     std::mt19937 eg((uint32_t)num_cached_nodes_);
-    std::shuffle(rank.begin(), rank.begin() + num_cached_nodes_, eg);
+    std::shuffle(rank.begin() + R, rank.begin() + num_cached_nodes_, eg);
   }
   // Everything cached (cache_percentage 1.0; 288 GB of HBM hold every BASELINE feature table): rows stay in NODE
   // order, slot = node id -- no id -> slot table and no table read per gathered row (ggms_extract_cached with
   // table == NULL).  The reference ranks and shuffles even then; the layout is not observable through its interface.
-  const bool full_cache = num_cached_nodes_ == ds.num_node;
+  const bool full_cache = num_cached_nodes_ == ds.num_node && R == 0;
   if (full_cache) {
     for (size_t i = 0; i < ds.num_node; ++i) rank[i] = (uint32_t)i;
     cache_table_ = nullptr;
@@ -603,11 +610,18 @@ void Engine::BuildCache() {
     for (size_t i = 0; i < num_cached_nodes_; ++i) table[rank[i]] = (uint32_t)i; // :197-229
     cache_table_ = (uint32_t *)dev_upload(table.data(), ds.num_node * 4, stream_);
   }
-  // DistGraph::FeatureLoad / _PartitionFeature, dist_graph.cu:493-521: rows rank[i], i == p (mod P)
-  const size_t my_rows = num_cached_nodes_ / P + (p < num_cached_nodes_ % P ? 1 : 0);
+  if (R) { // this GPU's copy of the hottest rows
+    std::vector<char> rep(R * row_bytes);
+    for (size_t i = 0; i < R; ++i) std::memcpy(&rep[i * row_bytes], feat + (size_t)(rank[i] & ds.feat_mask) * row_bytes, row_bytes);
+    d_replica_ = dev_upload(rep.data(), rep.size(), stream_);
+    SAM_HIP(hipStreamSynchronize(stream_));
+  }
+  // DistGraph::FeatureLoad / _PartitionFeature, dist_graph.cu:493-521: rows rank[i], (i - R) == p (mod P)
+  const size_t sharded = num_cached_nodes_ - R;
+  const size_t my_rows = sharded / P + (p < sharded % P ? 1 : 0);
   std::vector<char> tmp(std::max<size_t>(my_rows * row_bytes, 16));
   size_t c = 0;
-  for (size_t i = p; i < num_cached_nodes_; i += P, ++c)
+  for (size_t i = R + p; i < num_cached_nodes_; i += P, ++c)
     std::memcpy(&tmp[c * row_bytes], feat + (size_t)(rank[i] & ds.feat_mask) * row_bytes, row_bytes);
   cache_parts_.assign(P, nullptr);
   cache_parts_[p] = dev_upload(tmp.data(), my_rows * row_bytes, stream_);
@@ -657,8 +671,8 @@ void Engine::TrainInit(int worker_id, const std::string &ctx) {
     SAM_HIP(hipMalloc((void **)&b->output_nodes, max_seeds_ * 4));
     SAM_HIP(hipMalloc(&b->feat, max_unique_ * row_bytes));
     SAM_HIP(hipMalloc((void **)&b->label, max_seeds_ * 8));
-    SAM_HIP(hipMalloc((void **)&b->counts_dev, (3 * L + 4) * 8));
-    SAM_HIP(hipMemset(b->counts_dev, 0, (3 * L + 4) * 8));
+    SAM_HIP(hipMalloc((void **)&b->counts_dev, (3 * L + 8) * 8));
+    SAM_HIP(hipMemset(b->counts_dev, 0, (3 * L + 8) * 8));
     if (StagedHostTier()) { // index arrays of GetMissCacheIndex + pinned / device staging of the miss rows
       for (uint32_t **p : {&b->miss_src, &b->miss_dst, &b->hit_src, &b->hit_dst}) SAM_HIP(hipMalloc((void **)p, max_unique_ * 4));
       SAM_HIP(hipMalloc(&b->idx_ws, ggms_cache_index_workspace_bytes(max_unique_)));
@@ -666,8 +680,8 @@ void Engine::TrainInit(int worker_id, const std::string &ctx) {
       SAM_HIP(hipHostMalloc(&b->miss_rows_host, max_unique_ * row_bytes));
       SAM_HIP(hipHostMalloc((void **)&b->miss_ids_host, max_unique_ * 4));
     }
-    SAM_HIP(hipHostMalloc((void **)&b->counts, (3 * L + 4) * 8));
-    std::memset(b->counts, 0, (3 * L + 4) * 8);
+    SAM_HIP(hipHostMalloc((void **)&b->counts, (3 * L + 8) * 8));
+    std::memset(b->counts, 0, (3 * L + 8) * 8);
     SAM_HIP(hipEventCreateWithFlags(&b->ev_seeds, hipEventDisableTiming));
     SAM_HIP(hipEventCreate(&b->ev_start));
     SAM_HIP(hipEventCreate(&b->ev_sampled));
@@ -781,14 +795,17 @@ bool Engine::EnqueueOne(bool background) {
   const bool mock = ds.feat_mask != 0xffffffffu; // SAMGRAPH_EMPTY_FEAT: host rows are node & mask
   if (StagedHostTier()) {
     StagedExtract(b, xs);
-  } else if (cfg.UseGPUCache() && mock) {
+  } else if (cfg.UseGPUCache() && (mock || num_replica_)) { // every tier in one gather; rows per tier counted
+    SAM_HIP(hipMemsetAsync(n_miss, 0, 4 * 8, xs)); // {host, remote shard, local shard, replica} = counts[3L+2 .. 3L+5]
     ggms_feature_tiers_t tiers{};
     tiers.table = cache_table_;
+    tiers.replica = d_replica_;
+    tiers.num_replica = num_replica_;
     tiers.parts_dev = (const void *const *)d_cache_parts_tab_;
     tiers.num_part = std::max<uint32_t>(1, num_cache_part_);
     tiers.my_part = cfg.part_cache ? (uint32_t)worker_id_ : 0;
     tiers.host_feat = feat_src_;
-    tiers.host_row_mask = ds.feat_mask;
+    tiers.host_row_mask = mock ? ds.feat_mask : 0;
     SAM_GGMS(ggms_extract_tiered(b->feat, b->input_nodes, max_unique_, n_in, &tiers, ds.feat_dim, ds.feat_dtype, n_miss, xs));
   } else if (cfg.UseGPUCache()) {
     // DoArch6GetCacheMissIndex + DoArch6GPUCacheFeatureCopy (dist_loops.cc:1015-1285) in one pass
@@ -807,7 +824,7 @@ bool Engine::EnqueueOne(bool background) {
     SAM_GGMS(ggms_count_nodes(node_access_dev_, b->input_nodes, max_unique_, n_in, xs));
   // DoGPULabelExtract, dist_loops.cc:938-974
   SAM_GGMS(ggms_extract(b->label, label_src_, b->output_nodes, b->num_seeds, 1, GGMS_I64, xs));
-  SAM_HIP(hipMemcpyAsync(b->counts, b->counts_dev, (3 * L + 4) * 8, hipMemcpyDeviceToHost, xs));
+  SAM_HIP(hipMemcpyAsync(b->counts, b->counts_dev, (3 * L + 8) * 8, hipMemcpyDeviceToHost, xs));
   SAM_HIP(hipEventRecord(b->ev_done, xs));
   {
     std::lock_guard<std::mutex> lk(pool_mu_);
@@ -828,7 +845,7 @@ void Engine::StagedExtract(Batch *b, hipStream_t xs) {
   const size_t row_bytes = ds.feat_dim * ggms_dtype_bytes(ds.feat_dtype);
   if (!host_team_) host_team_ = std::make_unique<Team>((int)std::max<size_t>(1, cfg.omp_thread_num));
   uint64_t *n_in = b->counts_dev + 3 * L, *n_miss = b->counts_dev + 3 * L + 2, *n_hit = b->counts_dev + 3 * L + 3;
-  SAM_HIP(hipMemcpyAsync(b->counts, b->counts_dev, (3 * L + 4) * 8, hipMemcpyDeviceToHost, xs));
+  SAM_HIP(hipMemcpyAsync(b->counts, b->counts_dev, (3 * L + 8) * 8, hipMemcpyDeviceToHost, xs));
   SAM_HIP(hipStreamSynchronize(xs)); // the batch is sampled: its size is known on the host
   const size_t num_input = b->counts[3 * L];
   (void)n_in;

@@ -66,6 +66,7 @@ struct RunConfig {
   bool use_dist_graph = false;
   double dist_graph_percentage = 0.0;
   bool part_cache = false, gpu_extract = false;
+  double replicate_percentage = 0.0; // of the cached slots, hottest first: kept on every GPU (hybrid store)
   bool configured = false;
   // extensions (optional keys)
   bool has_seed = false;
@@ -137,7 +138,7 @@ struct Batch {
   uint32_t *input_nodes = nullptr, *output_nodes = nullptr;
   void *feat = nullptr;
   int64_t *label = nullptr;
-  uint64_t *counts_dev = nullptr; // 3L+1 (+2: num_miss, spare)
+  uint64_t *counts_dev = nullptr; // 3L+8: counts, status, then rows per tier {host miss, remote, local, replica}
   // pinned host copy (hipHostMalloc), valid after Finish()
   uint64_t *counts = nullptr;
   size_t num_seeds = 0, num_input = 0;
@@ -255,6 +256,8 @@ class Engine {
   void *d_cache_parts_tab_ = nullptr;
   uint32_t num_cache_part_ = 0;
   size_t num_cached_nodes_ = 0;
+  size_t num_replica_ = 0;                     // hybrid store: slots [0, num_replica_) live in d_replica_ on every GPU
+  void *d_replica_ = nullptr;
   void *d_feat_ = nullptr;                     // full feature table on the device (arch1) ...
   const void *feat_src_ = nullptr;             // ... or device-mapped host memory (gpu_extract / miss tier)
   const void *label_src_ = nullptr;
