@@ -228,7 +228,14 @@ def main():
     host_feat = None
     if not full:  # host tier: the full table in pinned host memory, read zero-copy by the gather kernel
         host_feat = torch.empty((N, dim), dtype=torch.float32, pin_memory=True)
-        feat_rows(torch.arange(N, dtype=torch.int64), host_feat)
+        chunk = 1 << 22  # generated on the GPU chunk by chunk and copied down (the CPU would take minutes at this size)
+        tmp = torch.empty((min(chunk, N), dim), dtype=torch.float32, device=dev)
+        for lo in range(0, N, chunk):
+            m = min(chunk, N - lo)
+            feat_rows(torch.arange(lo, lo + m, dtype=torch.int64, device=dev), tmp[:m])
+            host_feat[lo:lo + m].copy_(tmp[:m])
+        del tmp
+        log("host tier filled")
 
     def build_store(kind):
         """-> (extract(nodes, num_max, out, num_dev, counters), what it keeps alive) for one store kind."""

@@ -69,3 +69,36 @@ def test_two_ranks_one_gpu(store):
     d = _last_json(r.stdout)
     assert KEYS <= set(d) and d["n_gpus"] == 2 and d["value"] > 0
     assert store in d["config"]["workload"]
+
+
+def _two_ranks_full_size(flags, timeout=900):
+    env = dict(os.environ, GGMS_BENCH_DEVICE="0", GGMS_BENCH_BACKEND="gloo")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"),
+                        "--gpus", "2", "--steps", "5", "--warmup", "1", "--repeats", "1", "--other-stores", ""] + flags,
+                       capture_output=True, text=True, timeout=timeout, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    return _last_json(r.stdout)
+
+
+def test_configs3_papers100m_graphsage_feature_shards_full_size():
+    """BASELINE configs[3] at its real size, as far as one GPU allows: papers100M-shaped CSR, GraphSAGE [25,10], the
+    56.9-GB feature table split into GGMS shards over two ranks (two processes on the box's one GPU, 28.4 GB each --
+    a size hipIpc could not open before ggms_ipc_safe_bytes), rows read from the peer's shard inside the gather
+    kernel; bench.py checks the gathered rows of the last batch against the generator (rows_verified)."""
+    d = _two_ranks_full_size(["--fanout", "25,10", "--store", "peer"])
+    assert d["rows_verified"] and d["n_gpus"] == 2 and "N=111059956" in d["config"]["workload"]
+    st = d["stores"]["peer"]
+    assert 0.45 < st["remote_row_fraction"] < 0.55 and st["rows_by_tier"]["host"] == 0
+
+
+def test_configs4_friendster_pinsage_hybrid_store_full_size():
+    """BASELINE configs[4] at its real size on two ranks: Friendster-scale CSR (N 65.6 M, 256-dim rows), PinSAGE random
+    walks, hybrid GGMS -- the hotter half of the rows in HBM (a quarter of those replicated on both ranks, the rest
+    sharded), every row also in pinned host DRAM; one gather serves replica, local shard, peer shard and host rows."""
+    d = _two_ranks_full_size(["--preset", "friendster", "--sample-type", "random_walk", "--fanout", "5,5,5",
+                              "--store", "hybrid", "--cache-ratio", "0.5"], timeout=1200)
+    assert d["rows_verified"] and d["n_gpus"] == 2 and "N=65608366" in d["config"]["workload"]
+    t = d["stores"]["hybrid"]["rows_by_tier"]
+    assert min(t["host"], t["remote_shard"], t["local_shard"], t["replica"]) > 0
+    assert abs(sum(t.values()) - d["stores"]["hybrid"]["rows_per_step"] * 5) < 1
