@@ -57,6 +57,9 @@ def parse():
     ap.add_argument("--host-profile", action="store_true", help="print host enqueue time per section to stderr")
     ap.add_argument("--pipelines", type=int, default=1,
                     help="sampling batches in flight (each on its own stream with its own dedup table)")
+    ap.add_argument("--heavy-after-gather", action="store_true",
+                    help="the last (largest) layer's sampler launch of batch k+1 waits for the gather of batch k: the two "
+                         "fabric-heaviest kernels run one after the other, the smaller layers still overlap the gather")
     ap.add_argument("--no-overlap", action="store_true",
                     help="one stream: extract of batch k and sampling of batch k+1 run back to back "
                          "(default: two streams, the HBM-bound gather overlaps the latency-bound sampler)")
@@ -329,6 +332,7 @@ def main():
         torch.cuda.synchronize()
 
     host_t = [0.0] * 6
+    last_gather = [None]  # completion event of the most recent feature gather (--heavy-after-gather)
 
     def make_step(extract_fn, counters, acc, seeds_of):
         """One step of the hot path: sample on the batch's pipeline stream, gather + labels on the extract stream."""
@@ -343,7 +347,8 @@ def main():
                 if ev4 is not None:
                     ev4[0].record(s_sample)
                 h1 = time.perf_counter()
-                sampler.sample(seeds, slot=slot, copy_input_nodes=True)
+                sampler.sample(seeds, slot=slot, copy_input_nodes=True,
+                               heavy_wait=last_gather[0] if args.heavy_after_gather else None)
                 h2 = time.perf_counter()
                 sampled = torch.cuda.Event()
                 sampled.record(s_sample)
@@ -358,6 +363,9 @@ def main():
                 extract_fn(sampler.input_nodes[slot], sampler.max_unique, out[slot], counts[3 * L:3 * L + 1], counters)
                 if ev4 is not None:
                     ev4[3].record(s_extract)
+                if args.heavy_after_gather:
+                    last_gather[0] = torch.cuda.Event()
+                    last_gather[0].record(s_extract)
                 h4 = time.perf_counter()
                 ops.extract(labels, seeds, out=out_label[slot][:seeds.numel()])
                 h5 = time.perf_counter()

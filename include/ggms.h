@@ -287,6 +287,12 @@ typedef struct {
    * fills, scans, id mapping) is free to overlap with the neighbouring batches.  NULL = none. */
   ggms_event_t rng_wait;
   ggms_event_t rng_done;
+  /* Optional: the sampler launch of the LAST layer processed (layer 0, normally by far the largest: most of the
+   * batch's neighbour loads and table atomics) waits for this event.  A caller that gathers the previous batch's
+   * feature rows on another stream passes that gather's completion event: the memory fabric then serves the
+   * gather and the fabric-heaviest sampler kernel one after the other instead of time-slicing them;
+   * the smaller layers still overlap the gather.  NULL = no wait.  Results do not depend on it. */
+  ggms_event_t heavy_wait;
 } ggms_sample_extra_t;
 
 /* events for the ordering above (thin hipEvent_t handles, timing disabled) */

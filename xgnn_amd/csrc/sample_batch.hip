@@ -234,6 +234,7 @@ int ggms_sample_batch(int sample_type, const ggms_graph_t *graph, const ggms_id_
                                : counts_dev + 3 * num_layer;          // = number of input nodes
     // batch order on the shared RNG pool (and on khop2's CSR): only the sampler kernels are ordered
     if (first && extra && extra->rng_wait) GGMS_HIP(hipStreamWaitEvent(s, (hipEvent_t)extra->rng_wait, 0));
+    if (i == 0 && extra && extra->heavy_wait) GGMS_HIP(hipStreamWaitEvent(s, (hipEvent_t)extra->heavy_wait, 0));
     // direct table + khop3: the sampler enters its output into the table itself (DedupInsert)
     di.base = next_base; // this layer's edges take the indices [base, base + e_max)
     di.w = (unsigned long long *)ht->o2n;

@@ -505,7 +505,7 @@ class BatchSampler:
         except Exception:
             pass
 
-    def sample(self, seeds, slot=0, copy_input_nodes=False):
+    def sample(self, seeds, slot=0, copy_input_nodes=False, heavy_wait=None):
         """Enqueue one batch into output slot `slot`; read counts / row / col / ht.n2o after a sync.
         copy_input_nodes: also copy the unique list (ht.n2o, reused by a later batch) into the slot.
         Batch b runs on pipeline b % num_pipelines (its table is `self.ht` until the next call)."""
@@ -525,6 +525,8 @@ class BatchSampler:
         if self._events:
             ex.rng_wait = self._events[(b - 1) % K] if b > 0 else None
             ex.rng_done = self._events[pipe]
+        # heavy_wait (torch.cuda.Event): the last layer's sampler launch waits for it (ggms_sample_extra_t.heavy_wait)
+        ex.heavy_wait = C.c_void_p(heavy_wait.cuda_event) if heavy_wait is not None else None
         ws = self.wss[pipe]
         # copy_input_nodes: the slot keeps the batch's unique list.  The table's n2o buffer is the caller's
         # (ggms_hashtable_t is plain data), so the batch simply builds the list IN the slot's buffer -- no copy
