@@ -481,9 +481,12 @@ def main():
         for kind in [k for k in args.other_stores.split(",") if k and k != main_store]:
             extract_main = keep_main = None
             torch.cuda.empty_cache()
-            ex, keep_main = build_store(kind)
-            b2, next_step = measure(ex, args.steps, 2, 1, first_step=next_step)
-            stores[kind] = store_record(b2[0], kind)
+            try:  # a store that cannot be built here (memory) must not cost the line its main result
+                ex, keep_main = build_store(kind)
+                b2, next_step = measure(ex, args.steps, 2, 1, first_step=next_step)
+                stores[kind] = store_record(b2[0], kind)
+            except (RuntimeError, MemoryError) as e:
+                stores[kind] = {"error": f"{type(e).__name__}: {str(e)[:200]}"}
 
     # ---- N = 1: BASELINE configs[2], every row in pinned host DRAM (cache_ratio 0) -----------------------------
     host_tier = None
