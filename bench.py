@@ -68,7 +68,10 @@ def parse():
                          "inside the gather kernel over xGMI (hipIpc); 'a2a' = same shards, rows exchanged with RCCL "
                          "all-to-all; 'hybrid' = the --replicate-frac hottest rows (degree rank) on every GPU, the tail "
                          "sharded; 'replica' = every GPU holds all cached rows (DP over seeds only)")
-    ap.add_argument("--replicate-frac", type=float, default=0.25, help="hybrid store: fraction of rows replicated")
+    ap.add_argument("--replicate-frac", default="0.25",
+                    help="hybrid store: fraction of the cached rows replicated on every GPU, or 'auto' = the largest "
+                         "prefix that fits --hbm-budget-gb per GPU (ggms_store.plan_replication)")
+    ap.add_argument("--hbm-budget-gb", type=float, default=24.0, help="hybrid store with --replicate-frac auto")
     ap.add_argument("--other-stores", default="replica,hybrid",
                     help="N > 1: stores measured after the main timed region (one block) and reported under 'stores'")
     ap.add_argument("--cache-ratio", type=float, default=1.0,
@@ -263,7 +266,11 @@ def main():
             return extract, keep
         # sharded kinds.  Everything cached and nothing replicated: slot = node id, no table (as on one GPU).
         # Otherwise slots in degree-rank order (hot first); hybrid replicates the first R of them on every GPU.
-        R = int(num_cached * args.replicate_frac) if kind == "hybrid" else 0
+        R = 0
+        if kind == "hybrid":
+            R = (ggms_store.plan_replication(num_cached, row_bytes, world, int(args.hbm_budget_gb * 1e9))
+                 if args.replicate_frac == "auto" else int(num_cached * float(args.replicate_frac)))
+            R = min(R, num_cached - world)  # keep a sharded tail
         if full and R == 0:
             order, table = torch.arange(N, dtype=torch.int64, device=dev), None
         else:

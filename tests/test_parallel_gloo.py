@@ -197,3 +197,16 @@ def test_two_rank_feature_shards_all_to_all():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert res == [(0, True), (1, True)]
+
+
+def test_plan_replication_fills_the_budget():
+    from xgnn_amd.ggms_store import plan_replication
+    row = 512
+    n = 111_059_956
+    assert plan_replication(n, row, 1, 10 ** 9) == n                    # one GPU: nothing to shard
+    assert plan_replication(n, row, 8, n * row) == n                    # everything fits: replicate all
+    assert plan_replication(n, row, 8, n * row // 8) == 0               # just the shard fits: pure modulo shards
+    for world, budget in ((8, 24 * 10 ** 9), (4, 30 * 10 ** 9), (2, 40 * 10 ** 9)):
+        r = plan_replication(n, row, world, budget)
+        used = r * row + -(-(n - r) // world) * row
+        assert 0 < r < n and used <= budget < used + world * row * 2    # the largest prefix that fits

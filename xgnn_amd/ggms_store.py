@@ -157,6 +157,21 @@ class FeatureShards:
         return [int(x) for x in r.tolist()]
 
 
+def plan_replication(num_cached, row_bytes, world, hbm_budget_bytes):
+    """How many of the hottest cached slots to keep on EVERY GPU (the rest is sharded modulo `world`), given the
+    bytes of HBM one GPU may spend on feature rows.  The role the reference's PartitionSolver plays on NVLink
+    (dist_graph.cu:40-222: replicas until no GPU fetches more than its links carry): on a fully connected xGMI node
+    every remote row costs the same, so the best placement under a memory budget is simply the largest replicated
+    prefix that fits --  R * row + ceil((num_cached - R) / world) * row <= budget.
+    Returns R in [0, num_cached]; num_cached means 'replicate everything' (no xGMI traffic at all)."""
+    if world <= 1 or num_cached * row_bytes <= hbm_budget_bytes:
+        return num_cached
+    rows = hbm_budget_bytes // row_bytes  # rows one GPU can hold
+    # R + (num_cached - R) / world <= rows  ->  R <= (rows * world - num_cached) / (world - 1)
+    r = (rows * world - num_cached) // (world - 1)
+    return int(max(0, min(num_cached, r)))
+
+
 def shard_rows(feat_rows_fn, rank_list, num_cached, world, rank, dim, dtype, device, shared=False):
     """Build this rank's shard: row k = feature of node rank_list[rank + k * world] (partition_feature).
     feat_rows_fn(node_ids, out) fills `out` with the rows of `node_ids`.  shared=True allocates an
