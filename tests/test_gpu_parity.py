@@ -638,6 +638,32 @@ def test_batches_in_flight_keep_batch_order(ops, stype):
     np.testing.assert_array_equal(host_u32(t_ix), ix)
 
 
+def test_heavy_wait_changes_timing_not_results(ops):
+    """ggms_sample_extra_t.heavy_wait: the last layer's sampler launch waits for an event recorded on another stream
+    (a feature gather, in the pipeline).  Whatever the event, the batch is the oracle's."""
+    ip, ix = powerlaw_csr(20_000, mean_deg=30, seed=6)
+    g = ops.DeviceGraph(dev(ip), dev(ix))
+    fanouts = [5, 10, 15]
+    bs = ops.BatchSampler(g, fanouts, 400, sample_type=ops.KHOP3, seed=9)
+    states = oracle.random_states(bs.states.shape[0], 9)
+    other = torch.cuda.Stream()
+    big = torch.empty(1 << 26, dtype=torch.float32, device="cuda")
+    rng = np.random.RandomState(3)
+    for rep in range(3):
+        seeds = rng.permutation(20_000)[:400].astype(np.uint32)
+        with torch.cuda.stream(other):
+            big.add_(1.0)  # something for the event to sit behind
+            ev = torch.cuda.Event()
+            ev.record(other)
+        bs.sample(dev(seeds), heavy_wait=ev if rep else None)
+        got = bs.result()
+        want = oracle.do_sample(oracle.KHOP3, ip, ix, seeds, fanouts, states)
+        np.testing.assert_array_equal(host_u32(got["input_nodes"]), want["input_nodes"])
+        for i in range(3):
+            np.testing.assert_array_equal(host_u32(got["layers"][i]["row"]), want["layers"][i]["row"])
+            np.testing.assert_array_equal(host_u32(got["layers"][i]["col"]), want["layers"][i]["col"])
+
+
 @pytest.mark.parametrize("stype", ["weighted", "random_walk"])
 def test_sample_batch_weighted_and_random_walk(ops, stype):
     """DoGPUSample with the weighted (alias) sampler and with PinSAGE random walks (row/col/data)."""

@@ -331,7 +331,7 @@ __global__ __launch_bounds__(128) void k_khop0_generate(GraphView g, const uint3
                                                         uint32_t *__restrict__ raw, uint32_t cap,
                                                         uint32_t *__restrict__ out_src,
                                                         uint32_t *__restrict__ out_dst, SrcMode sm,
-                                                        uint32_t *__restrict__ heavy_count) {
+                                                        uint32_t *__restrict__ heavy_count, DedupInsert di) {
   extern __shared__ uint32_t slot_j[]; // [4][fanout]: winning position per reservoir slot (in-place seeds only)
   const uint64_t n = n_arg.get();
   const uint32_t x = threadIdx.x & 31, w = threadIdx.x >> 5;
@@ -379,8 +379,10 @@ __global__ __launch_bounds__(128) void k_khop0_generate(GraphView g, const uint3
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       __builtin_amdgcn_wave_barrier();
       for (uint32_t s0 = x; s0 < fanout; s0 += 32) {
+        const uint32_t nbr = edges[my_slots[s0]];
         out_src[o + s0] = sv;
-        out_dst[o + s0] = edges[my_slots[s0]];
+        out_dst[o + s0] = nbr;
+        if (di.w) di.enter(nbr, o + s0); // direct dedup table of the batch: entered where it is produced
       }
       __builtin_amdgcn_wave_barrier();
     }
@@ -421,7 +423,8 @@ __global__ __launch_bounds__(kBlock) void k_khop0_resolve(GraphView g, const uin
                                                           uint32_t *__restrict__ out_src,
                                                           uint32_t *__restrict__ out_dst, SrcMode sm,
                                                           uint32_t *__restrict__ heavy_count,
-                                                          uint32_t *__restrict__ heavy_list, uint32_t groups) {
+                                                          uint32_t *__restrict__ heavy_list, uint32_t groups,
+                                                          DedupInsert di) {
   extern __shared__ uint32_t slot_j[]; // [groups][fanout]
   constexpr uint32_t G = 16;
   const uint64_t n = n_arg.get();
@@ -437,8 +440,10 @@ __global__ __launch_bounds__(kBlock) void k_khop0_resolve(GraphView g, const uin
     const uint32_t sv = sm.value(rid, index);
     if (len <= fanout) {
       for (uint32_t j = lig; j < len; j += G) {
+        const uint32_t nbr = edges[j];
         out_src[o + j] = sv;
-        out_dst[o + j] = edges[j];
+        out_dst[o + j] = nbr;
+        if (di.w) di.enter(nbr, o + j);
       }
       continue;
     }
@@ -455,8 +460,10 @@ __global__ __launch_bounds__(kBlock) void k_khop0_resolve(GraphView g, const uin
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
     for (uint32_t s0 = lig; s0 < fanout; s0 += G) {
+      const uint32_t nbr = edges[my_slots[s0]];
       out_src[o + s0] = sv;
-      out_dst[o + s0] = edges[my_slots[s0]];
+      out_dst[o + s0] = nbr;
+      if (di.w) di.enter(nbr, o + s0);
     }
     __builtin_amdgcn_wave_barrier();
   }
@@ -470,7 +477,7 @@ __global__ __launch_bounds__(1024) void k_khop0_resolve_heavy(GraphView g, const
                                                               uint32_t *__restrict__ out_src,
                                                               uint32_t *__restrict__ out_dst, SrcMode sm,
                                                               const uint32_t *__restrict__ heavy_count,
-                                                              const uint32_t *__restrict__ heavy_list) {
+                                                              const uint32_t *__restrict__ heavy_list, DedupInsert di) {
   extern __shared__ uint32_t slot_j[]; // [fanout]
   const uint32_t num = *heavy_count;
   for (uint32_t h = blockIdx.x; h < num; h += gridDim.x) {
@@ -485,8 +492,10 @@ __global__ __launch_bounds__(1024) void k_khop0_resolve_heavy(GraphView g, const
     khop0_resolve_draws(raw, base, len - fanout, fanout, threadIdx.x, 1024, slot_j);
     __syncthreads();
     for (uint32_t s0 = threadIdx.x; s0 < fanout; s0 += 1024) {
+      const uint32_t nbr = edges[slot_j[s0]];
       out_src[o + s0] = sv;
-      out_dst[o + s0] = edges[slot_j[s0]];
+      out_dst[o + s0] = nbr;
+      if (di.w) di.enter(nbr, o + s0);
     }
     __syncthreads();
   }
@@ -507,7 +516,7 @@ __global__ __launch_bounds__(kBlock) void k_sample_khop2(const uint32_t *__restr
                                                          uint32_t fanout, const uint32_t *__restrict__ offset,
                                                          uint32_t *__restrict__ out_src,
                                                          uint32_t *__restrict__ out_dst,
-                                                         uint32_t *__restrict__ states, SrcMode sm) {
+                                                         uint32_t *__restrict__ states, SrcMode sm, DedupInsert di) {
   const uint64_t n = n_arg.get();
   const uint64_t num_tiles = (n + 1023) / 1024;
   for (uint64_t b = blockIdx.x; b < num_tiles; b += gridDim.x) {
@@ -525,8 +534,10 @@ __global__ __launch_bounds__(kBlock) void k_sample_khop2(const uint32_t *__restr
       uint32_t *list = indices + off;
       if (len <= fanout) {
         for (uint32_t j = 0; j < len; ++j) {
+          const uint32_t nbr = list[j];
           out_src[o + j] = sv;
-          out_dst[o + j] = list[j];
+          out_dst[o + j] = nbr;
+          if (di.w) di.enter(nbr, o + j);
         }
       } else {
         drew = true;
@@ -537,6 +548,7 @@ __global__ __launch_bounds__(kBlock) void k_sample_khop2(const uint32_t *__restr
           const uint32_t moved = list[tail];
           out_src[o + j] = sv;
           out_dst[o + j] = picked;
+          if (di.w) di.enter(picked, o + j);
           list[sel] = moved;
           list[tail] = picked;
         }
@@ -625,7 +637,8 @@ size_t khop0_ws_words(size_t num_input, size_t fanout) {
 
 int sample_khop0_impl(GraphView g, const uint32_t *input, size_t n_max, Count n, uint32_t fanout, uint32_t *out_src,
                       uint32_t *out_dst, uint64_t *num_out_dev, uint32_t *workspace, const uint32_t *seed_local,
-                      int src_local, hipStream_t s, ScanArea *shared_scan) {
+                      int src_local, hipStream_t s, ScanArea *shared_scan, const DedupInsert *insert) {
+  const DedupInsert di = insert ? *insert : DedupInsert{}; // w == NULL: no table to enter the output into
   uint32_t *offset = workspace;
   uint32_t *draw_base = offset + n_max;
   uint32_t *heavy_list = draw_base + n_max;
@@ -643,17 +656,17 @@ int sample_khop0_impl(GraphView g, const uint32_t *input, size_t n_max, Count n,
   const SrcMode sm{seed_local, src_local};
   const size_t lds = 4 * fanout * sizeof(uint32_t);
   hipLaunchKernelGGL(k_khop0_generate, dim3(grid_for((n_max + 63) / 64, 1)), dim3(128), lds, s, g, input, n, fanout,
-                     offset, draw_base, raw, cap, out_src, out_dst, sm, heavy_count);
+                     offset, draw_base, raw, cap, out_src, out_dst, sm, heavy_count, di);
   GGMS_LAUNCH_CHECK();
   // seeds per 256-thread block of the resolve kernel: 16 lanes each, as many as 48 KB of LDS slots allow
   const uint32_t groups = std::max<uint32_t>(1, std::min<uint32_t>(16, (48u << 10) / (4u * fanout)));
   hipLaunchKernelGGL(k_khop0_resolve, dim3(grid_for(n_max, groups)), dim3(kBlock), groups * fanout * sizeof(uint32_t),
                      s, g, input, n, fanout, offset, draw_base, raw, cap, out_src, out_dst, sm, heavy_count, heavy_list,
-                     groups);
+                     groups, di);
   GGMS_LAUNCH_CHECK();
   // the few neighbour lists with more than kKhop0Heavy parked draws (none on most batches: the kernel then exits at once)
   hipLaunchKernelGGL(k_khop0_resolve_heavy, dim3(256), dim3(1024), fanout * sizeof(uint32_t), s, g, input, fanout, offset,
-                     draw_base, raw, out_src, out_dst, sm, heavy_count, heavy_list);
+                     draw_base, raw, out_src, out_dst, sm, heavy_count, heavy_list, di);
   GGMS_LAUNCH_CHECK();
   return GGMS_OK;
 }
@@ -661,7 +674,7 @@ int sample_khop0_impl(GraphView g, const uint32_t *input, size_t n_max, Count n,
 int sample_khop2_impl(const uint32_t *indptr, uint32_t *indices, size_t num_node, const uint32_t *input, size_t n_max,
                       Count n, uint32_t fanout, uint32_t *out_src, uint32_t *out_dst, uint64_t *num_out_dev,
                       uint32_t *states, uint32_t *workspace, const uint32_t *seed_local, int src_local, hipStream_t s,
-                      ScanArea *shared_scan) {
+                      ScanArea *shared_scan, const DedupInsert *insert) {
   (void)num_node;
   uint32_t *offset = workspace;
   const GraphView g{indptr, indices, nullptr, nullptr, 0, 0};
@@ -670,7 +683,8 @@ int sample_khop2_impl(const uint32_t *indptr, uint32_t *indices, size_t num_node
                      num_out_dev, s);
   if (rc != GGMS_OK) return rc;
   hipLaunchKernelGGL(k_sample_khop2, dim3(grid_for((n_max + 1023) / 1024, 1)), dim3(kBlock), 0, s, indptr, indices,
-                     input, n, fanout, offset, out_src, out_dst, states, SrcMode{seed_local, src_local});
+                     input, n, fanout, offset, out_src, out_dst, states, SrcMode{seed_local, src_local},
+                     insert ? *insert : DedupInsert{});
   GGMS_LAUNCH_CHECK();
   return GGMS_OK;
 }
