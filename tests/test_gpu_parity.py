@@ -638,6 +638,39 @@ def test_batches_in_flight_keep_batch_order(ops, stype):
     np.testing.assert_array_equal(host_u32(t_ix), ix)
 
 
+@pytest.mark.parametrize("name", ["khop3", "khop0", "khop2", "khop1", "weighted_khop", "random_walk"])
+@pytest.mark.parametrize("direct", [True, False])
+def test_sampler_golden_vectors_hip(ops, name, direct):
+    """The HIP batch sampler against the committed known-answer vectors (tests/golden/sampler_golden.npz), both table
+    layouts: COO, input nodes and the RNG pool after the batch."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "sampler_golden.npz"))
+    ip, ix, seeds = g["indptr"], g["indices"], g["seeds"]
+    fanouts = [int(x) for x in g[f"{name}:fanouts"]]
+    code = {"khop3": ops.KHOP3, "khop0": ops.KHOP0, "khop2": ops.KHOP2, "khop1": ops.KHOP1,
+            "weighted_khop": ops.WEIGHTED_KHOP, "random_walk": ops.RANDOM_WALK}[name]
+    kw = {}
+    if name == "weighted_khop":
+        kw = dict(prob_table=dev(g["prob"]), alias_table=dev(g["alias"]))
+    if name == "random_walk":
+        kw = dict(random_walk_length=3, random_walk_restart_prob=0.5, num_random_walk=4)
+    graph = ops.DeviceGraph(dev(ip), dev(ix.copy()))
+    s = seeds if name != "khop2" else np.unique(seeds)
+    bs = ops.BatchSampler(graph, fanouts, s.size, sample_type=code, seed=int(g["rng_seed"]), direct_table=direct, **kw)
+    bs.sample(dev(s))
+    got = bs.result()
+    assert np.array_equal(host_u32(got["input_nodes"]), g[f"{name}:input_nodes"])
+    for i, l in enumerate(got["layers"]):
+        assert np.array_equal(host_u32(l["row"]), g[f"{name}:row{i}"]) and np.array_equal(host_u32(l["col"]), g[f"{name}:col{i}"])
+        assert [l["num_src"], l["num_dst"]] == [int(x) for x in g[f"{name}:num{i}"]]
+        if l["data"] is not None:
+            assert np.array_equal(host_u32(l["data"]), g[f"{name}:data{i}"])
+    if bs.states is not None:  # the pool may be sized differently; stream t is curand_init(seed + t) either way
+        st = states_np(bs.states)
+        m = min(st.shape[0], g[f"{name}:states_d"].size)
+        assert np.array_equal(st[:m, 0], g[f"{name}:states_d"][:m]) and np.array_equal(st[:m, 1:], g[f"{name}:states_v"][:m])
+
+
 def test_heavy_wait_changes_timing_not_results(ops):
     """ggms_sample_extra_t.heavy_wait: the last layer's sampler launch waits for an event recorded on another stream
     (a feature gather, in the pipeline).  Whatever the event, the batch is the oracle's."""
