@@ -671,6 +671,45 @@ def test_sampler_golden_vectors_hip(ops, name, direct):
         assert np.array_equal(st[:m, 0], g[f"{name}:states_d"][:m]) and np.array_equal(st[:m, 1:], g[f"{name}:states_v"][:m])
 
 
+def test_fused_khop3_random_shapes(ops):
+    """The one-launch khop3 layer (offset scan + positions + gather + dedup insert) over a sweep of seeded random shapes:
+    fan-outs 1..127 (LDS > 48 KB above 96), frontiers of 1, 127, 128, 129 ... seeds, repeated seeds, graphs with empty
+    lists and hubs, 1-3 layers -- leaf call and batch call, each equal to the oracle."""
+    rng = np.random.RandomState(2024)
+    graphs = [powerlaw_csr(4000, mean_deg=9, seed=1), powerlaw_csr(9000, mean_deg=40, seed=2), hub_csr(3000, 6, 6000, 9, 3)]
+    t_graphs = [ops.DeviceGraph(dev(ip), dev(ix)) for ip, ix in graphs]
+    for trial in range(36):
+        gi = trial % 3
+        ip, ix = graphs[gi]
+        N = ip.size - 1
+        L = int(rng.randint(1, 4))
+        fan_hi = 127 if trial % 6 == 0 else 24
+        fanouts = [int(rng.randint(1, fan_hi + 1)) for _ in range(L)]
+        nseed = int(rng.choice([1, 2, 63, 127, 128, 129, 255, 256, 700, 1500]))
+        if np.prod([f + 1 for f in fanouts]) * nseed > 3_000_000:
+            fanouts = [min(f, 12) for f in fanouts]
+        seeds = rng.randint(0, N, nseed).astype(np.uint32)  # with repeats
+        # leaf: GPUSampleKHop3
+        st = ops.random_states((nseed + 127) // 128 * 8, 100 + trial)
+        src, dst, num = ops.sample_khop3(t_graphs[gi], dev(seeds), fanouts[-1], st)
+        ost = oracle.random_states(st.shape[0], 100 + trial)
+        wsrc, wdst = oracle.sample_khop3(ip, ix, seeds, fanouts[-1], ost)
+        k = int(num.item())
+        assert k == wsrc.size, (trial, fanouts, nseed)
+        assert np.array_equal(host_u32(src, k), wsrc) and np.array_equal(host_u32(dst, k), wdst), (trial, fanouts, nseed)
+        # batch: DoGPUSample
+        bs = ops.BatchSampler(t_graphs[gi], fanouts, nseed, sample_type=ops.KHOP3, seed=7 + trial)
+        bs.sample(dev(seeds))
+        got = bs.result()
+        want = oracle.do_sample(oracle.KHOP3, ip, ix, seeds, fanouts, oracle.random_states(bs.states.shape[0], 7 + trial))
+        assert np.array_equal(host_u32(got["input_nodes"]), want["input_nodes"]), (trial, fanouts, nseed)
+        for i in range(L):
+            assert np.array_equal(host_u32(got["layers"][i]["row"]), want["layers"][i]["row"]), (trial, i, fanouts, nseed)
+            assert np.array_equal(host_u32(got["layers"][i]["col"]), want["layers"][i]["col"]), (trial, i, fanouts, nseed)
+        del bs
+    assert ops.device_status() == 0
+
+
 def test_heavy_wait_changes_timing_not_results(ops):
     """ggms_sample_extra_t.heavy_wait: the last layer's sampler launch waits for an event recorded on another stream
     (a feature gather, in the pipeline).  Whatever the event, the batch is the oracle's."""
