@@ -431,7 +431,8 @@ def test_sample_weighted_khop_hash_dedup(ops, graphs, gname, n, fanout):
 @pytest.mark.parametrize("gname,n,wl,p,nw,K", [("small", 1, 3, 0.5, 4, 5), ("small", 300, 3, 0.5, 4, 5),
                                                ("small", 0, 3, 0.5, 4, 5), ("mid", 8000, 3, 0.5, 4, 5),
                                                ("mid", 5000, 4, 0.2, 5, 3), ("mid", 3000, 10, 0.1, 10, 20),
-                                               ("mid", 1000, 2, 0.0, 1, 1)])
+                                               ("mid", 1000, 2, 0.0, 1, 1), ("mid", 4000, 6, 0.1, 6, 10),
+                                               ("mid", 2000, 8, 0.05, 16, 128), ("mid", 70000, 3, 0.5, 4, 5)])
 def test_sample_random_walk(ops, graphs, gname, n, wl, p, nw, K):
     """PinSAGE neighbourhood: walks with restart + per-seed top-K by visit count (ties: first visit)."""
     ip, ix, g = graphs[gname]

@@ -42,7 +42,9 @@ size_t random_walk_ws_words(size_t num_input, size_t walk_length, size_t num_wal
 int sample_random_walk_impl(GraphView g, const uint32_t *input, size_t n_max, Count n, uint32_t walk_length,
                             double restart_prob, uint32_t num_walk, uint32_t K, uint32_t *out_src, uint32_t *out_dst,
                             uint32_t *out_data, uint64_t *num_out_dev, uint32_t *states, uint32_t *workspace,
-                            const uint32_t *seed_local, int src_local, hipStream_t s, ScanArea *shared_scan = nullptr);
+                            const uint32_t *seed_local, int src_local, hipStream_t s, ScanArea *shared_scan,
+                            const DedupInsert *insert);
+size_t walk_scan_tiles(size_t num_input);
 
 int sample_weighted_hash_dedup_impl(const uint32_t *indptr, const uint32_t *indices, const float *prob,
                                     const uint32_t *alias, const uint32_t *input, size_t n_max, Count n,

@@ -131,6 +131,7 @@ static BatchLayout layout_of(int sample_type, size_t num_seeds, const size_t *fa
   // ONE scan area for the batch: sampler offsets (tiles of 128 seeds), owner scans (tiles of 2048 items), the
   // generic tile scans of the other samplers (<= kSinglePassTiles descriptors, else three launches)
   l.scan_tiles = std::max<size_t>({c.max_in_all / 128 + 2, owner_scan_tiles(l.dedup_items) + 2, kSinglePassTiles + 2});
+  if (sample_type == GGMS_RANDOM_WALK) l.scan_tiles = std::max(l.scan_tiles, walk_scan_tiles(c.max_in_all));
   l.scan = w;
   w += up4(std::max(tile_scan_words(std::max(c.max_e_all, c.max_in_all)), 8 + 2 * l.scan_tiles + 4) + 16);
   l.total = w;
@@ -274,11 +275,13 @@ int ggms_sample_batch(int sample_type, const ggms_graph_t *graph, const ggms_id_
       rc = sample_weighted_impl(graph->indptr, graph->indices, extra->prob_table, extra->alias_table, input, n_max, n,
                                 (uint32_t)fanouts[i], col[i], tmp_dst, num_edge, (uint32_t *)states, samp_ws,
                                 first ? seed_local : nullptr, 1, s, &scan, graph->num_node);
-    } else { // random walk: fanout[i] = num_neighbor = K (operation.cc:174)
+    } else { // random walk: fanout[i] = num_neighbor = K (operation.cc:174); enters its output like khop3
+      inserted = ht->direct != 0 && e_max != 0;
+      if (inserted) di.tag = next_dedup_tag();
       rc = sample_random_walk_impl(g, input, n_max, n, (uint32_t)extra->random_walk_length,
                                    extra->random_walk_restart_prob, (uint32_t)extra->num_random_walk,
                                    (uint32_t)fanouts[i], col[i], tmp_dst, extra->data[i], num_edge, (uint32_t *)states,
-                                   samp_ws, first ? seed_local : nullptr, 1, s, &scan);
+                                   samp_ws, first ? seed_local : nullptr, 1, s, &scan, inserted ? &di : nullptr);
     }
     if (rc != GGMS_OK) return rc;
     if (i == 0 && extra && extra->rng_done) GGMS_HIP(hipEventRecord((hipEvent_t)extra->rng_done, s));

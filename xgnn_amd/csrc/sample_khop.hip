@@ -76,14 +76,6 @@ __device__ __forceinline__ uint32_t row_shr(uint32_t v) {
   return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x110 + S, 0xf, 0xf, true);
 }
 
-struct FusedScan {
-  uint32_t *ctl;             // {ticket, done}
-  unsigned long long *desc;  // one descriptor per 128-seed tile
-  uint32_t epoch;
-  uint64_t *num_out;         // total number of edges
-  uint32_t *err;
-};
-
 // Only seeds with more neighbours than `fanout` enter the serial loop; the "take them all" seeds consume no
 // draws.  GPW = groups per wave64: 4 packs the lanes (large frontiers: the loop is issue-bound), 1 gives every
 // group a wave of its own (small frontiers: the chip has idle SIMDs and a group no longer waits for its three
@@ -277,6 +269,8 @@ __global__ __launch_bounds__(128 * (4 / GPW)) void k_khop3_fused(GraphView g, co
     // for a "take them all" seed and the sampler's pick otherwise; written out as (src value, neighbour id)
     const uint32_t prefix = s_prefix;
     const uint32_t slots = 128u * fanout;
+    // (one slot per lane and round: handling four at a time -- loads, then atomics, in flight together -- costs
+    // registers and measured 5 % SLOWER sampling on papers100M)
     for (uint32_t t = threadIdx.x; t < slots; t += NT) {
       // s = t / fanout (t < 2^14): mulhi by ceil(2^32 / fanout), one fix-up
       uint32_t sd = fanout == 1 ? t : __umulhi(t, fanout_magic);

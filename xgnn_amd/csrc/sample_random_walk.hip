@@ -66,84 +66,144 @@ __global__ __launch_bounds__(kBlock) void k_random_walk(GraphView g, const uint3
   }
 }
 
-// One lane per seed: distinct visited nodes + counts in first-visit order, then K stable arg-max picks.
-__global__ __launch_bounds__(kWave) void k_walk_topk(const uint32_t *__restrict__ tmp_src,
-                                                     const uint32_t *__restrict__ tmp_dst, Count n_arg, uint64_t stride,
-                                                     uint32_t per,
-                                                     uint32_t K, uint32_t *__restrict__ pad_dst,
-                                                     uint32_t *__restrict__ pad_cnt, uint32_t *__restrict__ num_top) {
-  extern __shared__ uint32_t lds[]; // uniq[per][64], cnt[per][64]
-  uint32_t *uniq = lds, *cnt = lds + per * kWave;
+// The rest of the layer in ONE launch: a workgroup takes a tile of T consecutive seeds from a ticket, one lane per seed
+//   1. collects the seed's distinct visited nodes + counts in first-visit order (its LDS column);
+//   2. scans take = min(distinct, K) over the tile and publishes the tile aggregate (decoupled look-back,
+//      tile_scan.h) -- compact_output_revised's offsets (cuda_frequency_hashmap.cu:500-532);
+//   3. makes its K stable arg-max picks (strict >, so ties keep the earlier visit: the stable descending sort of
+//      :733-746) and parks them at their place in the tile's compact slice, in LDS;
+//   4. wave 0 looks back for the tile's base offset (the predecessors published long ago: the wait hides behind 3);
+//   5. all lanes sweep the tile's slice edge by edge: (src, dst, count) written coalesced and -- INSERT, direct
+//      dedup table -- the visited node entered into the table (DedupInsert::enter), one atomic per lane per round
+//      instead of K dependent ones.
+template <uint32_t T, bool INSERT>
+__global__ __launch_bounds__(T) void k_walk_topk_emit(const uint32_t *__restrict__ tmp_src,
+                                                      const uint32_t *__restrict__ tmp_dst, Count n_arg,
+                                                      uint64_t stride, uint32_t per, uint32_t K, uint32_t Kc,
+                                                      const uint32_t *__restrict__ input, SrcMode sm,
+                                                      uint32_t *__restrict__ out_src, uint32_t *__restrict__ out_dst,
+                                                      uint32_t *__restrict__ out_data, FusedScan fs, DedupInsert di) {
+  constexpr uint32_t FLAG_A = 1, FLAG_P = 2, W = T / kWave;
+  extern __shared__ uint32_t lds[]; // uniq[per][T], cnt[per][T], stage_dst[Kc * T], stage_cnt[Kc * T]
+  uint32_t *uniq = lds, *cnt = lds + per * T, *stage_dst = cnt + per * T, *stage_cnt = stage_dst + Kc * T;
+  __shared__ uint32_t s_wsum[W], s_tile, s_prefix;
   const uint64_t n = n_arg.get();
-  const uint32_t lane = threadIdx.x;
-  for (uint64_t s = (uint64_t)blockIdx.x * kWave + lane; s < n; s += (uint64_t)gridDim.x * kWave) {
+  const uint64_t num_tiles = (n + T - 1) / T;
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
+  for (;;) {
+    if (tid == 0) s_tile = atomicAdd(&fs.ctl[0], 1u);
+    __syncthreads();
+    const uint64_t b = s_tile;
+    if (b >= num_tiles) break;
+    const uint64_t s = b * T + tid;
+    // ---- 1
     uint32_t nu = 0;
-    for (uint32_t e0 = 0; e0 < per; e0 += 8) { // 16 independent loads in flight, then the serial bookkeeping
-      uint32_t sv[8], dv[8];
+    if (s < n) {
+      for (uint32_t e0 = 0; e0 < per; e0 += 8) { // 16 independent loads in flight, then the serial bookkeeping
+        uint32_t sv[8], dv[8];
 #pragma unroll
-      for (uint32_t k = 0; k < 8; ++k) {
-        const uint64_t idx = (uint64_t)(e0 + k) * stride + s;
-        sv[k] = (e0 + k < per) ? tmp_src[idx] : kEmptyKey;
-        dv[k] = (e0 + k < per) ? tmp_dst[idx] : 0u; // tmp_dst of an empty visit is never written: value unused
-      }
+        for (uint32_t k = 0; k < 8; ++k) {
+          const uint64_t idx = (uint64_t)(e0 + k) * stride + s;
+          sv[k] = (e0 + k < per) ? tmp_src[idx] : kEmptyKey;
+          dv[k] = (e0 + k < per) ? tmp_dst[idx] : 0u; // tmp_dst of an empty visit is never written: value unused
+        }
 #pragma unroll
-      for (uint32_t k = 0; k < 8; ++k) {
-        if (sv[k] == kEmptyKey) continue;
-        const uint32_t d = dv[k];
-        uint32_t u = 0;
-        for (; u < nu; ++u)
-          if (uniq[u * kWave + lane] == d) break;
-        if (u == nu) {
-          uniq[nu * kWave + lane] = d;
-          cnt[nu * kWave + lane] = 1;
-          ++nu;
-        } else {
-          cnt[u * kWave + lane] += 1;
+        for (uint32_t k = 0; k < 8; ++k) {
+          if (sv[k] == kEmptyKey) continue;
+          const uint32_t d = dv[k];
+          uint32_t u = 0;
+          for (; u < nu; ++u)
+            if (uniq[u * T + tid] == d) break;
+          if (u == nu) {
+            uniq[nu * T + tid] = d;
+            cnt[nu * T + tid] = 1;
+            ++nu;
+          } else {
+            cnt[u * T + tid] += 1;
+          }
         }
       }
     }
+    // ---- 2
     const uint32_t take = nu < K ? nu : K;
+    const uint32_t incl = wave_inclusive_scan(take);
+    if (lane == 63) s_wsum[wv] = incl;
+    __syncthreads();
+    uint32_t before = 0, total = 0;
+#pragma unroll
+    for (uint32_t i = 0; i < W; ++i) {
+      const uint32_t x = s_wsum[i];
+      if (i < wv) before += x;
+      total += x;
+    }
+    if (tid == 0)
+      __hip_atomic_store(&fs.desc[b], scan_desc(fs.epoch, b == 0 ? FLAG_P : FLAG_A, total), __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_AGENT);
+    // ---- 3
+    const uint32_t at = before + incl - take;
     for (uint32_t k = 0; k < take; ++k) {
       uint32_t best = 0, best_c = 0;
       for (uint32_t u = 0; u < nu; ++u) {
-        const uint32_t c = cnt[u * kWave + lane];
-        if (c > best_c) { best_c = c; best = u; } // strict: ties keep the earlier visit
+        const uint32_t c = cnt[u * T + tid];
+        if (c > best_c) { best_c = c; best = u; }
       }
-      pad_dst[s * K + k] = uniq[best * kWave + lane];
-      pad_cnt[s * K + k] = best_c;
-      cnt[best * kWave + lane] = 0; // taken
+      stage_dst[at + k] = uniq[best * T + tid];
+      stage_cnt[at + k] = (tid << 8) | best_c; // count <= per <= 128
+      cnt[best * T + tid] = 0; // taken
     }
-    num_top[s] = take;
+    // ---- 4
+    if (tid < kWave) {
+      uint32_t prefix = 0;
+      if (b != 0) {
+        prefix = scan_lookback(fs.desc, b, fs.epoch, fs.err);
+        if (lane == 0)
+          __hip_atomic_store(&fs.desc[b], scan_desc(fs.epoch, FLAG_P, prefix + total), __ATOMIC_RELAXED,
+                             __HIP_MEMORY_SCOPE_AGENT);
+      }
+      if (lane == 0) {
+        s_prefix = prefix;
+        if (b + 1 == num_tiles) *fs.num_out = (uint64_t)prefix + total;
+      }
+    }
+    __syncthreads();
+    // ---- 5
+    const uint32_t prefix = s_prefix;
+    for (uint32_t o = tid; o < total; o += T) { // (four slots per lane and round measured no faster)
+      const uint32_t d = stage_dst[o], pc = stage_cnt[o];
+      const uint64_t index = b * T + (pc >> 8);
+      const uint32_t e = prefix + o;
+      out_src[e] = sm.local ? sm.value(0u, index) : input[index];
+      out_dst[e] = d;
+      out_data[e] = pc & 0xffu;
+      if (INSERT) di.enter(d, e);
+    }
+    __syncthreads(); // LDS is rewritten by the next tile
+  }
+  if (tid == 0) {
+    if (num_tiles == 0 && blockIdx.x == 0) *fs.num_out = 0;
+    if (atomicAdd(&fs.ctl[1], 1u) == gridDim.x - 1) { // the last block out re-arms the ticket
+      fs.ctl[0] = 0;
+      fs.ctl[1] = 0;
+    }
   }
 }
-
-struct TopCount {
-  const uint32_t *num_top;
-  __device__ __forceinline__ uint32_t operator()(uint64_t s) const { return num_top[s]; }
-};
-struct TopEmit { // compact_output_revised, cuda_frequency_hashmap.cu:500-532
-  const uint32_t *input, *pad_dst, *pad_cnt;
-  uint32_t K;
-  uint32_t *out_src, *out_dst, *out_data;
-  const uint32_t *seed_local;
-  int src_local;
-  __device__ __forceinline__ void operator()(uint64_t s, uint32_t take, uint32_t at) const {
-    const uint32_t sv = src_local ? (seed_local ? seed_local[s] : (uint32_t)s) : input[s];
-    for (uint32_t k = 0; k < take; ++k) {
-      out_src[at + k] = sv;
-      out_dst[at + k] = pad_dst[s * K + k];
-      out_data[at + k] = pad_cnt[s * K + k];
-    }
-  }
-};
 
 static void walk_block_shape(uint32_t num_walk, uint32_t &bx, uint32_t &by) {
   bx = kBlock; by = 1; // dim3 block(kCudaBlockSize, 1); while (x >= 2 * num_walk) { x /= 2; y *= 2; }  (:132-136)
   while (bx >= 2 * num_walk) { bx /= 2; by *= 2; }
 }
 
+// tile of the top-K kernel: the largest whose LDS (columns + staging) stays within 64 KB, down to one wave
+static uint32_t walk_tile(uint32_t per, uint32_t Kc) {
+  if (per + Kc <= 32) return 256;
+  if (per + Kc <= 64) return 128;
+  return 64; // per + Kc <= 256: 128 KB
+}
+size_t walk_scan_tiles(size_t num_input) { return (num_input + 63) / 64 + 2; }
+
 size_t random_walk_ws_words(size_t num_input, size_t walk_length, size_t num_walk, size_t K) {
-  return 2 * num_input * walk_length * num_walk + 2 * num_input * K + num_input + tile_scan_words(num_input) + 64;
+  (void)K;
+  return 2 * num_input * walk_length * num_walk + 8 + 2 * walk_scan_tiles(num_input) + 64;
 }
 
 // tmp_src / tmp_dst: [walk_length * num_walk][n_max], visit-major
@@ -159,26 +219,63 @@ int random_walk_raw_impl(GraphView g, const uint32_t *input, size_t n_max, Count
   return GGMS_OK;
 }
 
+template <uint32_t T, bool INSERT>
+static void launch_topk_emit(int grid, size_t lds, hipStream_t s, const uint32_t *tmp_src, const uint32_t *tmp_dst,
+                             Count n, uint64_t stride, uint32_t per, uint32_t K, uint32_t Kc, const uint32_t *input,
+                             SrcMode sm, uint32_t *out_src, uint32_t *out_dst, uint32_t *out_data, FusedScan fs,
+                             DedupInsert di) {
+  if (lds > 48 * 1024) {
+    static const bool once = [] {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_walk_topk_emit<T, INSERT>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
+      return true;
+    }();
+    (void)once;
+  }
+  hipLaunchKernelGGL((k_walk_topk_emit<T, INSERT>), dim3(grid), dim3(T), lds, s, tmp_src, tmp_dst, n, stride, per, K,
+                     Kc, input, sm, out_src, out_dst, out_data, fs, di);
+}
+
+// shared_scan: the batch's scan area (cleared by the batch prologue); else the workspace holds a private one that
+// is cleared here.  insert (direct dedup table): the visited nodes are entered into the table on the way out.
 int sample_random_walk_impl(GraphView g, const uint32_t *input, size_t n_max, Count n, uint32_t walk_length,
                             double restart_prob, uint32_t num_walk, uint32_t K, uint32_t *out_src, uint32_t *out_dst,
                             uint32_t *out_data, uint64_t *num_out_dev, uint32_t *states, uint32_t *workspace,
-                            const uint32_t *seed_local, int src_local, hipStream_t s, ScanArea *shared_scan) {
+                            const uint32_t *seed_local, int src_local, hipStream_t s, ScanArea *shared_scan,
+                            const DedupInsert *insert) {
   const uint32_t per = walk_length * num_walk;
   uint32_t *w = workspace;
   uint32_t *tmp_src = w; w += n_max * per;
   uint32_t *tmp_dst = w; w += n_max * per;
-  uint32_t *pad_dst = w; w += n_max * K;
-  uint32_t *pad_cnt = w; w += n_max * K;
-  uint32_t *num_top = w; w += n_max;
-  uint32_t *scan_scr = w;
   int rc = random_walk_raw_impl(g, input, n_max, n, walk_length, restart_prob, num_walk, tmp_src, tmp_dst, states, s);
   if (rc != GGMS_OK) return rc;
-  hipLaunchKernelGGL(k_walk_topk, dim3(grid_for(n_max, kWave)), dim3(kWave), 2 * per * kWave * sizeof(uint32_t), s,
-                     tmp_src, tmp_dst, n, (uint64_t)n_max, per, K, pad_dst, pad_cnt, num_top);
+  const uint32_t Kc = K < per ? K : per;
+  const uint32_t T = walk_tile(per, Kc);
+  const size_t tiles = (n_max + T - 1) / T;
+  uint32_t *ctl = scan_align(shared_scan ? shared_scan->words : w);
+  if (!shared_scan || !shared_scan->cleared)
+    GGMS_HIP(hipMemsetAsync(ctl, 0, (8 + 2 * (tiles + 1)) * sizeof(uint32_t), s));
+  const FusedScan fs{ctl, reinterpret_cast<unsigned long long *>(ctl + 8), next_scan_epoch(), num_out_dev,
+                     device_status_word()};
+  const SrcMode sm{seed_local, src_local};
+  const size_t lds = 2 * (size_t)(per + Kc) * T * sizeof(uint32_t);
+  const int grid = grid_for(tiles, 1);
+  const DedupInsert none{};
+#define GGMS_TOPK(TT)                                                                                              \
+  do {                                                                                                             \
+    if (insert)                                                                                                    \
+      launch_topk_emit<TT, true>(grid, lds, s, tmp_src, tmp_dst, n, (uint64_t)n_max, per, K, Kc, input, sm, out_src, \
+                                 out_dst, out_data, fs, *insert);                                                  \
+    else                                                                                                           \
+      launch_topk_emit<TT, false>(grid, lds, s, tmp_src, tmp_dst, n, (uint64_t)n_max, per, K, Kc, input, sm,       \
+                                  out_src, out_dst, out_data, fs, none);                                           \
+  } while (0)
+  if (T == 256) GGMS_TOPK(256);
+  else if (T == 128) GGMS_TOPK(128);
+  else GGMS_TOPK(64);
+#undef GGMS_TOPK
   GGMS_LAUNCH_CHECK();
-  const ScanArea sa = shared_scan ? *shared_scan : ScanArea{scan_scr, false};
-  return tile_scan(TopCount{num_top}, TopEmit{input, pad_dst, pad_cnt, K, out_src, out_dst, out_data, seed_local, src_local},
-                   n_max, n, sa, nullptr, nullptr, num_out_dev, s);
+  return GGMS_OK;
 }
 
 } // namespace ggms
@@ -214,7 +311,7 @@ int ggms_sample_random_walk(const ggms_graph_t *graph, const ggms_id_t *input, s
   GGMS_CHECK_ARG(ggms_random_walk_num_states(num_input, num_walk) <= num_states); // assert(thread_id < num_random_states)
   return sample_random_walk_impl(view_of(graph), input, num_input, count_of(num_input), (uint32_t)walk_length,
                                  restart_prob, (uint32_t)num_walk, (uint32_t)K, out_src, out_dst, out_data, num_out_dev,
-                                 (uint32_t *)states, (uint32_t *)workspace, nullptr, 0, s);
+                                 (uint32_t *)states, (uint32_t *)workspace, nullptr, 0, s, nullptr, nullptr);
 }
 
 } // extern "C"

@@ -97,6 +97,15 @@ __device__ __forceinline__ uint32_t scan_lookback(const unsigned long long *desc
   return acc;
 }
 
+// what a sampler kernel that scans its own tiles (k_khop3_fused, k_walk_topk_emit) needs of a scan area
+struct FusedScan {
+  uint32_t *ctl;             // {ticket, done}
+  unsigned long long *desc;  // one descriptor per tile
+  uint32_t epoch;
+  uint64_t *num_out;         // total number of edges
+  uint32_t *err;
+};
+
 template <typename ValueF, typename EmitF>
 __global__ __launch_bounds__(kBlock) void k_tile_scan(ValueF value, EmitF emit, Count n_arg, uint32_t *ctl,
                                                       unsigned long long *desc, uint32_t epoch,
