@@ -18,8 +18,11 @@ from xgnn_amd import datagen, ops  # noqa: E402
 
 nb = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 stype = sys.argv[2] if len(sys.argv) > 2 else "khop3"
-code = {"khop3": ops.KHOP3, "khop0": ops.KHOP0, "khop1": ops.KHOP1}[stype]
-ocode = {"khop3": oracle.KHOP3, "khop0": oracle.KHOP0, "khop1": oracle.KHOP1}[stype]
+code = {"khop3": ops.KHOP3, "khop0": ops.KHOP0, "khop1": ops.KHOP1, "random_walk": ops.RANDOM_WALK}[stype]
+ocode = {"khop3": oracle.KHOP3, "khop0": oracle.KHOP0, "khop1": oracle.KHOP1, "random_walk": oracle.RANDOM_WALK}[stype]
+walk = stype == "random_walk"  # PinSAGE defaults (sgnn/train_pinsage.py:138-142)
+kw = dict(random_walk_length=3, random_walk_restart_prob=0.5, num_random_walk=4) if walk else {}
+okw = dict(walk_length=3, restart_prob=0.5, num_walk=4) if walk else {}
 dev = torch.device("cuda", 0)
 g = datagen.make_graph("products", seed=42)
 ip, ix = g["indptr"], g["indices"]
@@ -28,9 +31,9 @@ graph = ops.DeviceGraph(to_dev(ip), to_dev(ix))
 u32 = lambda t, n: t[:n].cpu().numpy().view(np.uint32)  # noqa: E731
 noise_src = torch.empty((1 << 28,), dtype=torch.float32, device=dev)
 noise_dst = torch.empty_like(noise_src)
-for fanouts in ([25, 10], [5, 10, 15]):
+for fanouts in ([5, 5, 5], [10, 5]) if walk else ([25, 10], [5, 10, 15]):
     K, L = 2, len(fanouts)
-    bs = ops.BatchSampler(graph, fanouts, 8000, sample_type=code, seed=123, num_slots=nb, num_pipelines=K)
+    bs = ops.BatchSampler(graph, fanouts, 8000, sample_type=code, seed=123, num_slots=nb, num_pipelines=K, **kw)
     states = oracle.random_states(bs.states.shape[0], 123) if stype != "khop0" else None
     rng = np.random.RandomState(1)
     seeds = [g["train_set"][rng.permutation(g["train_set"].size)[:8000]] for _ in range(nb)]
@@ -47,7 +50,7 @@ for fanouts in ([25, 10], [5, 10, 15]):
     torch.cuda.synchronize()
     assert ops.device_status() == 0
     for b in range(nb):
-        want = oracle.do_sample(ocode, ip, ix, seeds[b], fanouts, states)
+        want = oracle.do_sample(ocode, ip, ix, seeds[b], fanouts, states, **okw)
         c = bs.counts_slots[b].cpu().tolist()
         assert np.array_equal(u32(bs.input_nodes[b], c[3 * L]), want["input_nodes"]), (fanouts, b, "input_nodes")
         for i in range(L):
@@ -55,6 +58,8 @@ for fanouts in ([25, 10], [5, 10, 15]):
             assert (c[3 * i], c[3 * i + 1], c[3 * i + 2]) == (wl["row"].size, wl["num_src"], wl["num_dst"]), (fanouts, b, i)
             assert np.array_equal(u32(bs.rows[b][i], c[3 * i]), wl["row"]), (fanouts, b, i, "row")
             assert np.array_equal(u32(bs.cols[b][i], c[3 * i]), wl["col"]), (fanouts, b, i, "col")
+            if walk:
+                assert np.array_equal(u32(bs.datas[b][i], c[3 * i]), wl["data"]), (fanouts, b, i, "data")
     print(f"soak ok: {stype} {fanouts}: {nb} batches of 8000 seeds on {K} pipelines, all equal to the oracle "
           f"({time.time() - t0:.1f} s)", flush=True)
     del bs
