@@ -198,7 +198,8 @@ int ggms_sample_weighted_khop(const ggms_graph_t *graph, const float *prob_table
 /* GPUSampleRandomWalk + FrequencyHashmap::GetTopK, cuda/cuda_sampling_random_walk.cu:116-165,
  * cuda/cuda_frequency_hashmap.cu:643-841: per seed, num_walk walks of walk_length steps with restart;
  * output = the K most visited nodes per seed (count descending, ties by first visit), seeds in input order;
- * out_data = visit count.  out_* hold num_input * K entries.  walk_length * num_walk <= 128. */
+ * out_data = visit count.  out_* hold num_input * K entries.  Up to 128 visits per seed
+ * (walk_length * num_walk; PinSAGE's defaults: 12) are ranked in LDS, more in the visit scratch itself (slower). */
 size_t ggms_sample_random_walk_workspace_bytes(size_t num_input, size_t walk_length,
                                                size_t num_walk, size_t K);
 size_t ggms_random_walk_num_states(size_t num_input, size_t num_walk); /* cuda_random_states.cu:48-60 */

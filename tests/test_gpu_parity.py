@@ -111,17 +111,28 @@ def test_mock_extract(ops, bits):
     assert got.cpu().numpy().tobytes() == table[idx & ((1 << bits) - 1)].tobytes()
 
 
-def test_extract_row_size_limits(ops):
-    """Rows up to 8191 chunks of 16 B (131 056 B) go through the gather; wider rows are refused, not mangled."""
+def test_extract_row_sizes_around_the_tile_sweep_limit(ops):
+    """Rows up to 8191 chunks of 16 B (131 056 B) go through the tile sweep, wider ones through the one-row-per-
+    workgroup kernel; odd widths pick narrower chunks.  All bit-exact, cached / miss-counted variant included."""
     rng = np.random.RandomState(4)
-    dim = 4 * 8191
-    table = rng.standard_normal((40, dim)).astype(np.float32)
-    idx = rng.randint(0, 40, 23).astype(np.uint32)
-    out = ops.extract(dev(table), dev(idx))
-    assert out.cpu().numpy().tobytes() == oracle.extract(table, idx).tobytes()
-    wide = torch.zeros((4, 4 * 8192), dtype=torch.float32, device="cuda")
-    with pytest.raises(RuntimeError):
-        ops.extract(wide, dev(np.array([1, 2], np.uint32)))
+    for dim, dtype in ((4 * 8191, np.float32), (4 * 8192, np.float32), (4 * 8192 + 4, np.float32),
+                       (40001, np.float32), (70001, np.uint8), (300001, np.uint8)):
+        table = rng.randint(0, 250, (40, dim)).astype(dtype)
+        idx = rng.randint(0, 40, 23).astype(np.uint32)
+        out = ops.extract(dev(table), dev(idx))
+        assert out.cpu().numpy().tobytes() == oracle.extract(table, idx).tobytes(), dim
+    # a cached gather of long rows over 2 shards: 40 % of the nodes cached, the others read from the "host" copy
+    dim, N, P = 4 * 9000, 64, 2
+    feat = rng.randint(0, 1000, (N, dim)).astype(np.float32)
+    rank_s, table = oracle.cache_build(rng.permutation(N).astype(np.uint32), 26, True)
+    parts = [dev(oracle.partition_feature(feat, rank_s, 26, p, P)) for p in range(P)]
+    ptab = ops.part_pointer_table(parts, "cuda")
+    nodes = rng.randint(0, N, 50).astype(np.uint32)
+    out = torch.zeros((50, dim), dtype=torch.float32, device="cuda")
+    nmiss = torch.zeros(1, dtype=torch.int64, device="cuda")
+    ops.extract_cached(out, dev(nodes), dev(table), ptab, P, dev(feat), num_miss=nmiss)
+    assert out.cpu().numpy().tobytes() == feat[nodes].tobytes()
+    assert int(nmiss.item()) == int((table[nodes] == 0xFFFFFFFF).sum())
 
 
 def test_extract_large_properties(ops):
@@ -432,7 +443,8 @@ def test_sample_weighted_khop_hash_dedup(ops, graphs, gname, n, fanout):
                                                ("small", 0, 3, 0.5, 4, 5), ("mid", 8000, 3, 0.5, 4, 5),
                                                ("mid", 5000, 4, 0.2, 5, 3), ("mid", 3000, 10, 0.1, 10, 20),
                                                ("mid", 1000, 2, 0.0, 1, 1), ("mid", 4000, 6, 0.1, 6, 10),
-                                               ("mid", 2000, 8, 0.05, 16, 128), ("mid", 70000, 3, 0.5, 4, 5)])
+                                               ("mid", 2000, 8, 0.05, 16, 128), ("mid", 70000, 3, 0.5, 4, 5),
+                                               ("mid", 600, 20, 0.02, 10, 7), ("mid", 150, 2, 0.1, 300, 400)])
 def test_sample_random_walk(ops, graphs, gname, n, wl, p, nw, K):
     """PinSAGE neighbourhood: walks with restart + per-seed top-K by visit count (ties: first visit)."""
     ip, ix, g = graphs[gname]
@@ -535,7 +547,7 @@ def test_partition_cache_paths(ops, P, dim):
 
 
 # ------------------------------------------- per-list limits and long lists
-@pytest.mark.parametrize("sampler,fanout", [("khop3", 127), ("khop3", 100), ("khop0", 2048), ("khop0", 100),
+@pytest.mark.parametrize("sampler,fanout", [("khop3", 127), ("khop3", 100), ("khop0", 2048), ("khop0", 100), ("khop0", 4000),
                                             ("khop0", 7), ("khop2", 300), ("khop1", 40)])
 def test_samplers_on_hub_graph(ops, sampler, fanout):
     """Six 6000-neighbour lists among short ones: khop3 at its fanout limit (127, khop3.cu:85), khop0 at its LDS slot
@@ -571,6 +583,37 @@ def test_samplers_on_hub_graph(ops, sampler, fanout):
         np.testing.assert_array_equal(host_u32(got[0], m), want[0])
         np.testing.assert_array_equal(host_u32(got[1], m), want[1])
     np.testing.assert_array_equal(host_u32(t_ix), ix_orc)
+
+
+@pytest.mark.parametrize("fanout", [2049, 3000])
+def test_khop0_fanout_beyond_the_lds_slots(ops, fanout):
+    """khop0 with more reservoir slots than LDS holds (fanout > 2048; the reference has no bound): the slots live in
+    the seed's slice of the output until the neighbours replace them.  Lists shorter than, just above (16-lane
+    resolve) and far above (whole-block resolve) the fanout; leaf operator and batch (fused dedup insert)."""
+    rng = np.random.RandomState(fanout)
+    N = 1500
+    deg = rng.choice([0, 9, 2300, 2600, 3100, 3600, 6000], size=N, p=[0.05, 0.55, 0.08, 0.08, 0.08, 0.08, 0.08])
+    ip = np.zeros(N + 1, np.uint32)
+    ip[1:] = np.cumsum(deg)
+    ix = rng.randint(0, N, int(ip[-1])).astype(np.uint32)
+    g = ops.DeviceGraph(dev(ip), dev(ix))
+    inp = rng.permutation(N)[:400].astype(np.uint32)
+    for rep in range(2):
+        got = ops.sample_khop0(g, dev(inp), fanout)
+        want = oracle.sample_khop0(ip, ix, inp, fanout)
+        m = int(got[2].item())
+        assert m == want[0].size
+        np.testing.assert_array_equal(host_u32(got[0], m), want[0])
+        np.testing.assert_array_equal(host_u32(got[1], m), want[1])
+    for direct in (True, False):
+        bs = ops.BatchSampler(g, [fanout], 40, sample_type=ops.KHOP0, seed=3, direct_table=direct)
+        seeds = inp[:40]
+        bs.sample(dev(seeds))
+        r = bs.result()
+        want = oracle.do_sample(oracle.KHOP0, ip, ix, seeds, [fanout], None)
+        np.testing.assert_array_equal(host_u32(r["input_nodes"]), want["input_nodes"])
+        np.testing.assert_array_equal(host_u32(r["layers"][0]["row"]), want["layers"][0]["row"])
+        np.testing.assert_array_equal(host_u32(r["layers"][0]["col"]), want["layers"][0]["col"])
 
 
 # ------------------------------------------------------- multi-layer batch
@@ -737,9 +780,10 @@ def test_heavy_wait_changes_timing_not_results(ops):
             np.testing.assert_array_equal(host_u32(got["layers"][i]["col"]), want["layers"][i]["col"])
 
 
-@pytest.mark.parametrize("stype", ["weighted", "random_walk"])
+@pytest.mark.parametrize("stype", ["weighted", "random_walk", "random_walk_long"])
 def test_sample_batch_weighted_and_random_walk(ops, stype):
-    """DoGPUSample with the weighted (alias) sampler and with PinSAGE random walks (row/col/data)."""
+    """DoGPUSample with the weighted (alias) sampler and with PinSAGE random walks (row/col/data); _long: 135 visits
+    per seed, beyond what the top-K kernel ranks in LDS (its spilling variant)."""
     ip, ix = powerlaw_csr(20_000, mean_deg=30, seed=2)
     N = ip.size - 1
     g = ops.DeviceGraph(dev(ip), dev(ix))
@@ -754,10 +798,11 @@ def test_sample_batch_weighted_and_random_walk(ops, stype):
         kw = dict(prob=prob, alias=alias)
         code = oracle.WEIGHTED_KHOP
     else:
-        fanouts = [5, 5, 5]  # num_neighbor per layer
-        bs = ops.BatchSampler(g, fanouts, 500, sample_type=ops.RANDOM_WALK, seed=5, random_walk_length=3,
-                              random_walk_restart_prob=0.5, num_random_walk=4)
-        kw = dict(walk_length=3, restart_prob=0.5, num_walk=4)
+        wl_, p_, nw_ = (3, 0.5, 4) if stype == "random_walk" else (15, 0.05, 9)
+        fanouts = [5, 5, 5] if stype == "random_walk" else [6, 40]  # num_neighbor per layer
+        bs = ops.BatchSampler(g, fanouts, 500, sample_type=ops.RANDOM_WALK, seed=5, random_walk_length=wl_,
+                              random_walk_restart_prob=p_, num_random_walk=nw_)
+        kw = dict(walk_length=wl_, restart_prob=p_, num_walk=nw_)
         code = oracle.RANDOM_WALK
     orc_states = oracle.random_states(bs.states.shape[0], 5)
     for rep in range(2):
@@ -771,7 +816,7 @@ def test_sample_batch_weighted_and_random_walk(ops, stype):
             assert (gl["num_src"], gl["num_dst"]) == (wl["num_src"], wl["num_dst"]), (rep, i)
             np.testing.assert_array_equal(host_u32(gl["row"]), wl["row"])
             np.testing.assert_array_equal(host_u32(gl["col"]), wl["col"])
-            if stype == "random_walk":
+            if stype != "weighted":
                 np.testing.assert_array_equal(host_u32(gl["data"]), wl["data"])
 
 

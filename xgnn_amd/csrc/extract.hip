@@ -241,6 +241,26 @@ __global__ __launch_bounds__(kBlock) void k_gather_rows(char *__restrict__ out, 
   }
 }
 
+// Rows of 8192 chunks or more (>= 128 KiB at 16-byte chunks; the tile sweep's chunk -> row division is exact only
+// below that): every row is a long contiguous stream by itself, so one workgroup copies one row.
+template <int CB, typename Rows>
+__global__ __launch_bounds__(kBlock) void k_gather_long_rows(char *__restrict__ out, Rows rows,
+                                                             const uint32_t *__restrict__ dst_index, Count n_arg,
+                                                             uint64_t rc, uint64_t *miss_count) {
+  using V = typename ChunkT<CB>::type;
+  const uint64_t n = n_arg.get();
+  for (uint64_t i = blockIdx.x; i < n; i += gridDim.x) {
+    uint32_t tier = 0;
+    const uint64_t sp = (uint64_t)rows.row(i, tier);
+    const uint64_t dp = (uint64_t)(out + (dst_index ? (uint64_t)dst_index[i] : i) * rc * CB);
+    if (miss_count && threadIdx.x == 0) {
+      if (tier == kTierHost) atomicAdd((unsigned long long *)miss_count, 1ull);
+      else if (Rows::kTiers && tier >= kTierRemote) atomicAdd((unsigned long long *)miss_count + (tier - 1), 1ull);
+    }
+    for (uint64_t c = threadIdx.x; c < rc; c += kBlock) store_chunk<V, true>(dp + c * CB, load_chunk<V, true>(sp + c * CB));
+  }
+}
+
 // identity copy of `n` rows (src_index == dst_index == NULL): plain coalesced stream, count on the device
 __global__ __launch_bounds__(kBlock) void k_copy_words(uint32_t *__restrict__ dst, const uint32_t *__restrict__ src,
                                                        Count n_arg, uint32_t words_per_row) {
@@ -259,9 +279,21 @@ static int launch_gather(char *out, Rows rows, const uint32_t *dst_index, size_t
                          size_t row_bytes, int cb, uint64_t *miss_count, hipStream_t stream) {
   if (n_max == 0) return GGMS_OK;
   const uint64_t rc = row_bytes / cb;
-  if (rc == 0 || rc >= 8192) {
-    set_error("extract: row of %zu bytes in %d-byte chunks is outside the supported range", row_bytes, cb);
+  if (rc == 0) {
+    set_error("extract: empty rows");
     return GGMS_ERR_INVALID;
+  }
+  if (rc >= 8192) {
+    const int g = grid_for(n_max, 1);
+    switch (cb) {
+      case 16: hipLaunchKernelGGL((k_gather_long_rows<16, Rows>), dim3(g), dim3(kBlock), 0, stream, out, rows, dst_index, n, rc, miss_count); break;
+      case 8: hipLaunchKernelGGL((k_gather_long_rows<8, Rows>), dim3(g), dim3(kBlock), 0, stream, out, rows, dst_index, n, rc, miss_count); break;
+      case 4: hipLaunchKernelGGL((k_gather_long_rows<4, Rows>), dim3(g), dim3(kBlock), 0, stream, out, rows, dst_index, n, rc, miss_count); break;
+      case 2: hipLaunchKernelGGL((k_gather_long_rows<2, Rows>), dim3(g), dim3(kBlock), 0, stream, out, rows, dst_index, n, rc, miss_count); break;
+      default: hipLaunchKernelGGL((k_gather_long_rows<1, Rows>), dim3(g), dim3(kBlock), 0, stream, out, rows, dst_index, n, rc, miss_count); break;
+    }
+    GGMS_LAUNCH_CHECK();
+    return GGMS_OK;
   }
   // rows of a batch are read once: non-temporal loads by default (GGMS_EXTRACT_NT=0 turns them off)
   static const bool env_nt = [] { const char *e = getenv("GGMS_EXTRACT_NT"); return !(e && e[0] == '0'); }();

@@ -167,8 +167,7 @@ int ggms_sample_batch(int sample_type, const ggms_graph_t *graph, const ggms_id_
     for (uint32_t i = 0; i < num_layer; ++i) GGMS_CHECK_ARG(fanouts[i] > 0 && fanouts[i] < 50);
   }
   if (sample_type == GGMS_RANDOM_WALK)
-    GGMS_CHECK_ARG(extra && extra->data && extra->random_walk_length > 0 && extra->num_random_walk > 0 && states &&
-                   extra->random_walk_length * extra->num_random_walk <= 128);
+    GGMS_CHECK_ARG(extra && extra->data && extra->random_walk_length > 0 && extra->num_random_walk > 0 && states);
   hipStream_t s = to_stream(stream);
   const BatchCaps c = caps_of(num_seeds, fanouts, num_layer);
   GGMS_CHECK_ARG(c.max_input[0] + c.max_edges[0] <= ht->n2o_size);

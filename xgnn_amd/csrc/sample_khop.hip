@@ -319,6 +319,29 @@ struct DrawCount { // draws a seed consumes: one per neighbour position beyond t
   }
 };
 
+// Reservoir slots: LDS up to kKhop0LdsFanout; beyond that (BIG -- the reference has no bound, its slots are its
+// padded output array) the seed's slice of out_dst itself holds the winning positions until they are replaced by
+// the neighbours found there: the same atomicMax, on HBM, with agent-scope accesses instead of LDS ones.
+constexpr uint32_t kKhop0LdsFanout = 2048;
+template <bool BIG>
+__device__ __forceinline__ void slot_init(uint32_t *p, uint32_t v) {
+  if constexpr (BIG) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else *p = v;
+}
+template <bool BIG>
+__device__ __forceinline__ uint32_t slot_read(uint32_t *p) {
+  if constexpr (BIG) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else return *p;
+}
+template <bool BIG>
+__device__ __forceinline__ void slot_fence_wave() {
+  __builtin_amdgcn_wave_barrier();
+  if constexpr (BIG) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
+  else __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
+template <bool BIG>
 __global__ __launch_bounds__(128) void k_khop0_generate(GraphView g, const uint32_t *__restrict__ input, Count n_arg,
                                                         uint32_t fanout, const uint32_t *__restrict__ offset,
                                                         const uint32_t *__restrict__ draw_base,
@@ -330,7 +353,6 @@ __global__ __launch_bounds__(128) void k_khop0_generate(GraphView g, const uint3
   const uint64_t n = n_arg.get();
   const uint32_t x = threadIdx.x & 31, w = threadIdx.x >> 5;
   const uint32_t half = threadIdx.x & 32u; // first lane of my logical warp inside the wave64
-  uint32_t *my_slots = slot_j + w * fanout;
   const uint64_t num_blocks = (n + 63) / 64;
   if (blockIdx.x == 0 && threadIdx.x == 0) *heavy_count = 0u; // list filled by k_khop0_resolve
   uint32_t first_j = x;
@@ -363,17 +385,16 @@ __global__ __launch_bounds__(128) void k_khop0_generate(GraphView g, const uint3
       const uint32_t *edges = g.neighbours(rid, len2);
       const uint32_t o = offset[index];
       const uint32_t sv = sm.value(rid, index);
-      for (uint32_t s0 = x; s0 < fanout; s0 += 32) my_slots[s0] = s0; // slot s starts as position s
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      uint32_t *const my_slots = BIG ? out_dst + o : slot_j + w * fanout;
+      for (uint32_t s0 = x; s0 < fanout; s0 += 32) slot_init<BIG>(&my_slots[s0], s0); // slot s starts as position s
+      slot_fence_wave<BIG>();
       for (; j < len; j += 32) {
         const uint32_t kk = st.next() % (j + 1);
         if (kk < fanout) atomicMax(&my_slots[kk], j); // highest j wins
       }
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-      __builtin_amdgcn_wave_barrier();
+      slot_fence_wave<BIG>();
       for (uint32_t s0 = x; s0 < fanout; s0 += 32) {
-        const uint32_t nbr = edges[my_slots[s0]];
+        const uint32_t nbr = edges[slot_read<BIG>(&my_slots[s0])];
         out_src[o + s0] = sv;
         out_dst[o + s0] = nbr;
         if (di.w) di.enter(nbr, o + s0); // direct dedup table of the batch: entered where it is produced
@@ -410,6 +431,7 @@ __device__ __forceinline__ void khop0_resolve_draws(const uint32_t *__restrict__
 // 16 lanes per seed (4 seeds per wave, 16 per block): copy (deg <= fanout) or resolve the parked draws.  The
 // per-seed chain of dependent loads (id -> degree -> offsets -> draws -> neighbours) is what bounds this kernel,
 // so several seeds share a wave.
+template <bool BIG>
 __global__ __launch_bounds__(kBlock) void k_khop0_resolve(GraphView g, const uint32_t *__restrict__ input, Count n_arg,
                                                           uint32_t fanout, const uint32_t *__restrict__ offset,
                                                           const uint32_t *__restrict__ draw_base,
@@ -424,7 +446,6 @@ __global__ __launch_bounds__(kBlock) void k_khop0_resolve(GraphView g, const uin
   const uint64_t n = n_arg.get();
   const uint32_t lig = threadIdx.x & (G - 1), grp = threadIdx.x / G;
   if (grp >= groups) return; // wide fanouts: fewer seeds per block, the LDS slots decide
-  uint32_t *my_slots = slot_j + grp * fanout;
   const uint64_t stride = (uint64_t)gridDim.x * groups;
   for (uint64_t index = (uint64_t)blockIdx.x * groups + grp; index < n; index += stride) {
     const uint32_t rid = input[index];
@@ -447,14 +468,13 @@ __global__ __launch_bounds__(kBlock) void k_khop0_resolve(GraphView g, const uin
       if (lig == 0) heavy_list[atomicAdd(heavy_count, 1u)] = (uint32_t)index;
       continue;
     }
-    for (uint32_t s0 = lig; s0 < fanout; s0 += G) my_slots[s0] = s0;
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    uint32_t *const my_slots = BIG ? out_dst + o : slot_j + grp * fanout;
+    for (uint32_t s0 = lig; s0 < fanout; s0 += G) slot_init<BIG>(&my_slots[s0], s0);
+    slot_fence_wave<BIG>();
     khop0_resolve_draws(raw, base, extra, fanout, lig, G, my_slots);
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
+    slot_fence_wave<BIG>();
     for (uint32_t s0 = lig; s0 < fanout; s0 += G) {
-      const uint32_t nbr = edges[my_slots[s0]];
+      const uint32_t nbr = edges[slot_read<BIG>(&my_slots[s0])];
       out_src[o + s0] = sv;
       out_dst[o + s0] = nbr;
       if (di.w) di.enter(nbr, o + s0);
@@ -464,6 +484,7 @@ __global__ __launch_bounds__(kBlock) void k_khop0_resolve(GraphView g, const uin
 }
 
 // the long neighbour lists: one 1024-thread block per listed seed
+template <bool BIG>
 __global__ __launch_bounds__(1024) void k_khop0_resolve_heavy(GraphView g, const uint32_t *__restrict__ input,
                                                               uint32_t fanout, const uint32_t *__restrict__ offset,
                                                               const uint32_t *__restrict__ draw_base,
@@ -481,12 +502,15 @@ __global__ __launch_bounds__(1024) void k_khop0_resolve_heavy(GraphView g, const
     const uint32_t *edges = g.neighbours(rid, len);
     const uint32_t o = offset[index], base = draw_base[index];
     const uint32_t sv = sm.value(rid, index);
-    for (uint32_t s0 = threadIdx.x; s0 < fanout; s0 += 1024) slot_j[s0] = s0;
+    uint32_t *const slots = BIG ? out_dst + o : slot_j;
+    for (uint32_t s0 = threadIdx.x; s0 < fanout; s0 += 1024) slot_init<BIG>(&slots[s0], s0);
+    if constexpr (BIG) __threadfence();
     __syncthreads();
-    khop0_resolve_draws(raw, base, len - fanout, fanout, threadIdx.x, 1024, slot_j);
+    khop0_resolve_draws(raw, base, len - fanout, fanout, threadIdx.x, 1024, slots);
+    if constexpr (BIG) __threadfence();
     __syncthreads();
     for (uint32_t s0 = threadIdx.x; s0 < fanout; s0 += 1024) {
-      const uint32_t nbr = edges[slot_j[s0]];
+      const uint32_t nbr = edges[slot_read<BIG>(&slots[s0])];
       out_src[o + s0] = sv;
       out_dst[o + s0] = nbr;
       if (di.w) di.enter(nbr, o + s0);
@@ -648,19 +672,33 @@ int sample_khop0_impl(GraphView g, const uint32_t *input, size_t n_max, Count n,
   rc = tile_scan(DrawCount{g, input, fanout}, StoreOffset{draw_base}, n_max, n, sb, nullptr, nullptr, nullptr, s);
   if (rc != GGMS_OK) return rc;
   const SrcMode sm{seed_local, src_local};
-  const size_t lds = 4 * fanout * sizeof(uint32_t);
-  hipLaunchKernelGGL(k_khop0_generate, dim3(grid_for((n_max + 63) / 64, 1)), dim3(128), lds, s, g, input, n, fanout,
-                     offset, draw_base, raw, cap, out_src, out_dst, sm, heavy_count, di);
+  const bool big = fanout > kKhop0LdsFanout; // slots in the output array instead of LDS
+  const size_t lds = big ? 0 : 4 * fanout * sizeof(uint32_t);
+  const int grid_gen = grid_for((n_max + 63) / 64, 1);
+  if (big)
+    hipLaunchKernelGGL(k_khop0_generate<true>, dim3(grid_gen), dim3(128), lds, s, g, input, n, fanout, offset, draw_base,
+                       raw, cap, out_src, out_dst, sm, heavy_count, di);
+  else
+    hipLaunchKernelGGL(k_khop0_generate<false>, dim3(grid_gen), dim3(128), lds, s, g, input, n, fanout, offset,
+                       draw_base, raw, cap, out_src, out_dst, sm, heavy_count, di);
   GGMS_LAUNCH_CHECK();
   // seeds per 256-thread block of the resolve kernel: 16 lanes each, as many as 48 KB of LDS slots allow
-  const uint32_t groups = std::max<uint32_t>(1, std::min<uint32_t>(16, (48u << 10) / (4u * fanout)));
-  hipLaunchKernelGGL(k_khop0_resolve, dim3(grid_for(n_max, groups)), dim3(kBlock), groups * fanout * sizeof(uint32_t),
-                     s, g, input, n, fanout, offset, draw_base, raw, cap, out_src, out_dst, sm, heavy_count, heavy_list,
-                     groups, di);
+  const uint32_t groups = big ? 16u : std::max<uint32_t>(1, std::min<uint32_t>(16, (48u << 10) / (4u * fanout)));
+  if (big)
+    hipLaunchKernelGGL(k_khop0_resolve<true>, dim3(grid_for(n_max, groups)), dim3(kBlock), 0, s, g, input, n, fanout,
+                       offset, draw_base, raw, cap, out_src, out_dst, sm, heavy_count, heavy_list, groups, di);
+  else
+    hipLaunchKernelGGL(k_khop0_resolve<false>, dim3(grid_for(n_max, groups)), dim3(kBlock),
+                       groups * fanout * sizeof(uint32_t), s, g, input, n, fanout, offset, draw_base, raw, cap, out_src,
+                       out_dst, sm, heavy_count, heavy_list, groups, di);
   GGMS_LAUNCH_CHECK();
   // the few neighbour lists with more than kKhop0Heavy parked draws (none on most batches: the kernel then exits at once)
-  hipLaunchKernelGGL(k_khop0_resolve_heavy, dim3(256), dim3(1024), fanout * sizeof(uint32_t), s, g, input, fanout, offset,
-                     draw_base, raw, out_src, out_dst, sm, heavy_count, heavy_list, di);
+  if (big)
+    hipLaunchKernelGGL(k_khop0_resolve_heavy<true>, dim3(256), dim3(1024), 0, s, g, input, fanout, offset, draw_base, raw,
+                       out_src, out_dst, sm, heavy_count, heavy_list, di);
+  else
+    hipLaunchKernelGGL(k_khop0_resolve_heavy<false>, dim3(256), dim3(1024), fanout * sizeof(uint32_t), s, g, input,
+                       fanout, offset, draw_base, raw, out_src, out_dst, sm, heavy_count, heavy_list, di);
   GGMS_LAUNCH_CHECK();
   return GGMS_OK;
 }
@@ -716,7 +754,7 @@ int ggms_sample_khop0(const ggms_graph_t *graph, const ggms_id_t *input, size_t 
                       ggms_id_t *out_src, ggms_id_t *out_dst, uint64_t *num_out_dev, void *workspace,
                       size_t workspace_bytes, ggms_stream_t stream) {
   GGMS_CHECK_ARG(graph && num_out_dev);
-  GGMS_CHECK_ARG(fanout > 0 && fanout <= 2048); // LDS slots: 4 x fanout words in place, 16 x fanout in the resolver
+  GGMS_CHECK_ARG(fanout > 0);
   hipStream_t s = to_stream(stream);
   if (num_input == 0) {
     GGMS_HIP(hipMemsetAsync(num_out_dev, 0, sizeof(uint64_t), s));

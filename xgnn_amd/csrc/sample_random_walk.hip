@@ -19,7 +19,7 @@
 
 namespace ggms {
 
-constexpr uint32_t kMaxVisits = 128; // num_walk * walk_length supported per seed (LDS budget)
+constexpr uint32_t kLdsVisits = 128; // num_walk * walk_length up to which a seed's visits are ranked in LDS
 
 __global__ __launch_bounds__(kBlock) void k_random_walk(GraphView g, const uint32_t *__restrict__ input, Count n_arg,
                                                         uint32_t walk_length, double restart_prob, uint32_t num_walk,
@@ -76,16 +76,20 @@ __global__ __launch_bounds__(kBlock) void k_random_walk(GraphView g, const uint3
 //   5. all lanes sweep the tile's slice edge by edge: (src, dst, count) written coalesced and -- INSERT, direct
 //      dedup table -- the visited node entered into the table (DedupInsert::enter), one atomic per lane per round
 //      instead of K dependent ones.
-template <uint32_t T, bool INSERT>
-__global__ __launch_bounds__(T) void k_walk_topk_emit(const uint32_t *__restrict__ tmp_src,
-                                                      const uint32_t *__restrict__ tmp_dst, Count n_arg,
+//
+// SPILL (more than kLdsVisits visits per seed -- far beyond PinSAGE's 12; the reference has no such bound, its
+// edge tables live in HBM): the lane's column is its own visit slice of tmp_dst / tmp_src, compacted in place (the
+// u-th distinct node lands at or before the visit it was read from), and every lane writes its own picks.
+template <uint32_t T, bool INSERT, bool SPILL>
+__global__ __launch_bounds__(T) void k_walk_topk_emit(uint32_t *tmp_src, uint32_t *tmp_dst, Count n_arg,
                                                       uint64_t stride, uint32_t per, uint32_t K, uint32_t Kc,
                                                       const uint32_t *__restrict__ input, SrcMode sm,
                                                       uint32_t *__restrict__ out_src, uint32_t *__restrict__ out_dst,
                                                       uint32_t *__restrict__ out_data, FusedScan fs, DedupInsert di) {
   constexpr uint32_t FLAG_A = 1, FLAG_P = 2, W = T / kWave;
   extern __shared__ uint32_t lds[]; // uniq[per][T], cnt[per][T], stage_dst[Kc * T], stage_cnt[Kc * T]
-  uint32_t *uniq = lds, *cnt = lds + per * T, *stage_dst = cnt + per * T, *stage_cnt = stage_dst + Kc * T;
+  uint32_t *const uniq = SPILL ? tmp_dst : lds, *const cnt = SPILL ? tmp_src : lds + per * T;
+  uint32_t *const stage_dst = lds + 2 * per * T, *const stage_cnt = stage_dst + Kc * T; // !SPILL only
   __shared__ uint32_t s_wsum[W], s_tile, s_prefix;
   const uint64_t n = n_arg.get();
   const uint64_t num_tiles = (n + T - 1) / T;
@@ -96,6 +100,7 @@ __global__ __launch_bounds__(T) void k_walk_topk_emit(const uint32_t *__restrict
     const uint64_t b = s_tile;
     if (b >= num_tiles) break;
     const uint64_t s = b * T + tid;
+    const auto col = [&](uint32_t u) -> uint64_t { return SPILL ? (uint64_t)u * stride + s : (uint64_t)u * T + tid; };
     // ---- 1
     uint32_t nu = 0;
     if (s < n) {
@@ -113,13 +118,13 @@ __global__ __launch_bounds__(T) void k_walk_topk_emit(const uint32_t *__restrict
           const uint32_t d = dv[k];
           uint32_t u = 0;
           for (; u < nu; ++u)
-            if (uniq[u * T + tid] == d) break;
+            if (uniq[col(u)] == d) break;
           if (u == nu) {
-            uniq[nu * T + tid] = d;
-            cnt[nu * T + tid] = 1;
+            uniq[col(nu)] = d;
+            cnt[col(nu)] = 1;
             ++nu;
           } else {
-            cnt[u * T + tid] += 1;
+            cnt[col(u)] += 1;
           }
         }
       }
@@ -141,16 +146,17 @@ __global__ __launch_bounds__(T) void k_walk_topk_emit(const uint32_t *__restrict
                          __HIP_MEMORY_SCOPE_AGENT);
     // ---- 3
     const uint32_t at = before + incl - take;
-    for (uint32_t k = 0; k < take; ++k) {
-      uint32_t best = 0, best_c = 0;
-      for (uint32_t u = 0; u < nu; ++u) {
-        const uint32_t c = cnt[u * T + tid];
-        if (c > best_c) { best_c = c; best = u; }
+    if (!SPILL)
+      for (uint32_t k = 0; k < take; ++k) {
+        uint32_t best = 0, best_c = 0;
+        for (uint32_t u = 0; u < nu; ++u) {
+          const uint32_t c = cnt[col(u)];
+          if (c > best_c) { best_c = c; best = u; }
+        }
+        stage_dst[at + k] = uniq[col(best)];
+        stage_cnt[at + k] = (tid << 8) | best_c; // count <= per <= kLdsVisits
+        cnt[col(best)] = 0; // taken
       }
-      stage_dst[at + k] = uniq[best * T + tid];
-      stage_cnt[at + k] = (tid << 8) | best_c; // count <= per <= 128
-      cnt[best * T + tid] = 0; // taken
-    }
     // ---- 4
     if (tid < kWave) {
       uint32_t prefix = 0;
@@ -168,14 +174,31 @@ __global__ __launch_bounds__(T) void k_walk_topk_emit(const uint32_t *__restrict
     __syncthreads();
     // ---- 5
     const uint32_t prefix = s_prefix;
-    for (uint32_t o = tid; o < total; o += T) { // (four slots per lane and round measured no faster)
-      const uint32_t d = stage_dst[o], pc = stage_cnt[o];
-      const uint64_t index = b * T + (pc >> 8);
-      const uint32_t e = prefix + o;
-      out_src[e] = sm.local ? sm.value(0u, index) : input[index];
-      out_dst[e] = d;
-      out_data[e] = pc & 0xffu;
-      if (INSERT) di.enter(d, e);
+    if (SPILL) {
+      const uint32_t srcv = (s < n) ? (sm.local ? sm.value(0u, s) : input[s]) : 0u;
+      for (uint32_t k = 0; k < take; ++k) {
+        uint32_t best = 0, best_c = 0;
+        for (uint32_t u = 0; u < nu; ++u) {
+          const uint32_t c = cnt[col(u)];
+          if (c > best_c) { best_c = c; best = u; }
+        }
+        const uint32_t e = prefix + at + k, d = uniq[col(best)];
+        cnt[col(best)] = 0; // taken
+        out_src[e] = srcv;
+        out_dst[e] = d;
+        out_data[e] = best_c;
+        if (INSERT) di.enter(d, e);
+      }
+    } else {
+      for (uint32_t o = tid; o < total; o += T) { // (four slots per lane and round measured no faster)
+        const uint32_t d = stage_dst[o], pc = stage_cnt[o];
+        const uint64_t index = b * T + (pc >> 8);
+        const uint32_t e = prefix + o;
+        out_src[e] = sm.local ? sm.value(0u, index) : input[index];
+        out_dst[e] = d;
+        out_data[e] = pc & 0xffu;
+        if (INSERT) di.enter(d, e);
+      }
     }
     __syncthreads(); // LDS is rewritten by the next tile
   }
@@ -194,10 +217,11 @@ static void walk_block_shape(uint32_t num_walk, uint32_t &bx, uint32_t &by) {
 }
 
 // tile of the top-K kernel: the largest whose LDS (columns + staging) stays within 64 KB, down to one wave
+// (kLdsVisits visits, K = visits: 128 KB); beyond that the spilling variant, which uses no LDS
 static uint32_t walk_tile(uint32_t per, uint32_t Kc) {
   if (per + Kc <= 32) return 256;
   if (per + Kc <= 64) return 128;
-  return 64; // per + Kc <= 256: 128 KB
+  return 64;
 }
 size_t walk_scan_tiles(size_t num_input) { return (num_input + 63) / 64 + 2; }
 
@@ -219,20 +243,20 @@ int random_walk_raw_impl(GraphView g, const uint32_t *input, size_t n_max, Count
   return GGMS_OK;
 }
 
-template <uint32_t T, bool INSERT>
-static void launch_topk_emit(int grid, size_t lds, hipStream_t s, const uint32_t *tmp_src, const uint32_t *tmp_dst,
+template <uint32_t T, bool INSERT, bool SPILL>
+static void launch_topk_emit(int grid, size_t lds, hipStream_t s, uint32_t *tmp_src, uint32_t *tmp_dst,
                              Count n, uint64_t stride, uint32_t per, uint32_t K, uint32_t Kc, const uint32_t *input,
                              SrcMode sm, uint32_t *out_src, uint32_t *out_dst, uint32_t *out_data, FusedScan fs,
                              DedupInsert di) {
   if (lds > 48 * 1024) {
     static const bool once = [] {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_walk_topk_emit<T, INSERT>),
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_walk_topk_emit<T, INSERT, SPILL>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
       return true;
     }();
     (void)once;
   }
-  hipLaunchKernelGGL((k_walk_topk_emit<T, INSERT>), dim3(grid), dim3(T), lds, s, tmp_src, tmp_dst, n, stride, per, K,
+  hipLaunchKernelGGL((k_walk_topk_emit<T, INSERT, SPILL>), dim3(grid), dim3(T), lds, s, tmp_src, tmp_dst, n, stride, per, K,
                      Kc, input, sm, out_src, out_dst, out_data, fs, di);
 }
 
@@ -250,7 +274,7 @@ int sample_random_walk_impl(GraphView g, const uint32_t *input, size_t n_max, Co
   int rc = random_walk_raw_impl(g, input, n_max, n, walk_length, restart_prob, num_walk, tmp_src, tmp_dst, states, s);
   if (rc != GGMS_OK) return rc;
   const uint32_t Kc = K < per ? K : per;
-  const uint32_t T = walk_tile(per, Kc);
+  const uint32_t T = per > kLdsVisits ? 64u : walk_tile(per, Kc);
   const size_t tiles = (n_max + T - 1) / T;
   uint32_t *ctl = scan_align(shared_scan ? shared_scan->words : w);
   if (!shared_scan || !shared_scan->cleared)
@@ -258,21 +282,23 @@ int sample_random_walk_impl(GraphView g, const uint32_t *input, size_t n_max, Co
   const FusedScan fs{ctl, reinterpret_cast<unsigned long long *>(ctl + 8), next_scan_epoch(), num_out_dev,
                      device_status_word()};
   const SrcMode sm{seed_local, src_local};
-  const size_t lds = 2 * (size_t)(per + Kc) * T * sizeof(uint32_t);
+  const bool spill = per > kLdsVisits;
+  const size_t lds = spill ? 0 : 2 * (size_t)(per + Kc) * T * sizeof(uint32_t);
   const int grid = grid_for(tiles, 1);
   const DedupInsert none{};
-#define GGMS_TOPK(TT)                                                                                              \
+#define GGMS_TOPK(TT, SP)                                                                                          \
   do {                                                                                                             \
     if (insert)                                                                                                    \
-      launch_topk_emit<TT, true>(grid, lds, s, tmp_src, tmp_dst, n, (uint64_t)n_max, per, K, Kc, input, sm, out_src, \
-                                 out_dst, out_data, fs, *insert);                                                  \
+      launch_topk_emit<TT, true, SP>(grid, lds, s, tmp_src, tmp_dst, n, (uint64_t)n_max, per, K, Kc, input, sm,    \
+                                     out_src, out_dst, out_data, fs, *insert);                                     \
     else                                                                                                           \
-      launch_topk_emit<TT, false>(grid, lds, s, tmp_src, tmp_dst, n, (uint64_t)n_max, per, K, Kc, input, sm,       \
-                                  out_src, out_dst, out_data, fs, none);                                           \
+      launch_topk_emit<TT, false, SP>(grid, lds, s, tmp_src, tmp_dst, n, (uint64_t)n_max, per, K, Kc, input, sm,   \
+                                      out_src, out_dst, out_data, fs, none);                                       \
   } while (0)
-  if (T == 256) GGMS_TOPK(256);
-  else if (T == 128) GGMS_TOPK(128);
-  else GGMS_TOPK(64);
+  if (spill) GGMS_TOPK(64, true);
+  else if (T == 256) GGMS_TOPK(256, false);
+  else if (T == 128) GGMS_TOPK(128, false);
+  else GGMS_TOPK(64, false);
 #undef GGMS_TOPK
   GGMS_LAUNCH_CHECK();
   return GGMS_OK;
@@ -300,7 +326,7 @@ int ggms_sample_random_walk(const ggms_graph_t *graph, const ggms_id_t *input, s
                             ggms_id_t *out_data, uint64_t *num_out_dev, void *states, size_t num_states,
                             void *workspace, size_t workspace_bytes, ggms_stream_t stream) {
   GGMS_CHECK_ARG(graph && num_out_dev && walk_length > 0 && num_walk > 0 && K > 0);
-  GGMS_CHECK_ARG(walk_length * num_walk <= kMaxVisits && num_walk <= kBlock);
+  GGMS_CHECK_ARG(walk_length * num_walk < (1ull << 31));
   hipStream_t s = to_stream(stream);
   if (num_input == 0) {
     GGMS_HIP(hipMemsetAsync(num_out_dev, 0, sizeof(uint64_t), s));
