@@ -36,7 +36,7 @@ int sample_weighted_impl(const uint32_t *indptr, const uint32_t *indices, const 
                          const uint32_t *input, size_t n_max, Count n, uint32_t fanout, uint32_t *out_src,
                          uint32_t *out_dst, uint64_t *num_out_dev, uint32_t *states, uint32_t *workspace,
                          const uint32_t *seed_local, int src_local, hipStream_t s, ScanArea *shared_scan = nullptr,
-                         uint32_t num_node = 0);
+                         uint32_t num_node = 0, const DedupInsert *insert = nullptr);
 // sample_random_walk.hip
 size_t random_walk_ws_words(size_t num_input, size_t walk_length, size_t num_walk, size_t K);
 int sample_random_walk_impl(GraphView g, const uint32_t *input, size_t n_max, Count n, uint32_t walk_length,

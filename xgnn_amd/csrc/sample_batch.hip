@@ -259,21 +259,27 @@ int ggms_sample_batch(int sample_type, const ggms_graph_t *graph, const ggms_id_
                              (uint32_t)fanouts[i], col[i], tmp_dst, num_edge, (uint32_t *)states, samp_ws,
                              first ? seed_local : nullptr, 1, s, &scan, nullptr);
     } else if (sample_type == GGMS_KHOP1) {
+      inserted = ht->direct != 0 && e_max != 0; // the weighted family enters its output in the compaction's emit
+      if (inserted) di.tag = next_dedup_tag();
       rc = sample_weighted_impl(graph->indptr, graph->indices, nullptr, nullptr, input, n_max, n,
                                 (uint32_t)fanouts[i], col[i], tmp_dst, num_edge, (uint32_t *)states, samp_ws,
-                                first ? seed_local : nullptr, 1, s, &scan, graph->num_node);
+                                first ? seed_local : nullptr, 1, s, &scan, graph->num_node, inserted ? &di : nullptr);
     } else if (sample_type == GGMS_WEIGHTED_KHOP_PREFIX) {
+      inserted = ht->direct != 0 && e_max != 0;
+      if (inserted) di.tag = next_dedup_tag();
       rc = sample_weighted_impl(graph->indptr, graph->indices, extra->prob_table, nullptr, input, n_max, n,
                                 (uint32_t)fanouts[i], col[i], tmp_dst, num_edge, (uint32_t *)states, samp_ws,
-                                first ? seed_local : nullptr, 1, s, &scan, graph->num_node);
+                                first ? seed_local : nullptr, 1, s, &scan, graph->num_node, inserted ? &di : nullptr);
     } else if (sample_type == GGMS_WEIGHTED_KHOP_HASH_DEDUP) {
       rc = sample_weighted_hash_dedup_impl(graph->indptr, graph->indices, extra->prob_table, extra->alias_table, input,
                                            n_max, n, (uint32_t)fanouts[i], col[i], tmp_dst, num_edge,
                                            (uint32_t *)states, samp_ws, first ? seed_local : nullptr, 1, s, &scan);
     } else if (sample_type == GGMS_WEIGHTED_KHOP) {
+      inserted = ht->direct != 0 && e_max != 0;
+      if (inserted) di.tag = next_dedup_tag();
       rc = sample_weighted_impl(graph->indptr, graph->indices, extra->prob_table, extra->alias_table, input, n_max, n,
                                 (uint32_t)fanouts[i], col[i], tmp_dst, num_edge, (uint32_t *)states, samp_ws,
-                                first ? seed_local : nullptr, 1, s, &scan, graph->num_node);
+                                first ? seed_local : nullptr, 1, s, &scan, graph->num_node, inserted ? &di : nullptr);
     } else { // random walk: fanout[i] = num_neighbor = K (operation.cc:174); enters its output like khop3
       inserted = ht->direct != 0 && e_max != 0;
       if (inserted) di.tag = next_dedup_tag();

@@ -134,12 +134,14 @@ struct KeepEmit { // compact_edge, :98-128
   uint32_t *out_src, *out_dst;
   const uint32_t *seed_local;
   int src_local;
+  DedupInsert di; // w != NULL: the batch's direct dedup table, entered where the edge is written
   __device__ __forceinline__ void operator()(uint64_t q, uint32_t keep, uint32_t at) const {
     if (!keep) return;
     uint32_t src, dst, pos;
     ss.at(q, src, dst, pos);
     out_src[at] = src_local ? (seed_local ? seed_local[pos] : pos) : src;
     out_dst[at] = dst;
+    if (di.w) di.enter(dst, at);
   }
 };
 
@@ -151,7 +153,7 @@ int sample_weighted_impl(const uint32_t *indptr, const uint32_t *indices, const 
                          const uint32_t *input, size_t n_max, Count n, uint32_t fanout, uint32_t *out_src,
                          uint32_t *out_dst, uint64_t *num_out_dev, uint32_t *states, uint32_t *workspace,
                          const uint32_t *seed_local, int src_local, hipStream_t s, ScanArea *shared_scan,
-                         uint32_t num_node) {
+                         uint32_t num_node, const DedupInsert *insert) {
   uint32_t *w = workspace;
   uint32_t *tmp_dst = w;  w += n_max * fanout;
   uint32_t *k0 = w;       w += n_max;
@@ -185,7 +187,7 @@ int sample_weighted_impl(const uint32_t *indptr, const uint32_t *indices, const 
   // element count of the compaction = n * fanout with n possibly on the device: a Count cannot multiply,
   // so KeepFlag bounds itself by ss.n and the scan runs over the upper bound
   const ScanArea sa = shared_scan ? *shared_scan : ScanArea{scan_scr, false};
-  return tile_scan(KeepFlag{ss}, KeepEmit{ss, out_src, out_dst, seed_local, src_local}, task_max,
+  return tile_scan(KeepFlag{ss}, KeepEmit{ss, out_src, out_dst, seed_local, src_local, insert ? *insert : DedupInsert{}}, task_max,
                    count_of(task_max), sa, nullptr, nullptr, num_out_dev, s);
 }
 
