@@ -201,9 +201,14 @@ struct DedupInsert {
   uint32_t base;  // index of this fill's item 0 (0 in leaf mode)
   uint32_t batch; // 1: batch mode, `map` holds the fills before this one
   IdxMap map;
-  __device__ __forceinline__ void enter(uint32_t key, uint32_t e) const {
+  // enter = issue + finish: a lane with several independent instances issues them all before finishing any, so
+  // that the atomics' round trips overlap
+  __device__ __forceinline__ unsigned long long issue(uint32_t key, uint32_t e) const {
+    return atomicMin(w + key, make_w1(version, 1u, base + e));
+  }
+  __device__ __forceinline__ void enter(uint32_t key, uint32_t e) const { finish(issue(key, e), e); }
+  __device__ __forceinline__ void finish(unsigned long long old, uint32_t e) const {
     const unsigned long long mine = make_w1(version, 1u, base + e);
-    const unsigned long long old = atomicMin(w + key, mine);
     if (old > mine) {
       cand[e] = 1u;
       if ((old >> 32) == (mine >> 32)) lost[(uint32_t)old - base] = tag; // a pending word of this fill: beaten

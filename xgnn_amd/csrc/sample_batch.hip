@@ -253,11 +253,15 @@ int ggms_sample_batch(int sample_type, const ggms_graph_t *graph, const ggms_id_
       rc = sample_khop0_impl(g, input, n_max, n, (uint32_t)fanouts[i], col[i], tmp_dst, num_edge, samp_ws,
                              first ? seed_local : nullptr, 1, s, &scan, inserted ? &di : nullptr);
     } else if (sample_type == GGMS_KHOP2) {
-      // no fused insert here: khop2 is one lane per stream, and a returning atomic inside its serial draw loop
-      // puts a memory round trip behind every draw (measured on products: 0.51 -> 0.71 ms per step)
+      // no fused insert by default: even with the four seeds of a lane in lock-step and their atomics issued
+      // together, the returning atomics sit in the draw loop's dependency chain (measured on products: 0.45 -> 0.62 ms
+      // per step).  GGMS_KHOP2_FUSED=1 turns it on (measurement hook).
+      static const bool fuse2 = [] { const char *e = getenv("GGMS_KHOP2_FUSED"); return e && e[0] == '1'; }();
+      inserted = fuse2 && ht->direct != 0 && e_max != 0;
+      if (inserted) di.tag = next_dedup_tag();
       rc = sample_khop2_impl(graph->indptr, const_cast<uint32_t *>(graph->indices), graph->num_node, input, n_max, n,
                              (uint32_t)fanouts[i], col[i], tmp_dst, num_edge, (uint32_t *)states, samp_ws,
-                             first ? seed_local : nullptr, 1, s, &scan, nullptr);
+                             first ? seed_local : nullptr, 1, s, &scan, inserted ? &di : nullptr);
     } else if (sample_type == GGMS_KHOP1) {
       inserted = ht->direct != 0 && e_max != 0; // the weighted family enters its output in the compaction's emit
       if (inserted) di.tag = next_dedup_tag();

@@ -524,12 +524,18 @@ __global__ __launch_bounds__(1024) void k_khop0_resolve_heavy(GraphView g, const
 // (khop2.cu:53-61).  Draw j of a seed picks position curand % (len - j) of the seed's own
 // neighbour list, emits it and swaps it to the shrinking tail (:82-91): `indices` is
 // permuted in place and the next batch samples from the permuted lists.  One lane per
-// stream, as the stream assignment demands; a draw costs one round trip to the list
-// (both loads issue together, the stores are fire-and-forget; same-lane accesses to one
-// address stay in program order).  The compact COO is written directly at the seed's
-// scanned offset.  Seeds of one call must be distinct (two copies of a seed would race
-// on the same list, as they do in the reference).
-__global__ __launch_bounds__(kBlock) void k_sample_khop2(const uint32_t *__restrict__ indptr, uint32_t *indices,
+// stream, as the stream assignment demands, and a draw costs one round trip to the list
+// (it must see the previous swap) -- but only the draws of ONE seed depend on each other.
+// The generator is pure ALU, so the lane first positions four copies of its stream where
+// the four seeds' draws begin (seed r starts after the draws of the seeds before it: 9 ALU
+// ops per skipped draw) and then walks the four lists in lock-step: `fanout` round trips
+// per lane instead of 4 x fanout, with identical draws and an identical final state.
+// The compact COO is written directly at the seed's scanned offset.  Seeds of one call
+// must be distinct (two copies of a seed would race on the same list, as in the reference).
+// One wave per workgroup (a quarter of a reference block): every memory instruction of this kernel touches 64
+// different lines, so the CU's address path, shared by the waves of a workgroup, is what a 256-thread block waits
+// for (measured: 8000 seeds = 8 blocks took 50 us by themselves); spread over four times as many CUs it does not.
+__global__ __launch_bounds__(kWave) void k_sample_khop2(const uint32_t *__restrict__ indptr, uint32_t *indices,
                                                          const uint32_t *__restrict__ input, Count n_arg,
                                                          uint32_t fanout, const uint32_t *__restrict__ offset,
                                                          uint32_t *__restrict__ out_src,
@@ -537,42 +543,107 @@ __global__ __launch_bounds__(kBlock) void k_sample_khop2(const uint32_t *__restr
                                                          uint32_t *__restrict__ states, SrcMode sm, DedupInsert di) {
   const uint64_t n = n_arg.get();
   const uint64_t num_tiles = (n + 1023) / 1024;
-  for (uint64_t b = blockIdx.x; b < num_tiles; b += gridDim.x) {
-    const uint64_t sid = b * kBlock + threadIdx.x;
-    Xorwow st;
-    st.load(states + 6 * sid);
-    bool drew = false;
-    for (uint32_t r = 0; r < 4; ++r) {
-      const uint64_t index = b * 1024 + threadIdx.x + (uint64_t)r * kBlock;
-      if (index >= n) break;
-      const uint32_t rid = input[index];
-      const uint32_t off = indptr[rid], len = indptr[rid + 1] - off;
-      const uint32_t o = offset[index];
-      const uint32_t sv = sm.value(rid, index);
-      uint32_t *list = indices + off;
-      if (len <= fanout) {
-        for (uint32_t j = 0; j < len; ++j) {
-          const uint32_t nbr = list[j];
-          out_src[o + j] = sv;
-          out_dst[o + j] = nbr;
-          if (di.w) di.enter(nbr, o + j);
-        }
-      } else {
-        drew = true;
-        for (uint32_t j = 0; j < fanout; ++j) {
-          const uint32_t sel = st.next() % (len - j);
-          const uint32_t tail = len - j - 1;
-          const uint32_t picked = list[sel];
-          const uint32_t moved = list[tail];
-          out_src[o + j] = sv;
-          out_dst[o + j] = picked;
-          if (di.w) di.enter(picked, o + j);
-          list[sel] = moved;
-          list[tail] = picked;
+  for (uint64_t q = blockIdx.x; q < 4 * num_tiles; q += gridDim.x) {
+    const uint64_t b = q >> 2;                                  // reference block
+    const uint32_t t = (uint32_t)(q & 3u) * kWave + threadIdx.x; // thread of that block
+    const uint64_t sid = b * kBlock + t;
+    uint32_t off[4], len[4], o[4], sv[4];
+    bool draws[4];
+    {
+      // the four seeds' heads: branch-free (indices clamped into the tile), so the four id -> indptr chains overlap
+      uint64_t index[4];
+      uint32_t rid[4], end[4];
+#pragma unroll
+      for (uint32_t r = 0; r < 4; ++r) {
+        const uint64_t i = b * 1024 + t + (uint64_t)r * kBlock;
+        index[r] = i < n ? i : n - 1; // n >= 1 inside a tile
+        rid[r] = input[index[r]];
+      }
+#pragma unroll
+      for (uint32_t r = 0; r < 4; ++r) {
+        off[r] = indptr[rid[r]];
+        end[r] = indptr[rid[r] + 1];
+        o[r] = offset[index[r]];
+        sv[r] = sm.value(rid[r], index[r]);
+      }
+#pragma unroll
+      for (uint32_t r = 0; r < 4; ++r) {
+        const bool live = b * 1024 + t + (uint64_t)r * kBlock < n;
+        len[r] = live ? end[r] - off[r] : 0u;
+        draws[r] = len[r] > fanout;
+      }
+    }
+    // short lists are copied whole: every (seed, position) is independent -- 16 loads in flight
+    {
+      uint32_t longest = 0;
+#pragma unroll
+      for (uint32_t r = 0; r < 4; ++r) longest = (!draws[r] && len[r] > longest) ? len[r] : longest;
+      for (uint32_t j0 = 0; j0 < longest; j0 += 4) {
+        uint32_t v[4][4];
+#pragma unroll
+        for (uint32_t r = 0; r < 4; ++r)
+#pragma unroll
+          for (uint32_t u = 0; u < 4; ++u)
+            if (!draws[r] && j0 + u < len[r]) v[r][u] = indices[off[r] + j0 + u];
+#pragma unroll
+        for (uint32_t r = 0; r < 4; ++r)
+#pragma unroll
+          for (uint32_t u = 0; u < 4; ++u)
+            if (!draws[r] && j0 + u < len[r]) {
+              out_src[o[r] + j0 + u] = sv[r];
+              out_dst[o[r] + j0 + u] = v[r][u];
+            }
+        if (di.w) {
+          unsigned long long old[4][4];
+#pragma unroll
+          for (uint32_t r = 0; r < 4; ++r)
+#pragma unroll
+            for (uint32_t u = 0; u < 4; ++u)
+              if (!draws[r] && j0 + u < len[r]) old[r][u] = di.issue(v[r][u], o[r] + j0 + u);
+#pragma unroll
+          for (uint32_t r = 0; r < 4; ++r)
+#pragma unroll
+            for (uint32_t u = 0; u < 4; ++u)
+              if (!draws[r] && j0 + u < len[r]) di.finish(old[r][u], o[r] + j0 + u);
         }
       }
     }
-    if (drew) st.store(states + 6 * sid);
+    if (!(draws[0] || draws[1] || draws[2] || draws[3])) continue; // stream untouched
+    Xorwow st[4];
+    st[0].load(states + 6 * sid);
+#pragma unroll
+    for (uint32_t r = 1; r < 4; ++r) { // seed r draws after seeds 0..r-1
+      st[r] = st[r - 1];
+      if (draws[r - 1])
+        for (uint32_t j = 0; j < fanout; ++j) (void)st[r].next();
+    }
+    for (uint32_t j = 0; j < fanout; ++j) {
+      uint32_t sel[4], tail[4], picked[4], moved[4];
+#pragma unroll
+      for (uint32_t r = 0; r < 4; ++r) {
+        if (!draws[r]) continue;
+        sel[r] = st[r].next() % (len[r] - j);
+        tail[r] = len[r] - j - 1;
+        picked[r] = indices[off[r] + sel[r]];
+        moved[r] = indices[off[r] + tail[r]];
+      }
+      unsigned long long old[4];
+#pragma unroll
+      for (uint32_t r = 0; r < 4; ++r) {
+        if (!draws[r]) continue;
+        out_src[o[r] + j] = sv[r];
+        out_dst[o[r] + j] = picked[r];
+        if (di.w) old[r] = di.issue(picked[r], o[r] + j);
+        indices[off[r] + sel[r]] = moved[r];
+        indices[off[r] + tail[r]] = picked[r];
+      }
+      if (di.w) {
+#pragma unroll
+        for (uint32_t r = 0; r < 4; ++r)
+          if (draws[r]) di.finish(old[r], o[r] + j);
+      }
+    }
+    st[3].store(states + 6 * sid); // past its own draws, or -- a short last list -- still where seed 2 ended
   }
 }
 
@@ -714,7 +785,7 @@ int sample_khop2_impl(const uint32_t *indptr, uint32_t *indices, size_t num_node
   int rc = tile_scan(SeedCount{g, input, fanout}, StoreOffset{offset}, n_max, n, sa, nullptr, nullptr,
                      num_out_dev, s);
   if (rc != GGMS_OK) return rc;
-  hipLaunchKernelGGL(k_sample_khop2, dim3(grid_for((n_max + 1023) / 1024, 1)), dim3(kBlock), 0, s, indptr, indices,
+  hipLaunchKernelGGL(k_sample_khop2, dim3(grid_for(4 * ((n_max + 1023) / 1024), 1)), dim3(kWave), 0, s, indptr, indices,
                      input, n, fanout, offset, out_src, out_dst, states, SrcMode{seed_local, src_local},
                      insert ? *insert : DedupInsert{});
   GGMS_LAUNCH_CHECK();
