@@ -238,6 +238,7 @@ GRAPHS = {
     "small": dict(num_node=300, mean_deg=12, seed=1),
     "mid": dict(num_node=20_000, mean_deg=30, seed=2),
     "wide": dict(num_node=70_000, mean_deg=8, seed=3),  # ids need 3 key bytes in the samplers' radix sort
+    "ids23": dict(num_node=4_500_000, mean_deg=2, seed=4),  # ids beyond 2^22: three 11-bit passes
 }
 
 
@@ -288,10 +289,13 @@ def test_sample_khop0(ops, graphs, gname, n, fanout):
 
 
 @pytest.mark.parametrize("gname,n,fanout", [("small", 1, 5), ("small", 300, 25), ("small", 0, 4), ("mid", 8000, 10),
-                                            ("mid", 30000, 25), ("mid", 5000, 3), ("wide", 9000, 6)])
+                                            ("mid", 30000, 25), ("mid", 5000, 3), ("wide", 9000, 6),
+                                            ("mid", 8192, 4), ("mid", 8193, 4), ("wide", 8192, 2),
+                                            ("mid", 1_100_000, 1), ("ids23", 9000, 3), ("ids23", 5000, 3)])
 def test_sample_khop1(ops, graphs, gname, n, fanout):
     """With replacement + stable sort by src + adjacent-duplicate drop (khop1.cu:42-127); 30000*25 > 512 K tasks
-    exercises the grid-stride reuse of a stream."""
+    exercises the grid-stride reuse of a stream.  The seed sort has three forms by size: one workgroup in LDS (up to
+    8192 seeds), 11-bit digits (up to 2^20), 8-bit digits beyond."""
     ip, ix, g = graphs[gname]
     rng = np.random.RandomState(n * 11 + fanout)
     inp = rng.randint(0, ip.size - 1, n).astype(np.uint32)

@@ -177,11 +177,10 @@ int sample_weighted_impl(const uint32_t *indptr, const uint32_t *indices, const 
   GGMS_LAUNCH_CHECK();
   hipLaunchKernelGGL(k_weighted_keys, dim3(grid_for(n_max, kBlock)), dim3(kBlock), 0, s, indptr, input, n, k0, v0);
   GGMS_LAUNCH_CHECK();
-  // keys are node ids (< num_node) or kEmptyKey: when the ids fit in 2 or 3 bytes those bytes order them, and the
-  // empty key (all ones) still sorts behind every id
-  const uint32_t passes = (num_node && num_node <= 0xffffu) ? 2u : (num_node && num_node <= 0xffffffu) ? 3u : 4u;
+  // keys are node ids (< num_node) or kEmptyKey: the sort only covers the bits an id can have set, and the empty
+  // key (all ones) still sorts behind every id (radix_plan)
   bool in_second = false;
-  int rc = radix_sort_pairs(k0, v0, k1, v1, n_max, n, sort_scr, s, passes, &in_second);
+  int rc = radix_sort_pairs(k0, v0, k1, v1, n_max, n, sort_scr, s, num_node, &in_second);
   if (rc != GGMS_OK) return rc;
   const SortedStream ss{in_second ? k1 : k0, in_second ? v1 : v0, tmp_dst, fanout, n};
   // element count of the compaction = n * fanout with n possibly on the device: a Count cannot multiply,
