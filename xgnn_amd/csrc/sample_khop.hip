@@ -270,7 +270,8 @@ __global__ __launch_bounds__(128 * (4 / GPW)) void k_khop3_fused(GraphView g, co
     const uint32_t prefix = s_prefix;
     const uint32_t slots = 128u * fanout;
     // (one slot per lane and round: handling four at a time -- loads, then atomics, in flight together -- costs
-    // registers and measured 5 % SLOWER sampling on papers100M)
+    // registers and measured 5 % SLOWER sampling on papers100M when applied everywhere, and as a launch-time choice
+    // for frontiers that fit the chip at once +1.3 % per step on products, nothing on papers100M: not kept)
     for (uint32_t t = threadIdx.x; t < slots; t += NT) {
       // s = t / fanout (t < 2^14): mulhi by ceil(2^32 / fanout), one fix-up
       uint32_t sd = fanout == 1 ? t : __umulhi(t, fanout_magic);
