@@ -18,8 +18,10 @@ from xgnn_amd import datagen, ops  # noqa: E402
 
 nb = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 stype = sys.argv[2] if len(sys.argv) > 2 else "khop3"
-code = {"khop3": ops.KHOP3, "khop0": ops.KHOP0, "khop1": ops.KHOP1, "random_walk": ops.RANDOM_WALK}[stype]
-ocode = {"khop3": oracle.KHOP3, "khop0": oracle.KHOP0, "khop1": oracle.KHOP1, "random_walk": oracle.RANDOM_WALK}[stype]
+code = {"khop3": ops.KHOP3, "khop0": ops.KHOP0, "khop1": ops.KHOP1, "khop2": ops.KHOP2,
+        "random_walk": ops.RANDOM_WALK}[stype]
+ocode = {"khop3": oracle.KHOP3, "khop0": oracle.KHOP0, "khop1": oracle.KHOP1, "khop2": oracle.KHOP2,
+         "random_walk": oracle.RANDOM_WALK}[stype]
 walk = stype == "random_walk"  # PinSAGE defaults (sgnn/train_pinsage.py:138-142)
 kw = dict(random_walk_length=3, random_walk_restart_prob=0.5, num_random_walk=4) if walk else {}
 okw = dict(walk_length=3, restart_prob=0.5, num_walk=4) if walk else {}
@@ -27,7 +29,9 @@ dev = torch.device("cuda", 0)
 g = datagen.make_graph("products", seed=42)
 ip, ix = g["indptr"], g["indices"]
 to_dev = lambda a: torch.from_numpy(a.view(np.int32) if a.dtype == np.uint32 else a).to(dev)  # noqa: E731
-graph = ops.DeviceGraph(to_dev(ip), to_dev(ix))
+graph = ops.DeviceGraph(to_dev(ip), to_dev(ix))  # khop2 permutes this copy; the oracle permutes `ix` the same way
+if stype == "khop2":
+    ix = ix.copy()
 u32 = lambda t, n: t[:n].cpu().numpy().view(np.uint32)  # noqa: E731
 noise_src = torch.empty((1 << 28,), dtype=torch.float32, device=dev)
 noise_dst = torch.empty_like(noise_src)
