@@ -685,6 +685,7 @@ void Engine::TrainInit(int worker_id, const std::string &ctx) {
     SAM_HIP(hipEventCreateWithFlags(&b->ev_seeds, hipEventDisableTiming));
     SAM_HIP(hipEventCreate(&b->ev_start));
     SAM_HIP(hipEventCreate(&b->ev_sampled));
+    SAM_HIP(hipEventCreate(&b->ev_xstart));
     SAM_HIP(hipEventCreate(&b->ev_done));
     slots_.push_back(std::move(b));
   }
@@ -792,6 +793,7 @@ bool Engine::EnqueueOne(bool background) {
   // extract overlaps batch k+1's sampling (the reference serialises them, dist_loops_arch6.cc:248-251)
   hipStream_t xs = stream_extract_;
   SAM_HIP(hipStreamWaitEvent(xs, b->ev_sampled, 0));
+  SAM_HIP(hipEventRecord(b->ev_xstart, xs)); // the extract's own start: behind the previous batch's extract on xs
   const bool mock = ds.feat_mask != 0xffffffffu; // SAMGRAPH_EMPTY_FEAT: host rows are node & mask
   if (StagedHostTier()) {
     StagedExtract(b, xs);
@@ -898,7 +900,7 @@ void Engine::Finish(Batch *b) {
   }
   float ms_sample = 0, ms_copy = 0;
   (void)hipEventElapsedTime(&ms_sample, b->ev_start, b->ev_sampled);
-  (void)hipEventElapsedTime(&ms_copy, b->ev_sampled, b->ev_done);
+  (void)hipEventElapsedTime(&ms_copy, b->ev_xstart, b->ev_done); // not from ev_sampled: that would add the queueing behind the previous extract
   uint64_t edges = 0;
   for (uint32_t i = 0; i < L; ++i) edges += b->counts[3 * i];
   const double row_bytes = (double)ds.feat_dim * ggms_dtype_bytes(ds.feat_dtype);

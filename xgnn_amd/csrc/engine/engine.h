@@ -143,7 +143,7 @@ struct Batch {
   uint64_t *counts = nullptr;
   size_t num_seeds = 0, num_input = 0;
   uint64_t num_miss = 0;
-  hipEvent_t ev_seeds = nullptr, ev_start = nullptr, ev_sampled = nullptr, ev_done = nullptr;
+  hipEvent_t ev_seeds = nullptr, ev_start = nullptr, ev_sampled = nullptr, ev_xstart = nullptr, ev_done = nullptr;
   // arch6 with `gpu_extract` off: the host-staged miss path (dist_loops.cc:1015-1207)
   uint32_t *miss_src = nullptr, *miss_dst = nullptr, *hit_src = nullptr, *hit_dst = nullptr;
   void *idx_ws = nullptr, *miss_rows_dev = nullptr;
