@@ -758,6 +758,76 @@ def test_fused_khop3_random_shapes(ops):
     assert ops.device_status() == 0
 
 
+def test_all_samplers_random_shapes(ops):
+    """Batch calls (DoGPUSample) of every other sample type over seeded random shapes, both table layouts: random walks
+    from 1 to 300 visits per seed (LDS tiles of 256 / 128 / 64 seeds and the spilling variant), khop0 up to fanout 2500
+    (LDS slots and slots in the output), khop2 (distinct seeds), khop1 / alias / prefix with frontiers around the seed
+    sort's 8192-pair switch."""
+    rng = np.random.RandomState(77)
+    graphs = [powerlaw_csr(4000, mean_deg=9, seed=1), powerlaw_csr(30_000, mean_deg=25, seed=2), hub_csr(3000, 6, 6000, 9, 3)]
+    kinds = ["random_walk", "khop0", "khop2", "khop1", "weighted", "prefix"]
+    for trial in range(48):
+        kind = kinds[trial % len(kinds)]
+        gi = (trial // len(kinds)) % 3
+        ip, ix = graphs[gi]
+        N = ip.size - 1
+        ix_orc = ix.copy()
+        g = ops.DeviceGraph(dev(ip), dev(ix.copy()))
+        L = int(rng.randint(1, 4))
+        nseed = int(rng.choice([1, 63, 64, 65, 256, 257, 900, 2100]))
+        direct = bool(trial % 2)
+        kw, okw = {}, {}
+        if kind == "random_walk":
+            wl, nw = [(3, 4), (1, 1), (5, 6), (4, 12), (10, 12), (15, 9), (2, 150)][int(rng.randint(0, 7))]
+            fanouts = [int(rng.randint(1, 9)) for _ in range(L)]
+            if wl * nw > 100:
+                nseed, fanouts = min(nseed, 257), fanouts[:2]
+            p = float(rng.choice([0.0, 0.3, 0.5]))
+            kw = dict(random_walk_length=wl, random_walk_restart_prob=p, num_random_walk=nw)
+            okw = dict(walk_length=wl, restart_prob=p, num_walk=nw)
+            code, ocode = ops.RANDOM_WALK, oracle.RANDOM_WALK
+        elif kind == "khop0":
+            fanouts = [int(rng.randint(1, 30)) for _ in range(L)]
+            if trial % 12 == 1:
+                fanouts, nseed = [int(rng.choice([2049, 2500]))], min(nseed, 65)
+            code, ocode = ops.KHOP0, oracle.KHOP0
+        elif kind == "khop2":
+            fanouts = [int(rng.randint(1, 30)) for _ in range(L)]
+            code, ocode = ops.KHOP2, oracle.KHOP2
+        else:
+            fanouts = [int(rng.randint(1, 12)) for _ in range(L)]
+            if L >= 2 and gi == 1:
+                nseed = 2100  # the deeper frontiers then straddle 8192 seeds
+            code, ocode = {"khop1": (ops.KHOP1, oracle.KHOP1), "weighted": (ops.WEIGHTED_KHOP, oracle.WEIGHTED_KHOP),
+                           "prefix": (ops.WEIGHTED_KHOP_PREFIX, oracle.WEIGHTED_KHOP_PREFIX)}[kind]
+            if kind == "weighted":
+                prob = rng.random_sample(ix.size).astype(np.float32)
+                alias = rng.randint(0, N, ix.size).astype(np.uint32)
+                kw, okw = dict(prob_table=dev(prob), alias_table=dev(alias)), dict(prob=prob, alias=alias)
+            if kind == "prefix":
+                from xgnn_amd import datagen
+                prob = datagen.build_prob_prefix_table(ip, datagen.edge_weights({"indptr": ip, "indices": ix}, seed=trial))
+                kw, okw = dict(prob_table=dev(prob)), dict(prob=prob)
+        seeds = (rng.permutation(N)[:nseed] if kind == "khop2" else rng.randint(0, N, nseed)).astype(np.uint32)
+        nseed = seeds.size
+        bs = ops.BatchSampler(g, fanouts, nseed, sample_type=code, seed=300 + trial, direct_table=direct, **kw)
+        states = oracle.random_states(bs.states.shape[0], 300 + trial) if bs.states is not None else None
+        for rep in range(2):
+            bs.sample(dev(seeds))
+            got = bs.result()
+            want = oracle.do_sample(ocode, ip, ix_orc, seeds, fanouts, states, **okw)
+            tag = (trial, kind, fanouts, nseed, direct, kw.get("random_walk_length"), kw.get("num_random_walk"), rep)
+            assert np.array_equal(host_u32(got["input_nodes"]), want["input_nodes"]), tag
+            for i in range(len(fanouts)):
+                gl, wl_ = got["layers"][i], want["layers"][i]
+                assert (gl["num_src"], gl["num_dst"]) == (wl_["num_src"], wl_["num_dst"]), tag + (i,)
+                assert np.array_equal(host_u32(gl["row"]), wl_["row"]) and np.array_equal(host_u32(gl["col"]), wl_["col"]), tag + (i,)
+                if kind == "random_walk":
+                    assert np.array_equal(host_u32(gl["data"]), wl_["data"]), tag + (i,)
+        del bs
+    assert ops.device_status() == 0
+
+
 def test_heavy_wait_changes_timing_not_results(ops):
     """ggms_sample_extra_t.heavy_wait: the last layer's sampler launch waits for an event recorded on another stream
     (a feature gather, in the pipeline).  Whatever the event, the batch is the oracle's."""
