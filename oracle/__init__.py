@@ -405,6 +405,8 @@ def do_sample(sample_type, indptr, indices, seeds, fanouts, states=None, prob=No
         if alias is not None:
             alias = _u32(alias)
             ex.alias_table = alias.ctypes.data
+    if sample_type == RANDOM_WALK and (walk_length < 1 or num_walk < 1):
+        raise ValueError("random walk needs walk_length >= 1 and num_walk >= 1 (the block-shape rule never ends on 0)")
     ex.walk_length, ex.restart_prob, ex.num_walk = walk_length, restart_prob, num_walk
     h = lib().orc_do_sample_ex(C.c_int(sample_type), _p(indptr), _p(indices), _sz(indptr.size - 1),
                                _p(seeds), _sz(seeds.size), f, _sz(len(fanouts)), _p(states),

@@ -105,6 +105,8 @@ void Engine::Configure(const std::unordered_map<std::string, std::string> &kv_in
     cfg.random_walk_restart_prob = std::stod(kv["random_walk_restart_prob"]);
     cfg.num_random_walk = std::stoull(kv["num_random_walk"]);
     cfg.num_neighbor = std::stoull(kv["num_neighbor"]);
+    SAM_CHECK(cfg.random_walk_length > 0 && cfg.num_random_walk > 0 && cfg.num_neighbor > 0,
+              "random walk needs random_walk_length, num_random_walk and num_neighbor >= 1");
     cfg.fanout.assign(cfg.num_layer, cfg.num_neighbor);
   }
   if (kv.count("use_dist_graph")) { // :191-203

@@ -213,7 +213,7 @@ __global__ __launch_bounds__(T) void k_walk_topk_emit(uint32_t *tmp_src, uint32_
 
 static void walk_block_shape(uint32_t num_walk, uint32_t &bx, uint32_t &by) {
   bx = kBlock; by = 1; // dim3 block(kCudaBlockSize, 1); while (x >= 2 * num_walk) { x /= 2; y *= 2; }  (:132-136)
-  while (bx >= 2 * num_walk) { bx /= 2; by *= 2; }
+  while (bx > 1 && bx >= 2 * num_walk) { bx /= 2; by *= 2; } // bx > 1: num_walk = 0 must not spin (callers refuse it)
 }
 
 // tile of the top-K kernel: the largest whose LDS (columns + staging) stays within 64 KB, down to one wave
@@ -316,6 +316,7 @@ size_t ggms_sample_random_walk_workspace_bytes(size_t num_input, size_t walk_len
 
 // PredictRandomWalkMaxThreads, cuda_random_states.cu:48-60
 size_t ggms_random_walk_num_states(size_t num_input, size_t num_walk) {
+  if (num_walk == 0) return 0;
   uint32_t bx, by;
   walk_block_shape((uint32_t)num_walk, bx, by);
   return (num_input + by - 1) / by * bx * by;
