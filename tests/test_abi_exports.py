@@ -71,6 +71,7 @@ def test_host_only_entry_points():
     assert l.ggms_random_states_count(2, f, 2, 8000, 0) == 512 * 1024
     f3 = (ctypes.c_size_t * 3)(5, 5, 5)
     assert l.ggms_random_states_count(3, f3, 3, 100, 4) == ((100 * 6 * 6 + 63) // 64) * 256
+    assert l.ggms_random_states_count(3, f3, 3, 100, 0) == 0  # no walks: no states (and no spin in the block-shape rule)
     # PredictRandomWalkMaxThreads (cuda_random_states.cu:48-60): the block-shape rule, which must not spin on 0 walks
     l.ggms_random_walk_num_states.restype = ctypes.c_size_t
     assert [l.ggms_random_walk_num_states(ctypes.c_size_t(100), ctypes.c_size_t(w)) for w in (0, 1, 4, 5, 300)] == \

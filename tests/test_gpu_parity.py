@@ -828,6 +828,24 @@ def test_all_samplers_random_shapes(ops):
     assert ops.device_status() == 0
 
 
+def test_sample_batch_refuses_degenerate_shapes(ops):
+    """A layer with fanout 0 (khop0's resolver would divide by it) or a random walk with no walks is an argument
+    error, not a crash or a spin."""
+    ip, ix = powerlaw_csr(2000, mean_deg=9, seed=1)
+    g = ops.DeviceGraph(dev(ip), dev(ix))
+    seeds = dev(np.arange(50, dtype=np.uint32))
+    for code in (ops.KHOP0, ops.KHOP3, ops.KHOP2, ops.KHOP1):
+        with pytest.raises(Exception):
+            bs = ops.BatchSampler(g, [5, 0], 50, sample_type=code, seed=1)
+            bs.sample(seeds)
+            bs.result()
+    with pytest.raises(Exception):
+        bs = ops.BatchSampler(g, [5, 5], 50, sample_type=ops.RANDOM_WALK, seed=1, random_walk_length=3,
+                              random_walk_restart_prob=0.5, num_random_walk=0)
+        bs.sample(seeds)
+        bs.result()
+
+
 def test_heavy_wait_changes_timing_not_results(ops):
     """ggms_sample_extra_t.heavy_wait: the last layer's sampler launch waits for an event recorded on another stream
     (a feature gather, in the pipeline).  Whatever the event, the batch is the oracle's."""

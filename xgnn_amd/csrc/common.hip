@@ -119,6 +119,7 @@ size_t ggms_random_states_count(int sample_type, const size_t *fanout, size_t nu
       return n < kMaxThreads ? n : kMaxThreads;
     }
     case GGMS_RANDOM_WALK: {
+      if (num_random_walk == 0) return 0; // the block-shape rule below never ends on 0 walks (callers refuse them)
       size_t nodes = predict_num_nodes(batch_size, fanout, num_fanout - 1);
       size_t bx = 256, by = 1;
       while (bx >= 2 * num_random_walk) { bx /= 2; by *= 2; }

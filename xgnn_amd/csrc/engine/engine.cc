@@ -74,6 +74,7 @@ void Engine::Configure(const std::unordered_map<std::string, std::string> &kv_in
   cfg.cache_policy = std::stoi(kv["_cache_policy"]);
   cfg.cache_percentage = std::stod(kv["cache_percentage"]);
   cfg.num_layer = std::stoull(kv["num_layer"]);
+  SAM_CHECK(cfg.batch_size > 0 && cfg.num_layer >= 1 && cfg.num_layer <= 16, "batch_size >= 1 and 1 <= num_layer <= 16");
   switch (cfg.arch) { // operation.cc:101-148
     case kArch1:
       SAM_CHECK(kv.count("sampler_ctx") && kv.count("trainer_ctx"), "arch1 needs sampler_ctx/trainer_ctx");
@@ -91,6 +92,7 @@ void Engine::Configure(const std::unordered_map<std::string, std::string> &kv_in
     case kArch6:
       SAM_CHECK(kv.count("num_worker"), "arch6 needs num_worker");
       cfg.num_worker = std::stoull(kv["num_worker"]);
+      SAM_CHECK(cfg.num_worker >= 1, "num_worker >= 1");
       break;
     default:
       fatal(__FILE__, __LINE__, "only arch0 (CPU), arch1 (standalone) and arch6 (SGNN/XGNN) are built; see DESIGN.md");
@@ -99,7 +101,12 @@ void Engine::Configure(const std::unordered_map<std::string, std::string> &kv_in
     SAM_CHECK(kv.count("num_fanout") && kv.count("fanout"), "khop sampling needs num_fanout/fanout");
     size_t nf = std::stoull(kv["num_fanout"]);
     std::stringstream ss(kv["fanout"]);
-    for (size_t i = 0; i < nf; ++i) { size_t f; ss >> f; cfg.fanout.push_back(f); }
+    for (size_t i = 0; i < nf; ++i) {
+      size_t f = 0;
+      ss >> f;
+      SAM_CHECK(f > 0, "fanout: num_fanout positive integers expected");
+      cfg.fanout.push_back(f);
+    }
   } else { // :164-175
     cfg.random_walk_length = std::stoull(kv["random_walk_length"]);
     cfg.random_walk_restart_prob = std::stod(kv["random_walk_restart_prob"]);

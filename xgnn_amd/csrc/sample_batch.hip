@@ -154,6 +154,7 @@ int ggms_sample_batch(int sample_type, const ggms_graph_t *graph, const ggms_id_
   GGMS_CHECK_ARG(num_layer >= 1 && num_layer <= 16);
   GGMS_CHECK_ARG(sample_type >= GGMS_KHOP0 && sample_type <= GGMS_KHOP3);
   GGMS_CHECK_ARG(num_seeds == 0 || seeds);
+  for (uint32_t i = 0; i < num_layer; ++i) GGMS_CHECK_ARG(fanouts[i] > 0); // a layer that samples nothing is a config error
   GGMS_CHECK_ARG(workspace && workspace_bytes >= ggms_sample_batch_workspace_bytes(sample_type, num_seeds, fanouts,
                                                                                    num_layer, extra));
   if (sample_type == GGMS_WEIGHTED_KHOP)
