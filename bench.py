@@ -46,8 +46,8 @@ def parse():
     ap.add_argument("--batch", type=int, default=8000)
     ap.add_argument("--fanout", default=None, help="default: 5,10,15 (papers100M / friendster), 25,10 (products)")
     ap.add_argument("--sample-type", default="khop3",
-                    choices=["khop3", "khop0", "khop2", "khop1", "weighted_khop", "weighted_khop_hash_dedup",
-                             "random_walk"],
+                    choices=["khop3", "khop0", "khop2", "khop1", "weighted_khop", "weighted_khop_prefix",
+                             "weighted_khop_hash_dedup", "random_walk"],
                     help="random_walk: PinSAGE defaults (walk length 3, restart 0.5, 4 walks); --fanout gives the "
                          "top-K per layer, e.g. 5,5,5.  weighted_khop: alias tables built from synthetic weights")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -296,10 +296,14 @@ def main():
         return extract, keep
 
     code = {"khop3": ops.KHOP3, "khop0": ops.KHOP0, "khop2": ops.KHOP2, "khop1": ops.KHOP1,
-            "weighted_khop": ops.WEIGHTED_KHOP, "weighted_khop_hash_dedup": ops.WEIGHTED_KHOP_HASH_DEDUP,
-            "random_walk": ops.RANDOM_WALK}[args.sample_type]
+            "weighted_khop": ops.WEIGHTED_KHOP, "weighted_khop_prefix": ops.WEIGHTED_KHOP_PREFIX,
+            "weighted_khop_hash_dedup": ops.WEIGHTED_KHOP_HASH_DEDUP, "random_walk": ops.RANDOM_WALK}[args.sample_type]
     extra_kw = {}
-    if args.sample_type.startswith("weighted_khop"):  # per-edge acceptance probability + alias neighbour (engine.cc:372-384)
+    if args.sample_type == "weighted_khop_prefix":  # running weight sums per neighbour list (create_prob_prefix_table.cc)
+        pre = datagen.build_prob_prefix_table(graph["indptr"], datagen.edge_weights(graph, "default", 7),
+                                              num_threads=usable_cores())
+        extra_kw = dict(prob_table=torch.from_numpy(pre).to(dev))
+    elif args.sample_type.startswith("weighted_khop"):  # per-edge acceptance probability + alias neighbour (engine.cc:372-384)
         # valid alias tables from seeded per-edge weights, as the reference's weight tool builds them
         prob, alias = datagen.build_alias_tables(graph["indptr"], graph["indices"], datagen.edge_weights(graph, "default", 7),
                                                  num_threads=usable_cores())

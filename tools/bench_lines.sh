@@ -13,6 +13,6 @@ run bench_products_sage_25_10 --preset products
 run bench_products_sage_25_10_no_overlap --preset products --no-overlap --no-cpu-baseline
 run bench_papers100M_sage_25_10 --fanout 25,10 --no-cpu-baseline
 run bench_friendster_pinsage_5_5_5 --preset friendster --sample-type random_walk --fanout 5,5,5 --no-cpu-baseline
-for st in khop0 khop2 khop1 weighted_khop; do
+for st in khop0 khop2 khop1 weighted_khop weighted_khop_prefix weighted_khop_hash_dedup; do
   run bench_products_$st --preset products --sample-type $st --no-cpu-baseline
 done

@@ -199,7 +199,10 @@ constexpr uint32_t kDedupSlots = 50;       // hash_dedup.cu:42
 constexpr uint32_t kDedupMaxTries = 65536; // the reference spins forever on a list without `fanout` distinct ids
 constexpr uint32_t kDedupMaxProbes = 64;   // ... and on a full table (a seed id met twice by one thread, fanout >= 25)
 
-__global__ __launch_bounds__(kBlock) void k_weighted_hash_dedup(const uint32_t *__restrict__ indptr,
+// One wave per workgroup (a quarter of a reference block), as in k_sample_khop2: every load here touches 64 different
+// lines and a workgroup's waves share the CU's address path.  A try is ONE round trip: the neighbour, its acceptance
+// probability and its alias are loaded together (the alias unconditionally), not the alias after the comparison.
+__global__ __launch_bounds__(kWave) void k_weighted_hash_dedup(const uint32_t *__restrict__ indptr,
                                                                 const uint32_t *__restrict__ indices,
                                                                 const float *__restrict__ prob,
                                                                 const uint32_t *__restrict__ alias,
@@ -208,18 +211,20 @@ __global__ __launch_bounds__(kBlock) void k_weighted_hash_dedup(const uint32_t *
                                                                 uint32_t *__restrict__ out_src,
                                                                 uint32_t *__restrict__ out_dst,
                                                                 uint32_t *__restrict__ states, SrcMode sm) {
-  __shared__ uint32_t val[kDedupSlots][kBlock], round_of[kDedupSlots][kBlock];
+  __shared__ uint32_t val[kDedupSlots][kWave], round_of[kDedupSlots][kWave];
   const uint64_t n = n_arg.get();
-  const uint32_t t = threadIdx.x;
+  const uint32_t t = threadIdx.x; // lane: column of the LDS tables
   const uint64_t num_tiles = (n + 1023) / 1024;
-  for (uint64_t b = blockIdx.x; b < num_tiles; b += gridDim.x) {
+  for (uint64_t q = blockIdx.x; q < 4 * num_tiles; q += gridDim.x) {
+    const uint64_t b = q >> 2;                          // reference block
+    const uint32_t tb = (uint32_t)(q & 3u) * kWave + t; // thread of that block
     for (uint32_t z = 0; z < kDedupSlots; ++z) { val[z][t] = kEmptyKey; round_of[z][t] = kEmptyKey; } // :72-76
-    const uint64_t sid = b * kBlock + t;
+    const uint64_t sid = b * kBlock + tb;
     Xorwow st;
     st.load(states + 6 * sid);
     bool drew = false;
     for (uint32_t r = 0; r < 4; ++r) {
-      const uint64_t index = b * 1024 + t + (uint64_t)r * kBlock;
+      const uint64_t index = b * 1024 + tb + (uint64_t)r * kBlock;
       if (index >= n) break;
       const uint32_t rid = input[index];
       const uint32_t off = indptr[rid], len = indptr[rid + 1] - off;
@@ -233,25 +238,52 @@ __global__ __launch_bounds__(kBlock) void k_weighted_hash_dedup(const uint32_t *
         continue;
       }
       drew = true;
+      // A try consumes exactly two draws whatever its outcome, so the next B tries' positions and uniforms are known
+      // in advance: their 3 B loads go out together and the tries are then resolved in order against the LDS table.
+      // If the seed completes inside a batch, the generator is put back to just after the last try used.
+      constexpr uint32_t B = 8;
       uint32_t got = 0, tries = 0;
       while (got < fanout) {
-        const bool give_up = ++tries > kDedupMaxTries;
-        const uint32_t k = st.next() % len;
-        const float u = st.uniform();
-        uint32_t cand = indices[off + k];
-        if (u > prob[off + k]) cand = alias[off + k]; // strict >, :101-103
-        uint32_t pos = cand % kDedupSlots, gap = 1;   // insert_hash_table, :41-57
-        bool is_new = true; // a probe sequence that finds neither a free slot nor the value takes the candidate
-        for (uint32_t probe = 0; probe < kDedupMaxProbes; ++probe) {
-          if (round_of[pos][t] != rid) { round_of[pos][t] = rid; val[pos][t] = cand; break; }
-          if (val[pos][t] == cand) { is_new = false; break; }
-          pos = (pos + gap) % kDedupSlots;
-          ++gap;
+        const Xorwow st0 = st;
+        uint32_t kk[B], nb[B], al[B];
+        float uu[B], pr[B];
+#pragma unroll
+        for (uint32_t i = 0; i < B; ++i) {
+          kk[i] = st.next() % len;
+          uu[i] = st.uniform();
         }
-        if (!is_new && !give_up) continue;
-        out_src[o + got] = sv;
-        out_dst[o + got] = cand;
-        ++got;
+#pragma unroll
+        for (uint32_t i = 0; i < B; ++i) {
+          nb[i] = indices[off + kk[i]];
+          al[i] = alias[off + kk[i]];
+          pr[i] = prob[off + kk[i]];
+        }
+        uint32_t used = B;
+#pragma unroll
+        for (uint32_t i = 0; i < B; ++i) {
+          if (got < fanout) {
+            const bool give_up = ++tries > kDedupMaxTries;
+            const uint32_t cand = (uu[i] > pr[i]) ? al[i] : nb[i]; // strict >, :101-103
+            uint32_t pos = cand % kDedupSlots, gap = 1;            // insert_hash_table, :41-57
+            bool is_new = true; // a probe sequence that finds neither a free slot nor the value takes the candidate
+            for (uint32_t probe = 0; probe < kDedupMaxProbes; ++probe) {
+              if (round_of[pos][t] != rid) { round_of[pos][t] = rid; val[pos][t] = cand; break; }
+              if (val[pos][t] == cand) { is_new = false; break; }
+              pos = (pos + gap) % kDedupSlots;
+              ++gap;
+            }
+            if (is_new || give_up) {
+              out_src[o + got] = sv;
+              out_dst[o + got] = cand;
+              ++got;
+              if (got == fanout) used = i + 1;
+            }
+          }
+        }
+        if (used < B) { // two draws per try actually made
+          st = st0;
+          for (uint32_t i = 0; i < 2 * used; ++i) (void)st.next();
+        }
       }
     }
     if (drew) st.store(states + 6 * sid);
@@ -268,7 +300,7 @@ int sample_weighted_hash_dedup_impl(const uint32_t *indptr, const uint32_t *indi
   int rc = tile_scan(MinDegFanout{indptr, input, fanout}, StoreWord{offset}, n_max, n, sa, nullptr, nullptr,
                      num_out_dev, s);
   if (rc != GGMS_OK) return rc;
-  hipLaunchKernelGGL(k_weighted_hash_dedup, dim3(grid_for((n_max + 1023) / 1024, 1)), dim3(kBlock), 0, s, indptr,
+  hipLaunchKernelGGL(k_weighted_hash_dedup, dim3(grid_for(4 * ((n_max + 1023) / 1024), 1)), dim3(kWave), 0, s, indptr,
                      indices, prob, alias, input, n, fanout, offset, out_src, out_dst, states,
                      SrcMode{seed_local, src_local});
   GGMS_LAUNCH_CHECK();
