@@ -74,6 +74,9 @@ def parse():
     ap.add_argument("--hbm-budget-gb", type=float, default=24.0, help="hybrid store with --replicate-frac auto")
     ap.add_argument("--other-stores", default="replica,hybrid",
                     help="N > 1: stores measured after the main timed region (one block) and reported under 'stores'")
+    ap.add_argument("--neighbour-skew", type=float, default=0.0,
+                    help="0 (default, SURVEY 8d): neighbour ids uniform; s > 0: a neighbour is drawn with probability "
+                         "proportional to in-degree^s (hub-heavy frontiers, as real power-law graphs have)")
     ap.add_argument("--cache-ratio", type=float, default=1.0,
                     help="fraction of feature rows (by degree rank) resident in HBM; the rest is gathered from "
                          "pinned host memory by the same kernel (GGMS host tier)")
@@ -166,14 +169,89 @@ def cpu_baseline(graph, fanouts, batch, feat, seconds):
     }
 
 
+def launch_ranks(args):
+    """`python bench.py --gpus N` (N > 1) started as a plain script: become the launcher of N ranks, one per GPU --
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 bench.py <same flags>` as a
+    child process, BEFORE this process has touched the GPU (it never does) -- the reference's own model: the parent
+    forks one worker per GPU after data_init (operation.cc:509-533, sgnn/train_graphsage.py:136-155).  Relays the
+    ranks' stdout (rank 0's JSON line), exits with the launcher's code, and exits non-zero if no line with
+    n_gpus == N came back: this script never reports a GPU count other than the ranks that really ran."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    # the host driver only supports dmabuf IPC: without it hipIpcGetMemHandle fails (INTEGRATION.md, "Environment")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    p = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env)
+    seen = None
+    for line in p.stdout:
+        sys.stdout.write(line)
+        sys.stdout.flush()
+        if line.startswith("{"):
+            try:
+                seen = json.loads(line).get("n_gpus")
+            except ValueError:
+                pass
+    rc = p.wait()
+    if rc == 0 and seen != args.gpus:
+        print(f"bench.py: launched {args.gpus} ranks but the line reports n_gpus = {seen}", file=sys.stderr)
+        rc = 1
+    sys.exit(rc)
+
+
+def shared_graph(datagen, args, world, local_rank, dist):
+    """The synthetic CSR of this run.  N > 1: generated ONCE per node (local rank 0, numpy) and handed to the other
+    ranks through /dev/shm as read-only mappings -- the reference's parent loads the dataset once into shared
+    memory before it forks its workers (engine.cc:109-180) -- instead of N generations and N host copies."""
+    kw = dict(seed=42, neighbour_skew=args.neighbour_skew)
+    if world == 1:
+        return datagen.make_graph(args.preset, **kw)
+    import shutil
+    d = f"/dev/shm/ggms_bench_{os.environ.get('MASTER_PORT', '0')}_{os.getuid()}"
+    try:
+        if local_rank == 0:
+            shutil.rmtree(d, ignore_errors=True)
+            os.makedirs(d)
+            g = datagen.make_graph(args.preset, **kw)
+            for k in ("indptr", "indices", "train_set"):
+                np.save(os.path.join(d, k + ".npy"), g[k])
+            json.dump(g["meta"], open(os.path.join(d, "meta.json"), "w"))
+        dist.barrier()
+        if local_rank != 0:
+            g = {k: np.load(os.path.join(d, k + ".npy"), mmap_mode="r") for k in ("indptr", "indices", "train_set")}
+            g["meta"] = json.load(open(os.path.join(d, "meta.json")))
+        dist.barrier()  # everybody holds its mappings: the files can go
+    finally:
+        if local_rank == 0:
+            shutil.rmtree(d, ignore_errors=True)
+    return g
+
+
 def main():
     args = parse()
-    import torch
-    import torch.distributed as dist
-
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        launch_ranks(args)  # does not return
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:  # never measure one thing and print another
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # before the first HIP call of this process
+
+    import torch
+    import torch.distributed as dist
+
+    # one rank per GPU (counting devices does not initialise the GPU); the one-GPU rehearsal hook is explicit
+    if "GGMS_BENCH_DEVICE" not in os.environ and torch.cuda.device_count() < world:
+        raise SystemExit(f"bench.py: --gpus {world} needs {world} GPUs, this node shows {torch.cuda.device_count()} "
+                         "(one-GPU rehearsal: GGMS_BENCH_DEVICE=0 GGMS_BENCH_BACKEND=gloo)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (MI355X); there is no CPU fallback for the product path")
     # test hooks (one-GPU box): GGMS_BENCH_DEVICE pins every rank to one device, GGMS_BENCH_BACKEND=gloo avoids
@@ -203,7 +281,7 @@ def main():
         args.fanout = "25,10" if args.preset in ("products", "tiny") else "5,10,15"
     fanouts = [int(x) for x in args.fanout.split(",")]
     main_store = (args.store or "peer") if world > 1 else "local"
-    graph = datagen.make_graph(args.preset, seed=42)
+    graph = shared_graph(datagen, args, world, local_rank, dist)
     log("graph generated")
     meta = graph["meta"]
     N, dim = meta["num_node"], meta["feat_dim"]

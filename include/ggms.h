@@ -58,11 +58,18 @@ const char *ggms_last_error(void);
  * (logging.cc:69-73); kernels here cannot abort, so they OR a bit into this word and return:
  *   GGMS_STATUS_SCAN_SPIN   an ordered scan's look-back gave up waiting for a predecessor tile (protocol error);
  *   GGMS_STATUS_TABLE_FULL  the hashed dedup table had no free bucket for a key (sized too small).
- * Results of a call that set a bit are invalid.  ggms_sample_batch copies the word into counts_dev[3 L + 1];
- * ggms_device_status reads it directly (synchronises the device; clear != 0 also zeroes it). */
+ * Results of a call that set a bit are invalid.  The word is per DEVICE, shared by every table, sampler and stream:
+ *   - ggms_sample_batch TAKES it at the end of the batch (atomic exchange with 0 into counts_dev[3 L + 1]): the
+ *     failure is reported once, to the batch that ends next on that device (with several batches in flight that
+ *     may be a neighbour of the one that failed -- the engine aborts on any of them), and later batches start clean;
+ *   - leaf operators leave it set until ggms_device_status(clear != 0), which drains the device first
+ *     (hipDeviceSynchronize: kernels on non-blocking streams included) and then zeroes it. */
 #define GGMS_STATUS_SCAN_SPIN 1u
 #define GGMS_STATUS_TABLE_FULL 2u
 int ggms_device_status(uint32_t *status_host, int clear);
+/* Test aid: the next ordered scan of a direct-layout table fill (this process) starts with a poisoned ticket, so
+ * that its look-back runs into its bound and sets GGMS_STATUS_SCAN_SPIN.  One shot. */
+void ggms_debug_poison_next_scan(void);
 size_t ggms_dtype_bytes(int dtype);
 
 /* ---------------------------------------------------------------------------

@@ -51,6 +51,7 @@ def main():
     import samgraph.torch as sam
     fanout = [int(x) for x in extra.pop("fanout", "5 4").split()]
     pipelined = extra.pop("pipelined", "0") == "1"
+    die_worker = int(extra.pop("die_worker", -1))  # this worker exits before it initialises (deadline tests)
     cfg = {"dataset_path": dataset, "_arch": sam.builtin_archs[arch]["arch"],
            "_sample_type": sam.sample_types[extra.pop("sample_type", "khop3")],
            "batch_size": int(extra.pop("batch_size", 64)), "num_epoch": int(extra.pop("num_epoch", 2)),
@@ -83,6 +84,8 @@ def main():
         pid = os.fork()
         if pid == 0:
             try:
+                if w == die_worker:
+                    os._exit(0)
                 ctx = f"cuda:{w}"
                 sam.sample_init(w, ctx)
                 sam.train_init(w, ctx)

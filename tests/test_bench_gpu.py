@@ -56,6 +56,73 @@ def test_two_ranks_default_is_the_sharded_store():
     assert 0 < st["hybrid"]["remote_row_fraction"] < st["peer"]["remote_row_fraction"]
 
 
+def test_gpus_flag_alone_starts_the_ranks():
+    """The bare command `python bench.py --gpus 2` (no launcher around it, as the driver runs N = 1): the script
+    starts its two ranks itself and the line says n_gpus: 2 -- here both pinned to the box's one GPU by the hooks."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(GGMS_BENCH_DEVICE="0", GGMS_BENCH_BACKEND="gloo")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--preset", "tiny", "--steps", "4",
+                        "--warmup", "1", "--batch", "512", "--other-stores", ""],
+                       capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = _last_json(r.stdout)
+    assert KEYS <= set(d) and d["n_gpus"] == 2 and d["config"]["parallelism"] == "dp2" and d["rows_verified"]
+
+
+def test_five_ranks_one_gpu_peer_and_hybrid():
+    """Rehearsal of the 8-GPU launch as far as a one-GPU box allows (its process guard admits six processes on the
+    card, and the test runner is one of them): five ranks, five-way GGMS shards, every rank mapping four peers
+    through hipIpc; main region on the sharded store, the hybrid one (hot prefix replicated) measured beside it."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(GGMS_BENCH_DEVICE="0", GGMS_BENCH_BACKEND="gloo")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "5", "--preset", "tiny", "--steps", "3",
+                        "--warmup", "1", "--batch", "128", "--repeats", "1", "--other-stores", "hybrid"],
+                       capture_output=True, text=True, timeout=1200, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = _last_json(r.stdout)
+    assert d["n_gpus"] == 5 and d["rows_verified"] and set(d["stores"]) == {"peer", "hybrid"}
+    assert 0.7 < d["stores"]["peer"]["remote_row_fraction"] < 0.9  # 4/5 of the rows live on a peer
+    assert 0 < d["stores"]["hybrid"]["remote_row_fraction"] < d["stores"]["peer"]["remote_row_fraction"]
+
+
+_NCCL_SCRIPT = """
+import os, sys
+sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests"))
+import numpy as np, torch, torch.distributed as dist
+import oracle
+from xgnn_amd import ggms_store
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=sys.argv[1], HSA_ENABLE_IPC_MODE_LEGACY="0")
+torch.cuda.set_device(0)
+dev = torch.device("cuda", 0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+assert dist.get_backend() == "nccl"
+# the collectives of the exchange form, on the device, through RCCL
+send = torch.arange(12, dtype=torch.int32, device=dev)
+recv = torch.empty_like(send)
+ggms_store._all_to_all(dist, recv, send, [12], [12])
+assert torch.equal(recv, send) and recv.is_cuda
+N, dim = 5000, 24
+feat = np.random.RandomState(1).standard_normal((N, dim)).astype(np.float32)
+st = ggms_store.FeatureShards(torch.from_numpy(feat).to(dev), None, 1, 0, mode="a2a", dist=dist)
+assert st._exchange_counts([7]) == [7]
+nodes = np.random.RandomState(2).randint(0, N, 3000).astype(np.uint32)
+out = torch.zeros((3000, dim), dtype=torch.float32, device=dev)
+st.extract(torch.from_numpy(nodes.view(np.int32)).to(dev), 3000, out)
+assert out.cpu().numpy().tobytes() == oracle.extract(feat, nodes).tobytes()
+dist.destroy_process_group()
+print("nccl-ok")
+"""
+
+
+def test_rccl_branches_of_the_exchange_store(tmp_path):
+    """A world-size-1 RCCL process group drives `_all_to_all` / `_exchange_counts` through their on-device branches
+    (one rank per GPU is RCCL's rule, so one rank is what this box can give them)."""
+    script = tmp_path / "nccl1.py"
+    script.write_text(_NCCL_SCRIPT.format(root=os.path.abspath(ROOT)))
+    r = subprocess.run([sys.executable, str(script), str(_free_port())], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "nccl-ok" in r.stdout, r.stderr[-3000:]
+
+
 @pytest.mark.parametrize("store", ["replica", "peer", "a2a", "hybrid"])
 def test_two_ranks_one_gpu(store):
     env = dict(os.environ, GGMS_BENCH_DEVICE="0", GGMS_BENCH_BACKEND="gloo")

@@ -365,6 +365,55 @@ def test_arch6_two_workers_one_gpu(tmp_path, opts):
 
 
 @pytest.mark.gpu
+def test_arch6_five_workers_one_gpu(tmp_path):
+    """Rehearsal of the 8-GPU deployment as far as a one-GPU box allows (its process guard admits six processes on
+    the card, and the test runner is one of them): five forked workers, five-way topology shards + partitioned
+    feature cache + hot-row replica, every worker opening four peers through hipIpc, the deadline-carrying worker
+    barrier -- each worker against the oracle replay of ITS slice of the epoch (DistAlignedShuffler)."""
+    d = make_dataset(tmp_path / "ds")
+    prefix = str(tmp_path / "out")
+    W = 5
+    env = dict(os.environ, SAMGRAPH_FORCE_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, DRIVER, d["path"], prefix, "arch6", str(W), "seed=7", "batch_size=32", "fanout=5 4",
+                        "cache_percentage=0.4", "part_cache=True", "gpu_extract=True", "use_dist_graph=1.0",
+                        "replicate_percentage=0.25", "num_epoch=1"],
+                       capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    for w in range(W):
+        _check(np.load(f"{prefix}.w{w}.npz"), _oracle_batches(d, w, W, 32, 1, [5, 4], 7, arch6=True), 2)
+
+
+@pytest.mark.gpu
+def test_arch6_worker_that_never_arrives_ends_the_run(tmp_path):
+    """A worker that dies before publishing its shards: the others must not wait forever at the worker barrier
+    (pthread_barrier_wait would) -- they abort with a message once SAMGRAPH_IPC_TIMEOUT_S has passed."""
+    import time
+    d = make_dataset(tmp_path / "ds")
+    env = dict(os.environ, SAMGRAPH_FORCE_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0", SAMGRAPH_IPC_TIMEOUT_S="4")
+    t0 = time.time()
+    r = subprocess.run([sys.executable, DRIVER, d["path"], str(tmp_path / "out"), "arch6", "2", "seed=7", "batch_size=64",
+                        "fanout=5 4", "cache_percentage=0.4", "part_cache=True", "gpu_extract=True", "use_dist_graph=1.0",
+                        "die_worker=1"], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode != 0 and time.time() - t0 < 120
+    assert "worker barrier" in r.stderr and "1 of 2 workers arrived" in r.stderr, r.stderr[-2000:]
+
+
+@pytest.mark.gpu
+def test_arch6_staged_extract_uses_the_configured_host_team(tmp_path):
+    """`gpu_extract` off (the reference's SGNN mode): the miss rows are gathered by omp_thread_num host threads
+    (cuda_cache_manager_host.cc:268-300 `omp parallel for num_threads(omp_thread_num)`), under arch6 too."""
+    d = make_dataset(tmp_path / "ds")
+    prefix = str(tmp_path / "out")
+    env = dict(os.environ, SAMGRAPH_FORCE_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0", SAMGRAPH_LOG_LEVEL="info")
+    r = subprocess.run([sys.executable, DRIVER, d["path"], prefix, "arch6", "1", "seed=7", "batch_size=64", "fanout=5 4",
+                        "cache_percentage=0.3", "omp_thread_num=5", "num_epoch=1"],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert "host team of 5 threads" in r.stderr
+    _check(np.load(f"{prefix}.w0.npz"), _oracle_batches(d, 0, 1, 64, 1, [5, 4], 7, arch6=True), 2)
+
+
+@pytest.mark.gpu
 def test_cpp_driver_over_the_c_abi(tmp_path):
     """A pure C++ caller (tools/samgraph_no_train.cc, the role of samgraph/main.cc) drives the same ABI."""
     exe = os.path.join(ROOT, "build", "samgraph_no_train")

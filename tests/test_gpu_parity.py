@@ -75,9 +75,9 @@ def test_stuck_scan_sets_the_status_word(ops, monkeypatch):
     ht = ops.OrderedHashTable(N, num_node=N)
     ht.reset()
     keys = dev(np.random.RandomState(1).randint(0, N, 10_000).astype(np.uint32))
-    monkeypatch.setenv("GGMS_TEST_POISON_SCAN", "1")
+    from xgnn_amd import lib
+    lib().ggms_debug_poison_next_scan()  # one shot
     ht.fill_with_duplicates(keys)
-    monkeypatch.delenv("GGMS_TEST_POISON_SCAN")
     assert ops.device_status(clear=True) & 1  # GGMS_STATUS_SCAN_SPIN
     ht.reset()
     ht.fill_with_duplicates(keys)  # the same table and a clean scan area work again

@@ -28,10 +28,35 @@ uint32_t *device_status_word() {
   if (!words[dev]) {
     uint32_t *p = nullptr;
     if (hipMalloc((void **)&p, 64) != hipSuccess) return nullptr;
-    if (hipMemset(p, 0, 64) != hipSuccess) return nullptr;
+    if (hipMemset(p, 0, 64) != hipSuccess) {
+      (void)hipFree(p);
+      return nullptr;
+    }
     words[dev] = p;
   }
   return words[dev];
+}
+
+// LDS one workgroup may use on the current device (gfx950: 160 KB), 0 if it cannot be read
+size_t device_lds_bytes() {
+  int dev = 0, v = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 0;
+  if (hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) != hipSuccess || v <= 0) return 0;
+  return (size_t)v;
+}
+
+// Several kernels keep their working set in more than the default 64 KB of dynamic LDS (khop3 at large fan-outs,
+// the random-walk top-K tile, the one-workgroup sort).  They are written for gfx950's 160 KB; on a device with
+// less the request fails HERE with a message instead of as a bare launch error.
+int raise_dynamic_lds(const void *func, size_t bytes, const char *who) {
+  const size_t have = device_lds_bytes();
+  if (have != 0 && bytes > have) {
+    set_error("%s needs %zu bytes of LDS per workgroup, this device offers %zu: the library is built for gfx950 (160 KB)",
+              who, bytes, have);
+    return GGMS_ERR_INVALID;
+  }
+  GGMS_HIP(hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+  return GGMS_OK;
 }
 
 unsigned long long next_dedup_tag() {
@@ -66,8 +91,13 @@ int ggms_device_status(uint32_t *status_host, int clear) {
     set_error("ggms_device_status: no device status word (no device?)");
     return GGMS_ERR_NO_DEVICE;
   }
-  GGMS_HIP(hipMemcpy(status_host, w, sizeof(uint32_t), hipMemcpyDeviceToHost)); // synchronises the device
-  if (clear && *status_host) GGMS_HIP(hipMemset(w, 0, sizeof(uint32_t)));
+  // kernels OR into the word from non-blocking streams, which a null-stream copy does not wait for: drain the device
+  GGMS_HIP(hipDeviceSynchronize());
+  GGMS_HIP(hipMemcpy(status_host, w, sizeof(uint32_t), hipMemcpyDeviceToHost));
+  if (clear && *status_host) {
+    GGMS_HIP(hipMemset(w, 0, sizeof(uint32_t)));
+    GGMS_HIP(hipDeviceSynchronize());
+  }
   return GGMS_OK;
 }
 

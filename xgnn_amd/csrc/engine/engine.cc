@@ -10,14 +10,19 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
 #include <iostream>
+#include <memory>
+#include <mutex>
 #include <random>
 #include <sstream>
+#include <thread>
 
 namespace sam {
 
@@ -35,7 +40,9 @@ void log_info(const std::string &msg) {
 // process-shared control block for arch6 workers (dist_graph.cu:566-636: anonymous MAP_SHARED mmap +
 // PTHREAD_PROCESS_SHARED barrier, inherited through fork)
 struct Engine::Shared {
-  pthread_barrier_t barrier;
+  // worker barrier with a deadline (pthread_barrier_wait has none): arrivals of the current generation + the
+  // generation counter; zero-initialised by the anonymous mapping, lock-free atomics are valid across processes
+  std::atomic<uint32_t> arrived, generation;
   int num_worker;
   static constexpr int kMaxWorker = 16;
   hipIpcMemHandle_t graph_indptr[kMaxWorker], graph_indices[kMaxWorker], feat_part[kMaxWorker];
@@ -75,6 +82,8 @@ void Engine::Configure(const std::unordered_map<std::string, std::string> &kv_in
   cfg.cache_percentage = std::stod(kv["cache_percentage"]);
   cfg.num_layer = std::stoull(kv["num_layer"]);
   SAM_CHECK(cfg.batch_size > 0 && cfg.num_layer >= 1 && cfg.num_layer <= 16, "batch_size >= 1 and 1 <= num_layer <= 16");
+  // every deployment: arch0's sampler / extractor team and arch6's host-staged miss path (gpu_extract off) use it
+  cfg.omp_thread_num = std::max<size_t>(1, std::stoull(kv["omp_thread_num"]));
   switch (cfg.arch) { // operation.cc:101-148
     case kArch1:
       SAM_CHECK(kv.count("sampler_ctx") && kv.count("trainer_ctx"), "arch1 needs sampler_ctx/trainer_ctx");
@@ -86,7 +95,6 @@ void Engine::Configure(const std::unordered_map<std::string, std::string> &kv_in
       SAM_CHECK(kv.count("sampler_ctx") && kv.count("trainer_ctx"), "arch0 needs sampler_ctx/trainer_ctx");
       cfg.trainer_on_host = kv["trainer_ctx"].rfind("cpu", 0) == 0;
       cfg.trainer_device = parse_device(kv["trainer_ctx"]);
-      cfg.omp_thread_num = std::max<size_t>(1, std::stoull(kv["omp_thread_num"]));
       cfg.num_worker = 1;
       break;
     case kArch6:
@@ -277,18 +285,73 @@ void Engine::DataInit() {
     shared_ = (Shared *)mmap(nullptr, sizeof(Shared), PROT_READ | PROT_WRITE, MAP_SHARED | MAP_ANONYMOUS, -1, 0);
     SAM_CHECK(shared_ != MAP_FAILED, "control block mmap failed");
     SAM_CHECK(cfg.num_worker <= (size_t)Shared::kMaxWorker, "too many workers");
-    pthread_barrierattr_t attr;
-    pthread_barrierattr_init(&attr);
-    pthread_barrierattr_setpshared(&attr, PTHREAD_PROCESS_SHARED);
-    pthread_barrier_init(&shared_->barrier, &attr, (unsigned)cfg.num_worker);
+    static_assert(std::atomic<uint32_t>::is_always_lock_free, "the worker barrier lives in shared memory");
+    shared_->arrived.store(0);
+    shared_->generation.store(0);
     shared_->num_worker = (int)cfg.num_worker;
   }
   prof.LogInit(/*kLogInitL2LoadDataset*/ 6, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
   data_ready_ = true;
 }
 
-void Engine::Barrier() {
-  if (shared_ && cfg.num_worker > 1) pthread_barrier_wait(&shared_->barrier);
+// Every wait on another worker has a deadline (SAMGRAPH_IPC_TIMEOUT_S, default 300 s): a worker that died, or a
+// hipIpcOpenMemHandle that never returns (seen on ROCm 7.2 for exporter sizes with bit 31 set, include/ggms.h
+// ggms_ipc_safe_bytes), must end the run with a message instead of holding it until somebody's time limit.
+static double ipc_timeout_s() {
+  static const double v = [] { const char *e = getenv("SAMGRAPH_IPC_TIMEOUT_S"); const double x = e ? atof(e) : 0; return x > 0 ? x : 300.0; }();
+  return v;
+}
+
+void Engine::Barrier(const char *what) {
+  if (!shared_ || cfg.num_worker <= 1) return;
+  const uint32_t gen = shared_->generation.load(std::memory_order_acquire);
+  const uint32_t here = shared_->arrived.fetch_add(1, std::memory_order_acq_rel) + 1;
+  if (here == (uint32_t)cfg.num_worker) { // last one in: re-arm, then release the others
+    shared_->arrived.store(0, std::memory_order_relaxed);
+    shared_->generation.fetch_add(1, std::memory_order_release);
+    return;
+  }
+  const auto t0 = std::chrono::steady_clock::now();
+  for (uint64_t spin = 0;; ++spin) {
+    if (shared_->generation.load(std::memory_order_acquire) != gen) return;
+    if (spin < 4096) continue; // a step barrier is usually released within microseconds
+    if ((spin & 63) == 0) {
+      const double waited = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+      if (waited > ipc_timeout_s())
+        fatal(__FILE__, __LINE__, "worker " + std::to_string(worker_id_) + " (device " + std::to_string(device_) + ") waited " +
+                                      std::to_string((int)waited) + " s at the worker barrier '" + what + "': " +
+                                      std::to_string(shared_->arrived.load()) + " of " + std::to_string(cfg.num_worker) +
+                                      " workers arrived -- a worker died or is stuck (SAMGRAPH_IPC_TIMEOUT_S)");
+    }
+    spin < 65536 ? (void)sched_yield() : (void)usleep(200);
+  }
+}
+
+// hipIpcOpenMemHandle under a deadline: the call runs on a helper thread; if it has not returned in time the process
+// ends with a message (the thread cannot be cancelled, so there is nothing to retry in-process).
+void *Engine::OpenPeer(const hipIpcMemHandle_t &handle, uint32_t peer, size_t bytes, const char *what) {
+  struct State { std::mutex m; std::condition_variable cv; bool done = false; hipError_t err = hipSuccess; void *ptr = nullptr; };
+  auto st = std::make_shared<State>();
+  const int dev = device_;
+  std::thread([st, handle, dev] {
+    void *p = nullptr;
+    hipError_t e = hipSetDevice(dev);
+    if (e == hipSuccess) e = hipIpcOpenMemHandle(&p, handle, hipIpcMemLazyEnablePeerAccess);
+    std::lock_guard<std::mutex> g(st->m);
+    st->err = e;
+    st->ptr = p;
+    st->done = true;
+    st->cv.notify_all();
+  }).detach();
+  std::unique_lock<std::mutex> lk(st->m);
+  if (!st->cv.wait_for(lk, std::chrono::duration<double>(ipc_timeout_s()), [&] { return st->done; }))
+    fatal(__FILE__, __LINE__, std::string("hipIpcOpenMemHandle(") + what + ") did not return within " +
+                                  std::to_string((int)ipc_timeout_s()) + " s: worker " + std::to_string(worker_id_) + " (device " +
+                                  std::to_string(device_) + ") opening the shard of worker " + std::to_string(peer) + ", " +
+                                  std::to_string(bytes) + " bytes (SAMGRAPH_IPC_TIMEOUT_S)");
+  SAM_CHECK(st->err == hipSuccess, std::string("hipIpcOpenMemHandle(") + what + ") from worker " + std::to_string(peer) + ": " +
+                                       hipGetErrorString(st->err));
+  return st->ptr;
 }
 
 // ------------------------------------------------------------------ shuffler
@@ -423,13 +486,15 @@ void Engine::UploadGraph() {
   if (P > 1) {
     SAM_HIP(hipIpcGetMemHandle(&shared_->graph_indptr[p], part_indptr_[p]));
     SAM_HIP(hipIpcGetMemHandle(&shared_->graph_indices[p], part_indices_[p]));
-    Barrier();
+    shared_->indptr_words[p] = isz;
+    shared_->indices_words[p] = ecount;
+    Barrier("graph shards published");
     for (uint32_t q = 0; q < P; ++q) {
       if (q == p) continue;
-      SAM_HIP(hipIpcOpenMemHandle(&part_indptr_[q], shared_->graph_indptr[q], hipIpcMemLazyEnablePeerAccess));
-      SAM_HIP(hipIpcOpenMemHandle(&part_indices_[q], shared_->graph_indices[q], hipIpcMemLazyEnablePeerAccess));
+      part_indptr_[q] = OpenPeer(shared_->graph_indptr[q], q, shared_->indptr_words[q] * 4, "graph indptr shard");
+      part_indices_[q] = OpenPeer(shared_->graph_indices[q], q, shared_->indices_words[q] * 4, "graph indices shard");
     }
-    Barrier();
+    Barrier("graph shards opened");
   }
   // slot P: the whole CSR in (device-mapped) host memory, :367-381
   part_indptr_[P] = (void *)map_host(ds.indptr.ptr, ds.indptr.bytes);
@@ -520,7 +585,7 @@ void Engine::SampleInit(int worker_id, const std::string &ctx) {
   if (cfg.UsePresample()) { // dist_engine.cc:455-466: worker 0 ranks the nodes, everybody waits
     auto t0 = std::chrono::steady_clock::now();
     if (worker_id_ == 0) Presample();
-    Barrier();
+    Barrier("presample ranking");
     prof.LogInit(/*kLogInitL2Presample*/ 8, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
   }
   sample_ready_ = true;
@@ -637,10 +702,11 @@ void Engine::BuildCache() {
   SAM_HIP(hipStreamSynchronize(stream_));
   if (P > 1) { // _DataIpcShare
     SAM_HIP(hipIpcGetMemHandle(&shared_->feat_part[p], cache_parts_[p]));
-    Barrier();
+    shared_->feat_rows[p] = my_rows;
+    Barrier("feature shards published");
     for (uint32_t q = 0; q < P; ++q)
-      if (q != p) SAM_HIP(hipIpcOpenMemHandle(&cache_parts_[q], shared_->feat_part[q], hipIpcMemLazyEnablePeerAccess));
-    Barrier();
+      if (q != p) cache_parts_[q] = OpenPeer(shared_->feat_part[q], q, shared_->feat_rows[q] * row_bytes, "feature shard");
+    Barrier("feature shards opened");
   }
   d_cache_parts_tab_ = dev_upload(cache_parts_.data(), P * sizeof(void *), stream_);
   num_cache_part_ = cfg.part_cache ? P : 0;
@@ -854,7 +920,10 @@ bool Engine::EnqueueOne(bool background) {
 void Engine::StagedExtract(Batch *b, hipStream_t xs) {
   const uint32_t L = (uint32_t)cfg.fanout.size();
   const size_t row_bytes = ds.feat_dim * ggms_dtype_bytes(ds.feat_dtype);
-  if (!host_team_) host_team_ = std::make_unique<Team>((int)std::max<size_t>(1, cfg.omp_thread_num));
+  if (!host_team_) {
+    host_team_ = std::make_unique<Team>((int)std::max<size_t>(1, cfg.omp_thread_num));
+    log_info("staged extract: host team of " + std::to_string(host_team_->size()) + " threads (omp_thread_num)");
+  }
   uint64_t *n_in = b->counts_dev + 3 * L, *n_miss = b->counts_dev + 3 * L + 2, *n_hit = b->counts_dev + 3 * L + 3;
   SAM_HIP(hipMemcpyAsync(b->counts, b->counts_dev, (3 * L + 8) * 8, hipMemcpyDeviceToHost, xs));
   SAM_HIP(hipStreamSynchronize(xs)); // the batch is sampled: its size is known on the host

@@ -181,7 +181,8 @@ class Engine {
   uint64_t BatchKey(uint64_t epoch, uint64_t step) const { return epoch * num_global_step_ + step; }
   int trainer_device() const { return device_; }
   int batch_device_type() const { return (cfg.arch == kArch0 && cfg.trainer_on_host) ? 0 : 2; } // DeviceType, common.h:48
-  void Barrier();
+  void Barrier(const char *what = "step");
+  void *OpenPeer(const hipIpcMemHandle_t &handle, uint32_t peer, size_t bytes, const char *what);
 
  private:
   // dataset

@@ -219,6 +219,8 @@ struct DedupInsert {
   }
 };
 unsigned long long next_dedup_tag(); // common.hip
+size_t device_lds_bytes();                                                       // common.hip
+int raise_dynamic_lds(const void *func, size_t bytes, const char *who);          // common.hip
 
 // ---- wave / block prefix sums (wave64) -------------------------------------
 __device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }

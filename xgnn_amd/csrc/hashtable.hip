@@ -31,6 +31,7 @@
 //         the fills' own outputs (IdxMap) -- k_owner_scan<true>, k_map_rest_all.
 // The hashed layout keeps the reference's sizing (TableSize) and the re-read form (OwnerFlag / AssignLocal).
 #include <algorithm>
+#include <atomic>
 
 #include "ggms_internal.h"
 #include "tile_scan.h"
@@ -203,8 +204,10 @@ __global__ __launch_bounds__(kBlock) void k_map_rest(Table t, const uint32_t *__
 // own fill.  A key's word is final once its fill is over, so the look-ups of all layers can wait until the last
 // fill is done.  Also hands the device status word to the batch's counts (counts_dev[3 L + 1]).
 __global__ __launch_bounds__(kBlock) void k_map_rest_all(const unsigned long long *__restrict__ w, MapRestJobs jobs,
-                                                         IdxMap map, const uint32_t *status, uint64_t *status_out) {
-  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && status_out) *status_out = status ? *status : 0u;
+                                                         IdxMap map, uint32_t *status, uint64_t *status_out) {
+  // the batch TAKES the device word (exchange with 0): a failure is reported to the batch that ends next, once,
+  // and does not mark every later batch of the device as failed
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && status_out) *status_out = status ? atomicExch(status, 0u) : 0u;
   const uint32_t l = blockIdx.y;
   uint32_t *__restrict__ row = jobs.row[l];
   const uint32_t *__restrict__ key = jobs.key[l];
@@ -354,6 +357,8 @@ __global__ __launch_bounds__(kBlock) void k_owner_scan(unsigned long long *__res
   }
 }
 
+static std::atomic<bool> g_poison_next_scan{false};
+
 static size_t owner_scan_grid_cap() { // GGMS_OSCAN_GRID: measurement hook
   static const size_t v = [] { const char *e = getenv("GGMS_OSCAN_GRID"); const long x = e ? atol(e) : 0; return x > 0 ? (size_t)x : (size_t)512; }();
   return v;
@@ -365,21 +370,21 @@ size_t owner_scan_tiles(size_t n_max) { return (n_max + kOwnTile - 1) / kOwnTile
 // workspace of one fill: cand / item_pos [n], lost [n] (64-bit), scan area
 size_t ht_ws_words(size_t num_input) { return 3 * num_input + tile_scan_words(num_input) + 24; }
 
-__global__ void k_status_copy(const uint32_t *status, uint64_t *status_out) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) *status_out = status ? *status : 0u;
+__global__ void k_status_copy(uint32_t *status, uint64_t *status_out) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) *status_out = status ? atomicExch(status, 0u) : 0u;
 }
 
 int launch_map_rest_all(const ggms_hashtable_t *ht, const MapRestJobs &jobs, uint32_t num_jobs, size_t max_items,
                         const IdxMap &map, uint64_t *status_out, hipStream_t s) {
   if (num_jobs == 0) { // nothing deferred (hashed layout, or no layer could sample): only the status word
     if (!status_out) return GGMS_OK;
-    hipLaunchKernelGGL(k_status_copy, dim3(1), dim3(64), 0, s, (const uint32_t *)device_status_word(), status_out);
+    hipLaunchKernelGGL(k_status_copy, dim3(1), dim3(64), 0, s, device_status_word(), status_out);
     GGMS_LAUNCH_CHECK();
     return GGMS_OK;
   }
   const int gx = grid_for(max_items ? max_items : 1, kBlock);
   hipLaunchKernelGGL(k_map_rest_all, dim3(gx, num_jobs), dim3(kBlock), 0, s, (const unsigned long long *)ht->o2n, jobs, map,
-                     (const uint32_t *)(status_out ? device_status_word() : nullptr), status_out);
+                     status_out ? device_status_word() : (uint32_t *)nullptr, status_out);
   GGMS_LAUNCH_CHECK();
   return GGMS_OK;
 }
@@ -426,9 +431,9 @@ int ht_fill_impl(const ggms_hashtable_t *ht, const uint32_t *input, size_t n_max
   unsigned long long *desc = reinterpret_cast<unsigned long long *>(ctl + 8);
   if (!scratch.cleared) {
     GGMS_HIP(hipMemsetAsync(ctl, 0, (8 + 2 * (owner_scan_tiles(n_max) + 1)) * sizeof(uint32_t), s));
-    // test hook (tests/test_gpu_parity.py): start the ticket at 1, so tile 0 is never processed and every later
+    // ggms_debug_poison_next_scan (tests): start the ticket at 1, so tile 0 is never processed and every later
     // tile's look-back runs into its bound -- the failure the status word exists for
-    if (getenv("GGMS_TEST_POISON_SCAN")) GGMS_HIP(hipMemsetD32Async((hipDeviceptr_t)ctl, 1, 1, s));
+    if (g_poison_next_scan.exchange(false)) GGMS_HIP(hipMemsetD32Async((hipDeviceptr_t)ctl, 1, 1, s));
   }
   // Fewer workgroups than tiles on purpose: a workgroup takes tiles from the ticket one after the other, so by the
   // time tile t is taken the tiles before t - grid have finished and the look-back finds a published prefix in
@@ -461,6 +466,8 @@ using namespace ggms;
 extern "C" {
 
 // TableSize(num, scale = kDefaultScale = 2): cuda_hashtable.cu:146-149, cuda_hashtable.h:105
+void ggms_debug_poison_next_scan(void) { g_poison_next_scan.store(true); }
+
 size_t ggms_hashtable_num_buckets(size_t capacity) {
   size_t half = capacity >> 1;
   size_t lg = 0; // floor(log2(half)); the reference's std::log2(0) = -inf case maps to 1 bucket << scale

@@ -257,12 +257,9 @@ inline int radix_sort_pairs(uint32_t *k0, uint32_t *v0, uint32_t *k1, uint32_t *
     uint32_t passes = 4; // 8-bit digits here
     for (uint32_t p = 1; p < 4; ++p)
       if (key_limit && (unsigned long long)key_limit <= (1ull << (8 * p)) - 1ull) { passes = p; break; }
-    static const bool once = [] {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sort_small), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                4 * kSmallSort * sizeof(uint32_t));
-      return true;
-    }();
-    (void)once;
+    static const int raised = raise_dynamic_lds(reinterpret_cast<const void *>(&k_sort_small),
+                                                4 * kSmallSort * sizeof(uint32_t), "k_sort_small");
+    if (raised != GGMS_OK) return raised;
     hipLaunchKernelGGL(k_sort_small, dim3(1), dim3(1024), 4 * kSmallSort * sizeof(uint32_t), s, k0, v0, k1, v1, n, passes);
     GGMS_LAUNCH_CHECK();
     *in_second = true;

@@ -664,18 +664,18 @@ static int khop3_groups_per_wave(size_t blocks) {
 size_t sample_ws_words(size_t num_input) { return num_input + tile_scan_words(num_input) + 16 + 2 * (num_input / 128 + 2); }
 
 template <int GPW, bool INSERT>
-static void launch_khop3_fused(int grid, size_t lds, hipStream_t s, GraphView g, const uint32_t *input, Count n,
+static int launch_khop3_fused(int grid, size_t lds, hipStream_t s, GraphView g, const uint32_t *input, Count n,
                                uint32_t fanout, uint32_t *out_src, uint32_t *out_dst, SrcMode sm, uint32_t *states,
                                uint32_t set_mask, FusedScan fs, DedupInsert di) {
   const uint32_t fanout_magic = (uint32_t)((0x100000000ull + fanout - 1) / fanout); // ceil(2^32 / fanout)
   if (lds > (48u << 10)) { // large fan-outs: more dynamic LDS than the default per-kernel limit (gfx950 has 160 KB)
-    static std::atomic<bool> raised{false};
-    if (!raised.exchange(true))
-      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_khop3_fused<GPW, INSERT>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 127 * 4);
+    static const int raised = raise_dynamic_lds(reinterpret_cast<const void *>(&k_khop3_fused<GPW, INSERT>), 128 * 127 * 4,
+                                                "k_khop3_fused (fanout >= 96)");
+    if (raised != GGMS_OK) return raised;
   }
   hipLaunchKernelGGL((k_khop3_fused<GPW, INSERT>), dim3(grid), dim3(128 * (4 / GPW)), lds, s, g, input, n, fanout,
                      fanout_magic, out_src, out_dst, sm, states, set_mask, fs, di);
+  return GGMS_OK;
 }
 
 // the whole layer in one launch (see k_khop3_fused).  shared_scan: the batch's scan area (cleared by the batch
@@ -698,15 +698,17 @@ int sample_khop3_impl(GraphView g, const uint32_t *input, size_t n_max, Count n,
   const int grid = grid_for(tiles, 1);
   const size_t lds = 128 * (size_t)fanout * sizeof(uint32_t);
   const DedupInsert none{};
+  int rc_l = GGMS_OK;
   if (insert) {
-    if (gpw == 1) launch_khop3_fused<1, true>(grid, lds, s, g, input, n, fanout, out_src, out_dst, sm, states, set_mask, fs, *insert);
-    else if (gpw == 2) launch_khop3_fused<2, true>(grid, lds, s, g, input, n, fanout, out_src, out_dst, sm, states, set_mask, fs, *insert);
-    else launch_khop3_fused<4, true>(grid, lds, s, g, input, n, fanout, out_src, out_dst, sm, states, set_mask, fs, *insert);
+    if (gpw == 1) rc_l = launch_khop3_fused<1, true>(grid, lds, s, g, input, n, fanout, out_src, out_dst, sm, states, set_mask, fs, *insert);
+    else if (gpw == 2) rc_l = launch_khop3_fused<2, true>(grid, lds, s, g, input, n, fanout, out_src, out_dst, sm, states, set_mask, fs, *insert);
+    else rc_l = launch_khop3_fused<4, true>(grid, lds, s, g, input, n, fanout, out_src, out_dst, sm, states, set_mask, fs, *insert);
   } else {
-    if (gpw == 1) launch_khop3_fused<1, false>(grid, lds, s, g, input, n, fanout, out_src, out_dst, sm, states, set_mask, fs, none);
-    else if (gpw == 2) launch_khop3_fused<2, false>(grid, lds, s, g, input, n, fanout, out_src, out_dst, sm, states, set_mask, fs, none);
-    else launch_khop3_fused<4, false>(grid, lds, s, g, input, n, fanout, out_src, out_dst, sm, states, set_mask, fs, none);
+    if (gpw == 1) rc_l = launch_khop3_fused<1, false>(grid, lds, s, g, input, n, fanout, out_src, out_dst, sm, states, set_mask, fs, none);
+    else if (gpw == 2) rc_l = launch_khop3_fused<2, false>(grid, lds, s, g, input, n, fanout, out_src, out_dst, sm, states, set_mask, fs, none);
+    else rc_l = launch_khop3_fused<4, false>(grid, lds, s, g, input, n, fanout, out_src, out_dst, sm, states, set_mask, fs, none);
   }
+  if (rc_l != GGMS_OK) return rc_l;
   GGMS_LAUNCH_CHECK();
   return GGMS_OK;
 }

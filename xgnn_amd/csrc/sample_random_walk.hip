@@ -244,20 +244,18 @@ int random_walk_raw_impl(GraphView g, const uint32_t *input, size_t n_max, Count
 }
 
 template <uint32_t T, bool INSERT, bool SPILL>
-static void launch_topk_emit(int grid, size_t lds, hipStream_t s, uint32_t *tmp_src, uint32_t *tmp_dst,
+static int launch_topk_emit(int grid, size_t lds, hipStream_t s, uint32_t *tmp_src, uint32_t *tmp_dst,
                              Count n, uint64_t stride, uint32_t per, uint32_t K, uint32_t Kc, const uint32_t *input,
                              SrcMode sm, uint32_t *out_src, uint32_t *out_dst, uint32_t *out_data, FusedScan fs,
                              DedupInsert di) {
   if (lds > 48 * 1024) {
-    static const bool once = [] {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_walk_topk_emit<T, INSERT, SPILL>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
-      return true;
-    }();
-    (void)once;
+    static const int raised = raise_dynamic_lds(reinterpret_cast<const void *>(&k_walk_topk_emit<T, INSERT, SPILL>),
+                                                160 * 1024 - 4096, "k_walk_topk_emit");
+    if (raised != GGMS_OK) return raised;
   }
   hipLaunchKernelGGL((k_walk_topk_emit<T, INSERT, SPILL>), dim3(grid), dim3(T), lds, s, tmp_src, tmp_dst, n, stride, per, K,
                      Kc, input, sm, out_src, out_dst, out_data, fs, di);
+  return GGMS_OK;
 }
 
 // shared_scan: the batch's scan area (cleared by the batch prologue); else the workspace holds a private one that
@@ -286,13 +284,14 @@ int sample_random_walk_impl(GraphView g, const uint32_t *input, size_t n_max, Co
   const size_t lds = spill ? 0 : 2 * (size_t)(per + Kc) * T * sizeof(uint32_t);
   const int grid = grid_for(tiles, 1);
   const DedupInsert none{};
+  int rc_l = GGMS_OK;
 #define GGMS_TOPK(TT, SP)                                                                                          \
   do {                                                                                                             \
     if (insert)                                                                                                    \
-      launch_topk_emit<TT, true, SP>(grid, lds, s, tmp_src, tmp_dst, n, (uint64_t)n_max, per, K, Kc, input, sm,    \
+      rc_l = launch_topk_emit<TT, true, SP>(grid, lds, s, tmp_src, tmp_dst, n, (uint64_t)n_max, per, K, Kc, input, sm,    \
                                      out_src, out_dst, out_data, fs, *insert);                                     \
     else                                                                                                           \
-      launch_topk_emit<TT, false, SP>(grid, lds, s, tmp_src, tmp_dst, n, (uint64_t)n_max, per, K, Kc, input, sm,   \
+      rc_l = launch_topk_emit<TT, false, SP>(grid, lds, s, tmp_src, tmp_dst, n, (uint64_t)n_max, per, K, Kc, input, sm,   \
                                       out_src, out_dst, out_data, fs, none);                                       \
   } while (0)
   if (spill) GGMS_TOPK(64, true);
@@ -300,6 +299,7 @@ int sample_random_walk_impl(GraphView g, const uint32_t *input, size_t n_max, Co
   else if (T == 128) GGMS_TOPK(128, false);
   else GGMS_TOPK(64, false);
 #undef GGMS_TOPK
+  if (rc_l != GGMS_OK) return rc_l;
   GGMS_LAUNCH_CHECK();
   return GGMS_OK;
 }

@@ -38,8 +38,20 @@ def powerlaw_degrees(num_node, mean_deg, alpha, dmax, rng):
     return np.minimum(dmax, np.floor(hi * base)).astype(np.int64)
 
 
-def make_graph(preset="products", seed=42, chunk=1 << 24):
-    """Returns dict(indptr uint32[N+1], indices uint32[E], train_set uint32[T], meta)."""
+def _host_threads():
+    import os
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    return max(1, min(16, n))
+
+
+def make_graph(preset="products", seed=42, chunk=1 << 24, neighbour_skew=0.0, threads=None):
+    """Returns dict(indptr uint32[N+1], indices uint32[E], train_set uint32[T], meta).
+
+    neighbour_skew = 0 (the default everywhere): neighbour ids uniform over the nodes.
+    neighbour_skew = p in (0, 1]: each neighbour is, with probability p, the OWNER OF A UNIFORMLY RANDOM EDGE SLOT
+    (probability proportional to the node's degree -- the hubs of the power law turn up in many lists, as in a real
+    symmetrised graph) and uniform otherwise.  Chunks are seeded one by one, so the result does not depend on the
+    number of host threads that fill them."""
     p = dict(PRESETS[preset]) if isinstance(preset, str) else dict(preset)
     rng = np.random.RandomState(seed)
     n = p["num_node"]
@@ -49,11 +61,33 @@ def make_graph(preset="products", seed=42, chunk=1 << 24):
     num_edge = int(indptr[-1])
     assert num_edge < 2 ** 32, "IdType is uint32 (constant.h:28): num_edge must stay below 2^32"
     indices = np.empty(num_edge, dtype=np.uint32)
-    for s in range(0, num_edge, chunk):  # chunked: bounded temporaries
+    owner = None
+    if neighbour_skew > 0:  # owner[e] = the node whose list holds edge slot e
+        owner = np.repeat(np.arange(n, dtype=np.uint32), deg)
+
+    def fill(s):  # chunked: bounded temporaries; numpy releases the GIL in randint / take
         e = min(num_edge, s + chunk)
-        indices[s:e] = np.random.RandomState(1234 + s // chunk).randint(0, n, size=e - s, dtype=np.int64)
+        ids = np.random.RandomState(1234 + s // chunk).randint(0, n, size=e - s, dtype=np.int64)
+        if owner is not None:
+            r2 = np.random.RandomState(991234 + s // chunk)
+            slot = r2.randint(0, num_edge, size=e - s, dtype=np.int64)
+            hub = r2.random_sample(e - s) < neighbour_skew
+            ids = np.where(hub, owner.take(slot), ids)
+        indices[s:e] = ids
+
+    starts = range(0, num_edge, chunk)
+    nt = threads or _host_threads()
+    if nt > 1 and len(starts) > 1:
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(nt) as ex:
+            list(ex.map(fill, starts))
+    else:
+        for s in starts:
+            fill(s)
+    del owner
     train = np.random.RandomState(seed + 1).permutation(n)[: p["num_train"]].astype(np.uint32)
     p["num_edge"] = num_edge
+    p["neighbour_skew"] = float(neighbour_skew)
     return dict(indptr=indptr.astype(np.uint32), indices=indices, train_set=train, meta=p)
 
 

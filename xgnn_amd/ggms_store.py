@@ -14,8 +14,55 @@ not cached stay in host memory.  Two interchangeable ways to bring a batch's row
 Both produce the bytes `extract(full_table, nodes)` would.  The device work goes through `leaf` (default:
 the HIP operators of xgnn_amd.ops); tests exercise the host logic on CPU ranks by passing their own leaf.
 """
+import os
+import sys
+import threading
+
 import numpy as np
 import torch
+
+
+def ipc_timeout_s():
+    """Deadline of every wait on a peer while the shards are connected (GGMS_IPC_TIMEOUT_S, default 120 s)."""
+    try:
+        v = float(os.environ.get("GGMS_IPC_TIMEOUT_S", "0"))
+    except ValueError:
+        v = 0.0
+    return v if v > 0 else 120.0
+
+
+def with_deadline(fn, what, seconds=None, on_timeout=None):
+    """Run fn() on a helper thread and wait for it at most `seconds`.  A wait on a peer that never ends --
+    a rank that died before publishing its shard, or a hipIpcOpenMemHandle that does not return (seen on ROCm 7.2
+    for exporter sizes with bit 31 set, include/ggms.h ggms_ipc_safe_bytes) -- must end the run with a message,
+    not hold it until somebody's time limit.  The stuck call cannot be cancelled and there is nothing to retry
+    in-process, so on expiry the process prints `what` and EXITS with code 3 (on_timeout, a test hook, replaces
+    the exit).  Exceptions of fn are re-raised here."""
+    seconds = ipc_timeout_s() if seconds is None else seconds
+    box = {}
+    # the current device is per thread: the helper must work on the caller's (RCCL stages objects on it)
+    dev = torch.cuda.current_device() if torch.cuda.is_available() and torch.cuda.is_initialized() else None
+
+    def run():
+        try:
+            if dev is not None:
+                torch.cuda.set_device(dev)
+            box["value"] = fn()
+        except BaseException as e:  # noqa: BLE001 -- handed to the caller
+            box["error"] = e
+
+    t = threading.Thread(target=run, name="ggms-deadline", daemon=True)
+    t.start()
+    t.join(seconds)
+    if t.is_alive():
+        msg = f"[ggms] gave up after {seconds:.0f} s: {what} (GGMS_IPC_TIMEOUT_S); exiting"
+        if on_timeout is not None:
+            return on_timeout(msg)
+        print(msg, file=sys.stderr, flush=True)
+        os._exit(3)
+    if "error" in box:
+        raise box["error"]
+    return box.get("value")
 
 
 class HipLeaf:
@@ -99,15 +146,27 @@ class FeatureShards:
         if shared_shard.tensor.is_cuda:
             torch.cuda.synchronize(shared_shard.tensor.device)
         mine = shared_shard.export_handle()
+        nbytes = int(np.prod(shared_shard.shape)) * self.shard.element_size()
+        me = f"rank {self.rank} of {self.world} (device {self.shard.device})"
         if self.world == 1:
-            handles = [mine]
+            handles = [(mine, nbytes)]
         else:
             handles = [None] * self.world
-            self.dist.all_gather_object(handles, mine, group=self.group)
-        ptrs = [shared_shard.ptr if r == self.rank else shared_shard.import_peer(handles[r]) for r in range(self.world)]
+            # every wait on a peer is bounded (with_deadline): exit with a message instead of hanging
+            with_deadline(lambda: self.dist.all_gather_object(handles, (mine, nbytes), group=self.group),
+                          f"{me} waiting for the peers' shard handles (all_gather): a rank never published its shard")
+        ptrs = []
+        for r in range(self.world):
+            if r == self.rank:
+                ptrs.append(shared_shard.ptr)
+                continue
+            h, peer_bytes = handles[r]
+            ptrs.append(with_deadline(lambda h=h: shared_shard.import_peer(h),
+                                      f"{me}: hipIpcOpenMemHandle of rank {r}'s shard ({peer_bytes} bytes) did not return"))
         self.parts_table = torch.tensor(ptrs, dtype=torch.int64, device=self.shard.device)
         if self.world > 1:
-            self.dist.barrier(group=self.group)
+            with_deadline(lambda: self.dist.barrier(group=self.group),
+                          f"{me} waiting at the barrier after mapping the peers' shards: a rank is stuck opening one")
         return self
 
     # ---- one batch ----------------------------------------------------------------------------------
@@ -116,8 +175,15 @@ class FeatureShards:
         counters (peer mode): int64[4] on the device, rows served by {host, remote shard, local shard, replica}."""
         if self.mode == "peer":
             if counters is not None or self.replica is not None:
+                # the tiered gather counts rows per tier (added to `counters`); num_miss = this call's host rows,
+                # taken from a scratch counter set
+                tiers = counters if num_miss is None else torch.zeros(4, dtype=torch.int64, device=out.device)
                 self.leaf.gather_tiered(out, nodes, num, self.table, self.replica, self.parts_table, self.world,
-                                        self.rank, self.host_feat, num_dev=num_dev, counters=counters)
+                                        self.rank, self.host_feat, num_dev=num_dev, counters=tiers)
+                if num_miss is not None:
+                    num_miss.copy_(tiers[0:1])
+                    if counters is not None:
+                        counters.add_(tiers)
             else:
                 self.leaf.gather_peer(out, nodes, num, self.table, self.parts_table, self.world, self.host_feat,
                                       **({"num_dev": num_dev, "num_miss": num_miss} if num_dev is not None else {}))
