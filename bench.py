@@ -52,6 +52,10 @@ def parse():
                          "top-K per layer, e.g. 5,5,5.  weighted_khop: alias tables built from synthetic weights")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-tier", action="store_true", help="skip the cache_ratio 0 sub-record (configs[2])")
+    ap.add_argument("--no-engine", action="store_true", help="skip the `engine` sub-record (samgraph.torch surface, child process)")
+    ap.add_argument("--engine-timeout", type=float, default=300.0)
+    ap.add_argument("--no-sampler-roofline", action="store_true",
+                    help="skip the sampler-alone timing and the memory-side rate probe (roofline_sampler)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline: keep sampling mini-batches this long")
     ap.add_argument("--host-steps", type=int, default=5, help="timed steps of the host-tier sub-record")
     ap.add_argument("--host-profile", action="store_true", help="print host enqueue time per section to stderr")
@@ -104,6 +108,11 @@ def measured_traffic(preset):
         return None
     d = json.load(open(files[-1]))
     d["source"] = os.path.relpath(files[-1], ROOT)
+    # the counters describe the gather kernel as it was when they were collected: the profile carries the sha256 of
+    # extract.hip at that time (tools/summarize_profiles.py); a different kernel source voids them
+    import hashlib
+    now = hashlib.sha256(open(os.path.join(ROOT, "xgnn_amd", "csrc", "extract.hip"), "rb").read()).hexdigest()
+    d["stale"] = d.get("extract_hip_sha256") != now
     return d
 
 
@@ -202,6 +211,38 @@ def launch_ranks(args):
         print(f"bench.py: launched {args.gpus} ranks but the line reports n_gpus = {seen}", file=sys.stderr)
         rc = 1
     sys.exit(rc)
+
+
+def engine_record(datagen, graph, fanouts, args, log):
+    """The same workload through the operator surface north_star names (samgraph.torch: config / init / sample_once /
+    get_next_batch) in a CHILD process: the graph is written in the reference's on-disk format without feat.bin /
+    label.bin (the loader then maps zero-filled tables, engine.cc:199-235 -- topology and sizes are the real ones), one
+    warm-up epoch, one reported epoch; rates from the reference's own log items (tools/engine_epoch.py)."""
+    import shutil
+    import subprocess
+    import tempfile
+    d = tempfile.mkdtemp(prefix="ggms_bench_ds_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    try:
+        t0 = time.perf_counter()
+        datagen.write_dataset(d, graph, minimal=True)
+        log(f"engine: dataset written in {time.perf_counter() - t0:.1f} s")
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "engine_epoch.py"), d, "--fanout"]
+                           + [str(f) for f in fanouts]
+                           + ["--batch-size", str(args.batch), "--sample-type", args.sample_type, "--cache-percentage", "1.0"],
+                           capture_output=True, text=True, timeout=args.engine_timeout)
+        lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        if r.returncode != 0 or not lines:
+            return {"error": f"engine child rc {r.returncode}: {r.stderr[-300:]}"}
+        e = json.loads(lines[-1])
+        e["surface"] = ("samgraph.torch config / init / sample_once / get_next_batch (arch1, cache_percentage 1.0) on the "
+                        "same graph written to disk in the reference's format, zero-filled feature table; second epoch; "
+                        "sample_edges_per_s and feature_GBps from kLogEpochNumSample / kLogEpochSampleTime and "
+                        "kLogEpochFeatureBytes / kLogEpochCopyTime")
+        return e
+    except subprocess.TimeoutExpired:
+        return {"error": f"engine child exceeded {args.engine_timeout} s"}
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
 
 
 def shared_graph(datagen, args, world, local_rank, dist):
@@ -498,6 +539,7 @@ def main():
                 ops.check_device_status("bench")
                 raise SystemExit(f"device status {c[3 * L + 1]} after a timed block")
             edges, rows = sum(c[3 * i] for i in range(L)), c[3 * L]
+            inputs = sum(c[3 * i + 2] for i in range(L))  # sampler inputs (seeds of every layer)
             t_sample_ms = sum(e[0].elapsed_time(e[1]) for e in ev)   # on the sampling stream
             t_extract_ms = sum(e[2].elapsed_time(e[3]) for e in ev)  # HIP events on the stream the gather is launched on
             stats = torch.tensor([elapsed, float(edges), float(rows), t_sample_ms, t_extract_ms,
@@ -507,7 +549,7 @@ def main():
                 stats = stats.cpu()
             mx, sm = parallel.reduce_stats(stats, dist if world > 1 else None)
             blocks.append(dict(elapsed=mx[0].item(), edges_all=sm[1].item(), rows_all=sm[2].item(), edges=edges,
-                               rows=rows, t_sample_ms=t_sample_ms, t_extract_ms=t_extract_ms,
+                               rows=rows, inputs=inputs, t_sample_ms=t_sample_ms, t_extract_ms=t_extract_ms,
                                feat_rate_all=sm[5].item(), tiers_all=[sm[6 + i].item() for i in range(4)]))
         return blocks, first_step + total
 
@@ -555,6 +597,48 @@ def main():
         serial_us = e0.elapsed_time(e1) / reps * 1e3
         serial_rows = n_last
 
+    # ---- the sampler chain with nothing beside it, and the memory-side ceilings it runs against ----------------
+    # (rank 0's GPU; N > 1: every rank does the same work, only rank 0 reports)
+    sampler_alone_ms = probe = None
+    if not args.no_sampler_roofline:
+        n_alone = max(4, min(args.steps, 20))
+        seeds_alone = [batch_seeds(next_step + k) for k in range(n_alone + 1)]
+        next_step += n_alone + 1
+        s0 = s_samples[0]
+        barrier()
+        a0, a1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        with torch.cuda.stream(s0):
+            sampler.sample(seeds_alone[0], slot=0, copy_input_nodes=True)  # warm
+            a0.record(s0)
+            for k in range(n_alone):
+                sampler.sample(seeds_alone[1 + k], slot=k % NSLOT, copy_input_nodes=True)
+            a1.record(s0)
+        torch.cuda.synchronize()
+        sampler_alone_ms = a0.elapsed_time(a1) / n_alone
+        # ceilings: random requests on a table the size of the dedup table (one 64-bit word per node id), one launch =
+        # one step's worth of edges.  Returning atomicMin / 4-byte load / both per request (ggms_fabric_probe).
+        import ctypes as C
+        from xgnn_amd import lib as _lib
+        words = N
+        ptab = torch.full((words,), -1, dtype=torch.int64, device=dev)
+        sink = torch.zeros(1, dtype=torch.int32, device=dev)
+        reqs = max(1, int(edges / args.steps))
+        probe = {"table_bytes": words * 8, "requests_per_launch": reqs}
+        salt = 0x7fffff00
+        for kind, name in ((0, "atomic"), (1, "load"), (2, "load_atomic_pair")):
+            p0, p1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            for rep in range(5):
+                if rep == 1:
+                    p0.record()
+                rc = _lib().ggms_fabric_probe(kind, C.c_void_p(ptab.data_ptr()), words, reqs, salt, C.c_void_p(sink.data_ptr()),
+                                              C.c_void_p(torch.cuda.current_stream().cuda_stream))
+                assert rc == 0
+                salt -= 1
+            p1.record()
+            torch.cuda.synchronize()
+            probe[name + "s_per_s"] = reqs / (p0.elapsed_time(p1) / 4 / 1e3)
+        del ptab
+
     # ---- N > 1: the other stores, one block each ------------------------------------------------------------------
     stores = None
     if world > 1:
@@ -576,6 +660,12 @@ def main():
                 stores[kind] = store_record(b2[0], kind)
             except (RuntimeError, MemoryError) as e:
                 stores[kind] = {"error": f"{type(e).__name__}: {str(e)[:200]}"}
+
+    # ---- N = 1: the same workload through the samgraph.torch surface (child process) --------------------------------
+    engine = None
+    if world == 1 and full and not args.no_engine and args.sample_type.startswith("khop"):
+        engine = engine_record(datagen, graph, fanouts, args, log)
+        log("engine sub-record done")
 
     # ---- N = 1: BASELINE configs[2], every row in pinned host DRAM (cache_ratio 0) -----------------------------
     host_tier = None
@@ -622,7 +712,7 @@ def main():
         achieved = algo_bytes_per_launch / avg_launch_s / 1e9
         tr = measured_traffic(args.preset)
         traffic = None
-        if tr is not None:  # PMC bytes per row (profiled run of this command) x rows of this run / this run's launch time
+        if tr is not None and not tr["stale"]:  # PMC bytes per row (profiled run of this command) x rows of this run / this run's launch time
             traffic = tr["hbm_bytes_per_launch"] / tr["rows_per_launch"] * (rows / args.steps) / avg_launch_s / 1e9
         elapsed_all = [b["elapsed"] for b in blocks]
         res = {
@@ -644,6 +734,7 @@ def main():
                         "spread": (max(elapsed_all) - min(elapsed_all)) / statistics.median(elapsed_all)},
             "config": {
                 "workload": f"{args.preset}-shaped power-law CSR N={N} E={meta['num_edge']} f32 dim {dim}, "
+                            f"{'neighbours uniform' if not args.neighbour_skew else f'neighbour skew {args.neighbour_skew} (prob. of a degree-proportional pick)'}, "
                             f"fanout {fanouts} {args.sample_type}, batch {args.batch}, "
                             f"graph in HBM, feature cache_ratio {args.cache_ratio}"
                             f"{' (all rows in HBM, node order)' if full else ' (rest in pinned host DRAM)'}, "
@@ -652,6 +743,10 @@ def main():
                 "parallelism": f"dp{world}",
                 "streams": "1 (serial)" if args.no_overlap else
                            f"{K} sampling pipeline(s) (batches in flight, RNG pool consumed in batch order) + 1 extract stream",
+                "neighbour_skew": args.neighbour_skew,
+                "not_covered": "the reference's example scripts themselves were not run (they import DGL, absent from "
+                               "this image): the line times the operator surface they call; parity is against the "
+                               "oracle, whose four curand_init constants are unverified (no CUDA in the pipeline)",
             },
             "feature_extract_GBps": blk["feat_rate_all"],  # sum over ranks of rows*dim*4 / (time inside the gather kernel)
             "per_gpu": {
@@ -677,11 +772,41 @@ def main():
                 "algorithmic_bytes_per_row": 4 + 2 * row_bytes,
                 "avg_launch_us": avg_launch_s * 1e6,
                 "avg_launch_us_alone": serial_us,
-                "traffic_source": tr["source"] if tr else None,
+                "traffic_source": (tr["source"] + (" (stale: extract.hip changed since; traffic nulled)" if tr["stale"] else
+                                                   f" @ extract.hip sha256 {tr['extract_hip_sha256'][:12]}")) if tr else None,
             },
         }
+        if sampler_alone_ms is not None:
+            E_step, S_step = edges / args.steps, blk["inputs"] / args.steps
+            algo = 12 * S_step + 28 * E_step  # per seed id + indptr pair; per edge neighbour + bucket + COO
+            t = sampler_alone_ms / 1e3
+            # request floor: one (neighbour load, dedup atomic) pair per edge + one indptr sector per seed, at the
+            # rates this device sustains for exactly those requests (measured above, same process, same table size)
+            floor_s = E_step / probe["load_atomic_pairs_per_s"] + S_step / probe["loads_per_s"]
+            res["roofline_sampler"] = {
+                "kernel": f"sampler chain of one batch alone on one stream: k_ht_insert, k_khop3_fused x {L}, "
+                          f"k_owner_scan_chunked x {L + 1}, k_map_rest_all x 2" if args.sample_type == "khop3" else
+                          f"sampler chain of one batch ({args.sample_type}) alone on one stream",
+                "bound": "hbm", "achieved": algo / t / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": algo / t / 8e12,
+                "traffic": None,
+                "algorithmic_bytes_per_step": algo, "alone_ms": sampler_alone_ms,
+                "edges_per_step": E_step, "seeds_per_step": S_step, "edges_per_s_alone": E_step / t,
+                # the chain is bounded by REQUESTS at the memory side, not by bytes: its atomics and
+                # random loads per second against what the device sustains
+                "memory_side": {
+                    "atomics_per_s": E_step / t, "atomics_per_s_ceiling": probe["atomics_per_s"],
+                    "random_loads_per_s": (E_step + S_step) / t, "random_loads_per_s_ceiling": probe["loads_per_s"],
+                    "load_atomic_pairs_per_s_ceiling": probe["load_atomic_pairs_per_s"],
+                    "probe_table_bytes": probe["table_bytes"], "probe_requests_per_launch": probe["requests_per_launch"],
+                    "request_floor_ms": floor_s * 1e3, "chain_over_floor": t / floor_s,
+                },
+            }
         if stores is not None:
             res["stores"] = stores
+        if engine is not None:
+            if "error" not in engine:  # how far the operator surface is from the headline of this run
+                engine["vs_headline_edges_per_s"] = engine["edges_per_s"] / res["value"]
+            res["engine"] = engine
         if host_tier is not None:
             res["host_tier"] = host_tier
         if world == 1 and not args.no_cpu_baseline:

@@ -67,6 +67,16 @@ const char *ggms_last_error(void);
 #define GGMS_STATUS_SCAN_SPIN 1u
 #define GGMS_STATUS_TABLE_FULL 2u
 int ggms_device_status(uint32_t *status_host, int clear);
+/* Rate probe for the bench report (no reference counterpart): num_requests random requests on a caller-owned table
+ * of table_words 64-bit words -- GGMS_PROBE_ATOMIC: one returning 64-bit atomicMin each (what a dedup insert is),
+ * GGMS_PROBE_LOAD: one 4-byte load each (what a neighbour read is), GGMS_PROBE_LOAD_ATOMIC: both (the sampler's
+ * per-edge mix).  The caller times the launch; `salt` (use a decreasing sequence) changes the key set per launch and
+ * keeps every atomic a real update.  sink: 4 device bytes. */
+#define GGMS_PROBE_ATOMIC 0
+#define GGMS_PROBE_LOAD 1
+#define GGMS_PROBE_LOAD_ATOMIC 2
+int ggms_fabric_probe(int kind, void *table, size_t table_words, size_t num_requests, uint32_t salt, void *sink,
+                      ggms_stream_t stream);
 /* Test aid: the next ordered scan of a direct-layout table fill (this process) starts with a poisoned ticket, so
  * that its look-back runs into its bound and sets GGMS_STATUS_SCAN_SPIN.  One shot. */
 void ggms_debug_poison_next_scan(void);

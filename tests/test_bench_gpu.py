@@ -37,6 +37,15 @@ def test_single_gpu_line():
     assert d["host_tier"]["feature_extract_GBps"] > 0 and d["host_tier"]["pinned_h2d_copy_GBps"] > 0
     cb = d["cpu_baseline"]
     assert cb["cores"] >= 1 and cb["value"] > 0 and set(cb["seconds"]) == {"sample", "remap", "extract", "total"}
+    # the sampler's own bound: algorithmic bytes vs 8 TB/s, and its requests against ceilings probed in this process
+    rs = d["roofline_sampler"]
+    assert rs["bound"] == "hbm" and 0 < rs["frac"] < 1 and rs["alone_ms"] > 0
+    ms = rs["memory_side"]
+    assert ms["atomics_per_s_ceiling"] > 1e9 and ms["random_loads_per_s_ceiling"] > 1e9 and ms["chain_over_floor"] > 0.5
+    # the same workload through the samgraph.torch surface, child process
+    en = d["engine"]
+    assert "error" not in en, en
+    assert en["ms_per_step"] > 0 and en["edges_per_s"] > 0 and en["feature_GBps"] > 0 and en["steps"] == 8
 
 
 def test_two_ranks_default_is_the_sharded_store():

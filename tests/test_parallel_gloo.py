@@ -62,13 +62,16 @@ def test_two_rank_seed_partition_and_reduction():
 class _NumpyLeaf:
     """Test stand-in for the HIP leaf operators (checker side: plain numpy on CPU tensors)."""
 
-    def split_by_owner(self, table, nodes, num, num_part):
+    def split_by_owner(self, table, nodes, num, num_part, order):
+        """buckets in the sequence `order` (a permutation of 0..num_part), stable inside a bucket"""
         slots = table[nodes[:num].long()]
         owner = torch.where(slots < 0, torch.full_like(slots, num_part), slots % num_part)
-        order = torch.argsort(owner, stable=True)
+        place = torch.empty(num_part + 1, dtype=torch.int64)
+        place[order] = torch.arange(num_part + 1)
+        by = torch.argsort(place[owner.long()], stable=True)
         counts = torch.bincount(owner, minlength=num_part + 1).to(torch.int64)
-        row = torch.where(slots < 0, nodes[:num], slots // num_part)[order].to(torch.int32)
-        return row, order.to(torch.int32), counts
+        row = torch.where(slots < 0, nodes[:num], slots // num_part)[by].to(torch.int32)
+        return row, by.to(torch.int32), counts
 
     def gather(self, src, index):
         return src[index.long()]

@@ -6,6 +6,6 @@
 for v in "$@"; do
   envp="${v%%|*}"; flags="${v#*|}"
   for rep in 1 2; do
-    env $envp python bench.py --no-cpu-baseline --no-host-tier $flags 2>/dev/null | python tools/brief.py "[$v] rep$rep"
+    env $envp python bench.py --no-cpu-baseline --no-host-tier --no-engine --no-sampler-roofline $flags 2>/dev/null | python tools/brief.py "[$v] rep$rep"
   done
 done

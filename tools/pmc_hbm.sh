@@ -5,7 +5,7 @@ TAG=${1:-hbm}; shift
 OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-CMD="python $GRAFT_REPO_ROOT/bench.py --steps 6 --warmup 2 --repeats 1 --no-cpu-baseline --no-host-tier --no-overlap $@"
+CMD="python $GRAFT_REPO_ROOT/bench.py --steps 6 --warmup 2 --repeats 1 --no-cpu-baseline --no-host-tier --no-engine --no-sampler-roofline --no-overlap $@"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- $CMD > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -- $CMD > /dev/null 2>&1
 python - <<PY

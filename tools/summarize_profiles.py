@@ -20,9 +20,15 @@ import sys
 
 
 def one(pattern):
-    f = glob.glob(pattern)
+    """The file of the BENCH process: the default command also runs the `engine` sub-record in a child process, which
+    rocprofv3 traces into files of its own (another pid).  Only the bench process launches k_fabric_probe
+    (roofline_sampler) and the IdentRows gather; the child is recognised by their absence."""
+    f = sorted(glob.glob(pattern))
     if not f:
         raise SystemExit(f"missing {pattern}")
+    for cand in f:
+        if "k_fabric_probe" in open(cand, errors="replace").read():
+            return cand
     return f[0]
 
 
@@ -120,6 +126,10 @@ def main():
         out["rocprof_avg_us_alone"] = sum(durs[in_pipe:in_pipe + 10]) / 10
         out["bench_avg_launch_us_same_run"] = bench["roofline"]["avg_launch_us"]
         out["bench_avg_launch_us_alone_same_run"] = bench["roofline"]["avg_launch_us_alone"]
+    # what the counters describe: bench.py nulls roofline.traffic when the kernel source has changed since
+    import hashlib
+    src = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "xgnn_amd", "csrc", "extract.hip")
+    out["extract_hip_sha256"] = hashlib.sha256(open(src, "rb").read()).hexdigest()
     with open(f"{dst}_extract_traffic_{preset}.json", "w") as f:
         json.dump(out, f, indent=1)
     print(json.dumps(out, indent=1))

@@ -6,6 +6,7 @@
 // Here: ONE stable scan of the miss flags.  A hit's position in the hit list is
 // i - (number of misses before i), so both lists come out of the same pass, in
 // input order, and both totals stay on the device.
+#include <algorithm>
 #include <cstring>
 
 #include "tile_scan.h"
@@ -56,25 +57,46 @@ __device__ __forceinline__ uint32_t owner_of(uint32_t slot, uint32_t num_part) {
   return slot == kEmptyKey ? num_part : slot % num_part;
 }
 
+// Counters shared by the whole grid are touched ONCE per workgroup and bucket: atomics on one address are served one
+// at a time at the memory side (12 ns each, tools/micro_ticket.hip) -- one per wave and bucket was 400 K of them per
+// papers100M batch on nine neighbouring words.  Waves count into LDS; a workgroup owns a contiguous piece of the
+// batch (kOwnerGrid pieces), so that the bucket kernel can claim its slice of every bucket with one returning atomic
+// and then place its rows with LDS cursors only.
+constexpr int kOwnerGrid = 256;
+constexpr uint32_t kOwnerBuckets = 65; // num_part <= 64, + the host tier
+
+__device__ __forceinline__ void owner_piece(uint64_t n, uint64_t &lo, uint64_t &hi) { // this workgroup's items
+  const uint64_t per = ((n + gridDim.x - 1) / gridDim.x + kBlock - 1) / kBlock * kBlock; // whole block rounds
+  lo = (uint64_t)blockIdx.x * per;
+  hi = lo + per < n ? lo + per : n;
+}
+
 __global__ __launch_bounds__(kBlock) void k_owner_histogram(const uint32_t *__restrict__ table,
                                                             const uint32_t *__restrict__ nodes, Count n_arg,
                                                             uint32_t num_part, uint32_t *__restrict__ slots_out,
                                                             unsigned long long *counts) {
+  __shared__ unsigned int s_cnt[kOwnerBuckets];
   const uint64_t n = n_arg.get();
-  const uint64_t rounded = (n + kWave - 1) / kWave * kWave; // whole waves stay together for the ballots
-  for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < rounded; i += (uint64_t)gridDim.x * kBlock) {
-    const bool valid = i < n;
+  for (uint32_t p = threadIdx.x; p <= num_part; p += kBlock) s_cnt[p] = 0u;
+  __syncthreads();
+  uint64_t lo, hi;
+  owner_piece(n, lo, hi);
+  for (uint64_t i0 = lo; i0 < hi; i0 += kBlock) { // whole waves stay together for the ballots
+    const uint64_t i = i0 + threadIdx.x;
     uint32_t owner = 0xffffffffu;
-    if (valid) {
+    if (i < hi) {
       const uint32_t slot = table ? table[nodes[i]] : nodes[i]; // no table: every node cached at slot = node id
       slots_out[i] = slot;
       owner = owner_of(slot, num_part);
     }
-    for (uint32_t p = 0; p <= num_part; ++p) { // one atomic per (wave, bucket)
+    for (uint32_t p = 0; p <= num_part; ++p) {
       const uint64_t m = __ballot(owner == p);
-      if (m && lane_id() == (uint32_t)__builtin_ctzll(m)) atomicAdd(&counts[p], (unsigned long long)__popcll(m));
+      if (m && lane_id() == (uint32_t)__builtin_ctzll(m)) atomicAdd(&s_cnt[p], (unsigned int)__popcll(m));
     }
   }
+  __syncthreads();
+  for (uint32_t p = threadIdx.x; p <= num_part; p += kBlock)
+    if (s_cnt[p]) atomicAdd(&counts[p], (unsigned long long)s_cnt[p]);
 }
 
 __global__ __launch_bounds__(kBlock) void k_owner_bucket(const uint32_t *__restrict__ slots,
@@ -82,12 +104,33 @@ __global__ __launch_bounds__(kBlock) void k_owner_bucket(const uint32_t *__restr
                                                          uint32_t num_part, unsigned long long *cursor,
                                                          uint32_t *__restrict__ bucket_row,
                                                          uint32_t *__restrict__ bucket_pos) {
+  __shared__ unsigned int s_cnt[kOwnerBuckets];
+  __shared__ unsigned long long s_base[kOwnerBuckets];
   const uint64_t n = n_arg.get();
-  const uint64_t rounded = (n + kWave - 1) / kWave * kWave;
-  for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < rounded; i += (uint64_t)gridDim.x * kBlock) {
-    const bool valid = i < n;
+  for (uint32_t p = threadIdx.x; p <= num_part; p += kBlock) s_cnt[p] = 0u;
+  __syncthreads();
+  uint64_t lo, hi;
+  owner_piece(n, lo, hi);
+  // pass 1: this piece's rows per bucket
+  for (uint64_t i0 = lo; i0 < hi; i0 += kBlock) {
+    const uint64_t i = i0 + threadIdx.x;
+    const uint32_t owner = i < hi ? owner_of(slots[i], num_part) : 0xffffffffu;
+    for (uint32_t p = 0; p <= num_part; ++p) {
+      const uint64_t m = __ballot(owner == p);
+      if (m && lane_id() == (uint32_t)__builtin_ctzll(m)) atomicAdd(&s_cnt[p], (unsigned int)__popcll(m));
+    }
+  }
+  __syncthreads();
+  // claim a slice of every bucket (one returning atomic per bucket), then hand it out from LDS
+  for (uint32_t p = threadIdx.x; p <= num_part; p += kBlock) {
+    s_base[p] = s_cnt[p] ? atomicAdd(&cursor[p], (unsigned long long)s_cnt[p]) : 0ull;
+    s_cnt[p] = 0u;
+  }
+  __syncthreads();
+  for (uint64_t i0 = lo; i0 < hi; i0 += kBlock) {
+    const uint64_t i = i0 + threadIdx.x;
     uint32_t owner = 0xffffffffu, slot = 0;
-    if (valid) {
+    if (i < hi) {
       slot = slots[i];
       owner = owner_of(slot, num_part);
     }
@@ -95,11 +138,11 @@ __global__ __launch_bounds__(kBlock) void k_owner_bucket(const uint32_t *__restr
       const uint64_t m = __ballot(owner == p);
       if (!m) continue;
       const uint32_t leader = (uint32_t)__builtin_ctzll(m);
-      unsigned long long base = 0;
-      if (lane_id() == leader) base = atomicAdd(&cursor[p], (unsigned long long)__popcll(m));
-      base = __shfl(base, (int)leader, 64);
+      unsigned int off = 0;
+      if (lane_id() == leader) off = atomicAdd(&s_cnt[p], (unsigned int)__popcll(m));
+      off = __shfl(off, (int)leader, 64);
       if (owner == p) {
-        const uint64_t at = base + __popcll(m & ((1ull << lane_id()) - 1ull));
+        const uint64_t at = s_base[p] + off + __popcll(m & ((1ull << lane_id()) - 1ull));
         bucket_row[at] = (p == num_part) ? nodes[i] : slot / num_part;
         bucket_pos[at] = (uint32_t)i;
       }
@@ -152,7 +195,7 @@ int ggms_owner_histogram(const ggms_id_t *table, const ggms_id_t *nodes, size_t 
   GGMS_CHECK_ARG(num_part >= 1 && num_part <= 64 && counts_dev);
   if (num_nodes == 0) return GGMS_OK;
   GGMS_CHECK_ARG(nodes && slots_out && num_nodes < (1ull << 32)); // table == NULL: identity slots (full cache)
-  hipLaunchKernelGGL(k_owner_histogram, dim3(grid_for(num_nodes, kBlock)), dim3(kBlock), 0, to_stream(stream), table,
+  hipLaunchKernelGGL(k_owner_histogram, dim3(std::min(grid_for(num_nodes, kBlock), kOwnerGrid)), dim3(kBlock), 0, to_stream(stream), table,
                      nodes, count_of(num_nodes, num_nodes_dev), num_part, slots_out, (unsigned long long *)counts_dev);
   GGMS_LAUNCH_CHECK();
   return GGMS_OK;
@@ -164,7 +207,7 @@ int ggms_owner_bucket(const ggms_id_t *slots, const ggms_id_t *nodes, size_t num
   GGMS_CHECK_ARG(num_part >= 1 && num_part <= 64 && cursor_dev);
   if (num_nodes == 0) return GGMS_OK;
   GGMS_CHECK_ARG(slots && nodes && bucket_row && bucket_pos && num_nodes < (1ull << 32));
-  hipLaunchKernelGGL(k_owner_bucket, dim3(grid_for(num_nodes, kBlock)), dim3(kBlock), 0, to_stream(stream), slots, nodes,
+  hipLaunchKernelGGL(k_owner_bucket, dim3(std::min(grid_for(num_nodes, kBlock), kOwnerGrid)), dim3(kBlock), 0, to_stream(stream), slots, nodes,
                      count_of(num_nodes, num_nodes_dev), num_part, (unsigned long long *)cursor_dev, bucket_row,
                      bucket_pos);
   GGMS_LAUNCH_CHECK();

@@ -188,6 +188,12 @@ __global__ __launch_bounds__(kBlock) void k_gather_rows(char *__restrict__ out, 
 
   uint64_t sp, dp;
   uint32_t miss; // tier of my row (kTierHost = a cache miss)
+  // rows per tier: counted per wave in registers, combined per workgroup in LDS and added to the caller's counters
+  // ONCE per workgroup at the end.  (An atomic per wave and tile -- 46 K tiles x 3 tiers on one line -- is served one
+  // at a time at the memory side, 12 ns each: 1.6 ms of counter updates behind a 0.5-ms gather, tools/micro_ticket.hip.)
+  uint32_t tier_acc[kTierReplica + 1] = {};
+  __shared__ unsigned int s_tier[kTierReplica + 1];
+  if (miss_count && threadIdx.x <= kTierReplica) s_tier[threadIdx.x] = 0u;
   resolve(wave, sp, dp, miss);
   for (uint64_t tile = wave; tile < num_tiles; tile += num_waves) {
     // software pipeline: the next tile's index -> table -> pointer chain is in flight while this
@@ -196,15 +202,11 @@ __global__ __launch_bounds__(kBlock) void k_gather_rows(char *__restrict__ out, 
     uint32_t miss_n;
     resolve(tile + num_waves, sp_n, dp_n, miss_n);
 
-    if (miss_count) { // one atomic per wave, tile and tier that occurs
-      const uint64_t m = __ballot(miss == kTierHost);
-      if (lane == 0 && m) atomicAdd((unsigned long long *)miss_count, (unsigned long long)__popcll(m));
+    if (miss_count) {
+      tier_acc[0] += (uint32_t)__popcll(__ballot(miss == kTierHost));
       if constexpr (Rows::kTiers) {
 #pragma unroll
-        for (uint32_t k = kTierRemote; k <= kTierReplica; ++k) {
-          const uint64_t mk = __ballot(miss == k);
-          if (lane == 0 && mk) atomicAdd((unsigned long long *)miss_count + (k - 1), (unsigned long long)__popcll(mk));
-        }
+        for (uint32_t k = kTierRemote; k <= kTierReplica; ++k) tier_acc[k - 1] += (uint32_t)__popcll(__ballot(miss == k));
       }
     }
     const uint64_t row0 = tile * kWave;
@@ -238,6 +240,17 @@ __global__ __launch_bounds__(kBlock) void k_gather_rows(char *__restrict__ out, 
       }
     }
     sp = sp_n; dp = dp_n; miss = miss_n;
+  }
+  if (miss_count) { // uniform: every wave of the workgroup gets here
+    __syncthreads(); // s_tier is zeroed
+    if (lane == 0) {
+#pragma unroll
+      for (uint32_t k = 0; k < (Rows::kTiers ? kTierReplica : 1u); ++k)
+        if (tier_acc[k]) atomicAdd(&s_tier[k], tier_acc[k]);
+    }
+    __syncthreads();
+    if (threadIdx.x < (Rows::kTiers ? kTierReplica : 1u) && s_tier[threadIdx.x])
+      atomicAdd((unsigned long long *)miss_count + threadIdx.x, (unsigned long long)s_tier[threadIdx.x]);
   }
 }
 

@@ -136,10 +136,10 @@ struct Xorwow {
     return v4 + d;
   }
   // curand_uniform: x * 2^-32 + 2^-33 in f32
-  __device__ __forceinline__ float uniform() {
-    const uint32_t x = next();
+  __device__ static __forceinline__ float to_uniform(uint32_t x) {
     return __fmaf_rn(__uint2float_rn(x), 2.3283064e-10f, 2.3283064e-10f / 2.0f);
   }
+  __device__ __forceinline__ float uniform() { return to_uniform(next()); }
   // curand_uniform_double (XORWOW): two draws, 53-bit mantissa
   __device__ __forceinline__ double uniform_double() {
     const uint32_t x = next();

@@ -54,11 +54,14 @@ int sample_weighted_hash_dedup_impl(const uint32_t *indptr, const uint32_t *indi
 
 // hashtable.hip
 size_t ht_ws_words(size_t num_input);
+size_t chunk_desc_words(); // 32-bit descriptors of the chunked owner scan: their own piece of a scan area
 // What the first kernel of a batch (the insert of the seeds) does on the side: clear the shared scan area's
 // control words + single-pass descriptors, reset the table's item count, record |seeds|.
 struct BatchPrologue {
   uint32_t *zero_words;
   uint32_t num_zero;
+  uint32_t *zero_words2; // second range (the chunked owner scan's descriptors)
+  uint32_t num_zero2;
   uint32_t *num_items;
   uint64_t *record_n;
 };

@@ -112,6 +112,7 @@ __global__ __launch_bounds__(kBlock) void k_ht_insert(Table t, const uint32_t *_
   const uint64_t n = n_arg.get();
   if (blockIdx.x == 0) {
     for (uint32_t z = threadIdx.x; z < pro.num_zero; z += kBlock) pro.zero_words[z] = 0u;
+    for (uint32_t z = threadIdx.x; z < pro.num_zero2; z += kBlock) pro.zero_words2[z] = 0u;
     if (threadIdx.x == 0) {
       if (pro.num_items) *pro.num_items = 0u;
       if (pro.record_n) *pro.record_n = n;
@@ -357,6 +358,271 @@ __global__ __launch_bounds__(kBlock) void k_owner_scan(unsigned long long *__res
   }
 }
 
+// ---- direct layout, the ordered scan proper: chunked, request-efficient ----------------------------------------
+// Two things k_owner_scan above pays for, both at the memory side where this path is bounded (tools/micro_atomics2.hip):
+//   * a thread's 8 consecutive items are 32 / 64 bytes apart from its neighbour's, so every 16-byte load instruction
+//     of a wave touches 32-64 different lines and each line is requested by 2-4 different instructions: three times
+//     the line requests the bytes need.  Here a wave's load instruction covers ONE contiguous span: in round q of a
+//     tile, thread t holds items 512 q + 2 t and 512 q + 2 t + 1 (8-byte loads of cand / items, a 16-byte load of lost);
+//   * one ticket per tile from ONE counter: same-address atomics are served one at a time, 11 ns each
+//     (tools/micro_ticket.hip) -- 1220 tickets, as many failing ones and exit counts are most of the old kernel's 42 us;
+//     and tiles chained by decoupled look-back walk t / 64 windows of descriptors, one dependent round trip each, when
+//     every workgroup starts at once.  Here workgroup c owns CHUNK c of `per` consecutive tiles (no ticket), publishes
+//     the chunk's owner count (<= 16 bits: a 32-bit descriptor {epoch : 16 | count : 16}) and fetches the counts of ALL
+//     chunks before it with loads that are in flight together.  Chunk 0's descriptor is 64-bit and carries the
+//     table's item count in.
+// Ranks come from ballots: a (tile, round, wave) segment is 128 consecutive items, its owners are counted with two
+// ballots, the segment totals of the whole chunk meet in LDS after ONE barrier.  Owners park their keys in LDS at
+// their rank and the chunk's slice of n2o is written in one coalesced sweep.  Chunks of up to kChunkRegTiles tiles
+// stay in registers between the count and the write-out; longer ones (input near its worst-case bound) re-read.
+constexpr uint32_t kChunkGrid = 1024, kChunkRegTiles = 2;
+constexpr uint32_t kChunkMaxTiles = 65535u / kOwnTile; // 31: a chunk's count must fit the descriptor's 16 bits
+constexpr uint32_t kOwnRounds = kOwnTile / (2 * kBlock); // 4 rounds of 512 items
+constexpr uint32_t kOwnSegs = kOwnRounds * (kBlock / kWave); // 16 segments of 128 items per tile
+
+struct OwnTile { // one thread's items of a tile: entry 2 q + j = item 512 q + 2 t + j
+  uint32_t key[kOwnItems], cnd[kOwnItems], flags; // flags: bit (2 q + j) = that item owns its key
+};
+
+__device__ __forceinline__ void own_tile_load(OwnTile &t, const uint32_t *__restrict__ items,
+                                              const uint32_t *__restrict__ cand,
+                                              const unsigned long long *__restrict__ lost, unsigned long long tag,
+                                              uint64_t tile0, uint64_t n, bool vec_ok, bool need_keys) {
+  t.flags = 0;
+#pragma unroll
+  for (uint32_t q = 0; q < kOwnRounds; ++q) {
+    const uint64_t i = tile0 + 2ull * kBlock * q + 2ull * threadIdx.x;
+    uint32_t c0 = 0, c1 = 0, k0 = 0, k1 = 0;
+    unsigned long long l0 = tag, l1 = tag;
+    if (vec_ok && i + 2 <= n) {
+      const uint2 c = *reinterpret_cast<const uint2 *>(cand + i);
+      const ulonglong2 l = *reinterpret_cast<const ulonglong2 *>(lost + i);
+      if (need_keys) {
+        const uint2 k = *reinterpret_cast<const uint2 *>(items + i);
+        k0 = k.x; k1 = k.y;
+      }
+      c0 = c.x; c1 = c.y; l0 = l.x; l1 = l.y;
+    } else {
+      if (i < n) { c0 = cand[i]; l0 = lost[i]; if (need_keys) k0 = items[i]; }
+      if (i + 1 < n) { c1 = cand[i + 1]; l1 = lost[i + 1]; if (need_keys) k1 = items[i + 1]; }
+    }
+    t.key[2 * q] = k0; t.key[2 * q + 1] = k1;
+    t.cnd[2 * q] = c0; t.cnd[2 * q + 1] = c1;
+    t.flags |= ((c0 == 1u && l0 != tag) ? 1u : 0u) << (2 * q);
+    t.flags |= ((c1 == 1u && l1 != tag) ? 1u : 0u) << (2 * q + 1);
+  }
+}
+
+// rank of this thread's first item of every round INSIDE its segment + the segment totals into seg[] (one word per
+// (round, wave), round-major): two ballots per round.  rank[q] is returned packed, 8 bits each (<= 128).
+__device__ __forceinline__ uint32_t own_tile_rank(const OwnTile &t, uint32_t *seg) {
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  const uint64_t lt = (1ull << lane) - 1ull;
+  uint32_t packed = 0;
+#pragma unroll
+  for (uint32_t q = 0; q < kOwnRounds; ++q) {
+    const uint64_t m0 = __ballot((t.flags >> (2 * q)) & 1u), m1 = __ballot((t.flags >> (2 * q + 1)) & 1u);
+    packed |= (uint32_t)(__popcll(m0 & lt) + __popcll(m1 & lt)) << (8 * q);
+    if (lane == 0) seg[q * (kBlock / kWave) + wave] = (uint32_t)(__popcll(m0) + __popcll(m1));
+  }
+  return packed;
+}
+
+// owners park their keys in LDS at their rank inside the chunk, everybody writes its local ids (8-byte stores, a
+// wave's store instruction covers one contiguous span)
+template <bool BATCH>
+__device__ __forceinline__ void own_tile_emit(const OwnTile &t, uint32_t prefix, uint32_t ranks_packed,
+                                              const uint32_t *seg_excl /* exclusive prefix of the tile's segments */,
+                                              uint32_t *s_keys, unsigned long long *__restrict__ w, uint32_t version,
+                                              uint32_t *__restrict__ mapped, uint64_t tile0, uint64_t n, bool vec_ok) {
+  const uint32_t wave = threadIdx.x >> 6;
+#pragma unroll
+  for (uint32_t q = 0; q < kOwnRounds; ++q) {
+    uint32_t rank = seg_excl[q * (kBlock / kWave) + wave] + ((ranks_packed >> (8 * q)) & 0xffu); // inside the chunk
+    uint32_t out[2];
+#pragma unroll
+    for (uint32_t j = 0; j < 2; ++j) {
+      const uint32_t e = 2 * q + j;
+      out[j] = (BATCH && t.cnd[e] >= 2u) ? t.cnd[e] - 2u : kEmptyKey;
+      if (t.flags & (1u << e)) {
+        if (!BATCH) w[t.key[e]] = make_w1(version, 0u, prefix + rank);
+        s_keys[rank] = t.key[e];
+        out[j] = prefix + rank;
+        ++rank;
+      }
+    }
+    if (mapped) {
+      const uint64_t i = tile0 + 2ull * kBlock * q + 2ull * threadIdx.x;
+      if (vec_ok && i + 2 <= n) {
+        *reinterpret_cast<uint2 *>(mapped + i) = make_uint2(out[0], out[1]);
+      } else {
+        if (i < n) mapped[i] = out[0];
+        if (i + 1 < n) mapped[i + 1] = out[1];
+      }
+    }
+  }
+}
+
+template <bool BATCH>
+__global__ __launch_bounds__(kBlock) void k_owner_scan_chunked(unsigned long long *__restrict__ w, uint32_t version,
+                                                               uint32_t *__restrict__ n2o,
+                                                               const uint32_t *__restrict__ items,
+                                                               const uint32_t *__restrict__ cand,
+                                                               const unsigned long long *__restrict__ lost,
+                                                               unsigned long long tag, uint32_t *__restrict__ mapped,
+                                                               Count n_arg, unsigned long long *desc0,
+                                                               uint32_t *chunk_desc, uint32_t epoch, uint32_t epoch16,
+                                                               uint32_t *num_items, uint64_t *mirror_a,
+                                                               uint64_t *mirror_b, uint32_t *err, uint32_t skip_below) {
+  constexpr uint32_t FLAG_P = 2;
+  __shared__ uint32_t smem[kBlock / kWave];
+  __shared__ uint32_t s_total;
+  __shared__ uint32_t s_seg[kChunkRegTiles * kOwnSegs];  // owners per (tile, round, wave) segment, then their prefix
+  __shared__ uint32_t s_keys[kChunkRegTiles * kOwnTile]; // the owners' keys of a chunk (or of one tile), in rank order
+  const uint64_t n = n_arg.get();
+  const uint64_t tiles = (n + kOwnTile - 1) / kOwnTile;
+  const uint32_t per = (uint32_t)((tiles + gridDim.x - 1) / gridDim.x);          // tiles per chunk
+  const uint32_t chunks = per ? (uint32_t)((tiles + per - 1) / per) : 0u;        // chunks that hold items
+  // 8-byte accesses of cand / items / mapped, 16-byte accesses of lost (workspace pieces are 16-byte aligned; a
+  // caller's sliced tensor may not be)
+  const bool vec_ok = (((((uintptr_t)items) | ((uintptr_t)cand) | ((uintptr_t)mapped)) & 7u) | (((uintptr_t)lost) & 15u)) == 0;
+  // chunk = workgroup id, no ticket: 1024 tickets from one counter are 11 us of same-address atomics
+  // (tools/micro_ticket.hip), and a chunk only ever waits for LOWER chunks, which publish before they wait for anybody
+  // -- with workgroups dispatched in id order a waiting chunk's predecessors are running or done.  Should a
+  // predecessor ever not show up, the bounded wait below turns that into the status word, not into a hang.
+  const uint32_t c = blockIdx.x;
+  if (c < chunks && c >= skip_below) { // skip_below: 0; ggms_debug_poison_next_scan drops chunk 0 (tests of the bound)
+    const uint64_t t0 = (uint64_t)c * per;
+    const uint32_t my_tiles = (uint32_t)min((uint64_t)per, tiles - t0);
+    const bool in_regs = per <= kChunkRegTiles; // uniform over the grid
+    OwnTile tl[kChunkRegTiles];
+    uint32_t ranks[kChunkRegTiles];
+    uint32_t running = 0;
+    if (in_regs) {
+#pragma unroll
+      for (uint32_t k = 0; k < kChunkRegTiles; ++k) {
+        tl[k].flags = 0;
+        if (k < my_tiles) own_tile_load(tl[k], items, cand, lost, tag, (t0 + k) * kOwnTile, n, vec_ok, true);
+      }
+#pragma unroll
+      for (uint32_t k = 0; k < kChunkRegTiles; ++k) ranks[k] = own_tile_rank(tl[k], s_seg + k * kOwnSegs);
+      __syncthreads();
+      // exclusive prefix over the chunk's segments (tile-major, round, wave = item order), by wave 0
+      if (threadIdx.x < kWave) {
+        const uint32_t v = threadIdx.x < kChunkRegTiles * kOwnSegs ? s_seg[threadIdx.x] : 0u;
+        const uint32_t incl = wave_inclusive_scan(v);
+        if (threadIdx.x < kChunkRegTiles * kOwnSegs) s_seg[threadIdx.x] = incl - v;
+        if (threadIdx.x == 63) s_total = incl;
+      }
+      __syncthreads();
+      running = s_total;
+    } else { // count pass; the tiles are read again for the write-out
+      uint32_t mine = 0;
+      for (uint32_t k = 0; k < my_tiles; ++k) {
+        OwnTile t;
+        own_tile_load(t, items, cand, lost, tag, (t0 + k) * kOwnTile, n, vec_ok, false);
+        mine += __popc(t.flags);
+      }
+      (void)block_exclusive_scan(mine, smem, running);
+    }
+    // publish this chunk's count; chunk 0 carries the table's item count in
+    uint32_t prefix = 0;
+    if (c == 0) {
+      prefix = *num_items; // nobody writes it before chunk 0's descriptor is out (the total needs that descriptor)
+      if (threadIdx.x == 0)
+        __hip_atomic_store(desc0, scan_desc(epoch, FLAG_P, prefix + running), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      if (threadIdx.x == 0)
+        __hip_atomic_store(&chunk_desc[c], (epoch16 << 16) | running, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      // every earlier chunk's count: first all loads in flight together, then wait for the stragglers (bounded)
+      constexpr uint32_t kLook = kChunkGrid / kBlock;
+      uint32_t got[kLook];
+      bool ready[kLook];
+#pragma unroll
+      for (uint32_t r = 0; r < kLook; ++r) {
+        const uint32_t j = threadIdx.x + r * kBlock;
+        got[r] = 0;
+        ready[r] = j == 0 || j >= c;
+        if (j != 0 && j < c) {
+          const uint32_t d = __hip_atomic_load(&chunk_desc[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          ready[r] = (d >> 16) == epoch16;
+          got[r] = d & 0xffffu;
+        }
+      }
+      uint32_t sum = 0;
+#pragma unroll
+      for (uint32_t r = 0; r < kLook; ++r) {
+        const uint32_t j = threadIdx.x + r * kBlock;
+        for (uint32_t spins = 0; !ready[r]; ++spins) {
+          if (spins > (1u << 22)) { // a protocol error must not hang the GPU
+            if (err) atomicOr(err, kErrScanSpin);
+            got[r] = 0;
+            break;
+          }
+          __builtin_amdgcn_s_sleep(1);
+          const uint32_t d = __hip_atomic_load(&chunk_desc[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          ready[r] = (d >> 16) == epoch16;
+          got[r] = d & 0xffffu;
+        }
+        sum += got[r];
+      }
+      if (threadIdx.x == 0) { // chunk 0: absolute count (the base included), 64-bit descriptor
+        for (uint32_t spins = 0;; ++spins) {
+          const unsigned long long d = __hip_atomic_load(desc0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if ((uint32_t)(d >> 34) == epoch && ((uint32_t)(d >> 32) & 3u) == FLAG_P) { sum += (uint32_t)d; break; }
+          if (spins > (1u << 22)) {
+            if (err) atomicOr(err, kErrScanSpin);
+            break;
+          }
+          __builtin_amdgcn_s_sleep(1);
+        }
+      }
+      (void)block_exclusive_scan(sum, smem, prefix);
+    }
+    if (c + 1 == chunks && threadIdx.x == 0) { // the last chunk knows the total
+      const uint32_t total = prefix + running;
+      *num_items = total;
+      if (mirror_a) *mirror_a = (uint64_t)total;
+      if (mirror_b) *mirror_b = (uint64_t)total;
+    }
+    if (in_regs) {
+#pragma unroll
+      for (uint32_t k = 0; k < kChunkRegTiles; ++k)
+        if (k < my_tiles)
+          own_tile_emit<BATCH>(tl[k], prefix, ranks[k], s_seg + k * kOwnSegs, s_keys, w, version, mapped,
+                               (t0 + k) * kOwnTile, n, vec_ok);
+      __syncthreads();
+      for (uint32_t i = threadIdx.x; i < running; i += kBlock) n2o[prefix + i] = s_keys[i]; // the chunk's slice of n2o
+    } else {
+      uint32_t run2 = prefix;
+      for (uint32_t k = 0; k < my_tiles; ++k) {
+        OwnTile t;
+        own_tile_load(t, items, cand, lost, tag, (t0 + k) * kOwnTile, n, vec_ok, true);
+        const uint32_t rk = own_tile_rank(t, s_seg);
+        __syncthreads();
+        if (threadIdx.x < kWave) {
+          const uint32_t v = threadIdx.x < kOwnSegs ? s_seg[threadIdx.x] : 0u;
+          const uint32_t incl = wave_inclusive_scan(v);
+          if (threadIdx.x < kOwnSegs) s_seg[threadIdx.x] = incl - v;
+          if (threadIdx.x == 63) s_total = incl;
+        }
+        __syncthreads();
+        const uint32_t total = s_total;
+        own_tile_emit<BATCH>(t, run2, rk, s_seg, s_keys, w, version, mapped, (t0 + k) * kOwnTile, n, vec_ok);
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < total; i += kBlock) n2o[run2 + i] = s_keys[i];
+        __syncthreads(); // s_seg / s_keys / s_total are rewritten by the next tile
+        run2 += total;
+      }
+    }
+  }
+  if (threadIdx.x == 0 && tiles == 0 && c == 0) { // empty input: the count stays what it is
+    const uint32_t base = *num_items;
+    if (mirror_a) *mirror_a = (uint64_t)base;
+    if (mirror_b) *mirror_b = (uint64_t)base;
+  }
+}
+
 static std::atomic<bool> g_poison_next_scan{false};
 
 static size_t owner_scan_grid_cap() { // GGMS_OSCAN_GRID: measurement hook
@@ -368,7 +634,8 @@ static size_t owner_scan_grid_cap() { // GGMS_OSCAN_GRID: measurement hook
 size_t owner_scan_tiles(size_t n_max) { return (n_max + kOwnTile - 1) / kOwnTile; }
 
 // workspace of one fill: cand / item_pos [n], lost [n] (64-bit), scan area
-size_t ht_ws_words(size_t num_input) { return 3 * num_input + tile_scan_words(num_input) + 24; }
+size_t ht_ws_words(size_t num_input) { return 3 * num_input + tile_scan_words(num_input) + 24 + chunk_desc_words(); }
+size_t chunk_desc_words() { return kChunkGrid + 8; }
 
 __global__ void k_status_copy(uint32_t *status, uint64_t *status_out) {
   if (threadIdx.x == 0 && blockIdx.x == 0) *status_out = status ? atomicExch(status, 0u) : 0u;
@@ -398,10 +665,11 @@ int launch_map_rest_all(const ggms_hashtable_t *ht, const MapRestJobs &jobs, uin
 int ht_fill_impl(const ggms_hashtable_t *ht, const uint32_t *input, size_t n_max, Count n, DedupInsert di,
                  bool inserted, ScanArea scratch, uint64_t *mirror_a, uint64_t *mirror_b, hipStream_t s,
                  uint32_t *mapped, const BatchPrologue *prologue, int rest, const uint64_t *n_dev_for_rest) {
-  BatchPrologue pro{nullptr, 0, nullptr, nullptr};
+  BatchPrologue pro{nullptr, 0, nullptr, 0, nullptr, nullptr};
   if (prologue) pro = *prologue;
   if (n_max == 0) { // no kernel to ride on
     if (pro.num_zero) GGMS_HIP(hipMemsetAsync(pro.zero_words, 0, pro.num_zero * sizeof(uint32_t), s));
+    if (pro.num_zero2) GGMS_HIP(hipMemsetAsync(pro.zero_words2, 0, pro.num_zero2 * sizeof(uint32_t), s));
     if (pro.num_items) GGMS_HIP(hipMemsetAsync(pro.num_items, 0, sizeof(uint32_t), s));
     if (pro.record_n) GGMS_HIP(hipMemsetAsync(pro.record_n, 0, sizeof(uint64_t), s));
     return GGMS_OK;
@@ -431,20 +699,50 @@ int ht_fill_impl(const ggms_hashtable_t *ht, const uint32_t *input, size_t n_max
   unsigned long long *desc = reinterpret_cast<unsigned long long *>(ctl + 8);
   if (!scratch.cleared) {
     GGMS_HIP(hipMemsetAsync(ctl, 0, (8 + 2 * (owner_scan_tiles(n_max) + 1)) * sizeof(uint32_t), s));
-    // ggms_debug_poison_next_scan (tests): start the ticket at 1, so tile 0 is never processed and every later
-    // tile's look-back runs into its bound -- the failure the status word exists for
-    if (g_poison_next_scan.exchange(false)) GGMS_HIP(hipMemsetD32Async((hipDeviceptr_t)ctl, 1, 1, s));
   }
-  // Fewer workgroups than tiles on purpose: a workgroup takes tiles from the ticket one after the other, so by the
-  // time tile t is taken the tiles before t - grid have finished and the look-back finds a published prefix in
-  // its first window; with one workgroup per tile every tile starts at once and tile t walks t / 64 windows.
-  const int oscan_grid = (int)std::min<size_t>(grid_for(owner_scan_tiles(n_max), 1), owner_scan_grid_cap());
-  if (di.batch)
-    hipLaunchKernelGGL(k_owner_scan<true>, dim3(oscan_grid), dim3(kBlock), 0, s, di.w, di.version, ht->n2o, input, di.cand,
-                       di.lost, di.tag, mapped, n, ctl, desc, next_scan_epoch(), ht->num_items_dev, mirror_a, mirror_b, err);
-  else
-    hipLaunchKernelGGL(k_owner_scan<false>, dim3(oscan_grid), dim3(kBlock), 0, s, di.w, di.version, ht->n2o, input, di.cand,
-                       di.lost, di.tag, mapped, n, ctl, desc, next_scan_epoch(), ht->num_items_dev, mirror_a, mirror_b, err);
+  // ggms_debug_poison_next_scan (tests): tile / chunk 0 is never processed, so every later one waits for it until its
+  // bound -- the failure the status word exists for
+  const bool poisoned = !scratch.cleared && g_poison_next_scan.exchange(false);
+  if (poisoned) GGMS_HIP(hipMemsetD32Async((hipDeviceptr_t)ctl, 1, 1, s));
+  // chunked form (one ticket, one look-back per workgroup) wherever the caller's scan area has room for its
+  // descriptors; GGMS_OSCAN=tiles keeps the tile-chained kernel (measurement hook)
+  static const bool force_tiles = [] { const char *e = getenv("GGMS_OSCAN"); return e && e[0] == 't'; }();
+  // GGMS_OSCAN_CHUNK_GRID: fewer chunks than kChunkGrid (tests: chunks too long for registers take the two-pass form)
+  static const size_t chunk_grid = [] {
+    const char *e = getenv("GGMS_OSCAN_CHUNK_GRID");
+    const long v = e ? atol(e) : 0;
+    return v > 0 && v < (long)kChunkGrid ? (size_t)v : (size_t)kChunkGrid;
+  }();
+  const int cgrid = (int)std::min<size_t>(std::max<size_t>(owner_scan_tiles(n_max), 1), chunk_grid);
+  // a chunk's owner count travels in 16 bits: at most kChunkMaxTiles tiles per chunk (65 M items at the full grid);
+  // beyond that the tile-chained kernel runs
+  const bool chunk_fits = owner_scan_tiles(n_max) <= (size_t)kChunkMaxTiles * (size_t)cgrid;
+  if (scratch.chunk && !force_tiles && chunk_fits) {
+    if (!scratch.cleared) GGMS_HIP(hipMemsetAsync(scratch.chunk, 0, chunk_desc_words() * sizeof(uint32_t), s));
+    const uint32_t epoch = next_scan_epoch();
+    const uint32_t epoch16 = epoch % 65535u + 1u; // never 0: a cleared descriptor is "not written"
+    const uint32_t skip_below = poisoned ? 1u : 0u;
+    unsigned long long *desc0 = desc;             // chunk 0: 64-bit, carries the table's item count in
+    if (di.batch)
+      hipLaunchKernelGGL(k_owner_scan_chunked<true>, dim3(cgrid), dim3(kBlock), 0, s, di.w, di.version, ht->n2o, input,
+                         di.cand, di.lost, di.tag, mapped, n, desc0, scratch.chunk, epoch, epoch16, ht->num_items_dev,
+                         mirror_a, mirror_b, err, skip_below);
+    else
+      hipLaunchKernelGGL(k_owner_scan_chunked<false>, dim3(cgrid), dim3(kBlock), 0, s, di.w, di.version, ht->n2o, input,
+                         di.cand, di.lost, di.tag, mapped, n, desc0, scratch.chunk, epoch, epoch16, ht->num_items_dev,
+                         mirror_a, mirror_b, err, skip_below);
+  } else {
+    // Fewer workgroups than tiles on purpose: a workgroup takes tiles from the ticket one after the other, so by the
+    // time tile t is taken the tiles before t - grid have finished and the look-back finds a published prefix in
+    // its first window; with one workgroup per tile every tile starts at once and tile t walks t / 64 windows.
+    const int oscan_grid = (int)std::min<size_t>(grid_for(owner_scan_tiles(n_max), 1), owner_scan_grid_cap());
+    if (di.batch)
+      hipLaunchKernelGGL(k_owner_scan<true>, dim3(oscan_grid), dim3(kBlock), 0, s, di.w, di.version, ht->n2o, input, di.cand,
+                         di.lost, di.tag, mapped, n, ctl, desc, next_scan_epoch(), ht->num_items_dev, mirror_a, mirror_b, err);
+    else
+      hipLaunchKernelGGL(k_owner_scan<false>, dim3(oscan_grid), dim3(kBlock), 0, s, di.w, di.version, ht->n2o, input, di.cand,
+                         di.lost, di.tag, mapped, n, ctl, desc, next_scan_epoch(), ht->num_items_dev, mirror_a, mirror_b, err);
+  }
   GGMS_LAUNCH_CHECK();
   if (!mapped || rest == kRestDefer) return GGMS_OK;
   if (di.batch) { // this fill's own non-owners, now: the map must already hold this fill's segment
@@ -516,11 +814,13 @@ int ggms_hashtable_fill_with_duplicates(ggms_hashtable_t *ht, const ggms_id_t *i
     uint32_t *item_pos = (uint32_t *)workspace;
     unsigned long long *lost = (unsigned long long *)(((uintptr_t)(item_pos + num_input) + 15) & ~(uintptr_t)15);
     uint32_t *scan_words = (uint32_t *)(lost + num_input);
+    ScanArea area{scan_words, false};
+    area.chunk = scan_words + tile_scan_words(num_input) + 8; // the last chunk_desc_words() of the workspace
     DedupInsert di{};
     di.cand = item_pos;
     di.lost = lost; // leaf mode: base 0, the owners' words are rewritten as {assigned, local id}
-    int rc = ht_fill_impl(ht, input, num_input, count_of(num_input), di, false, ScanArea{scan_words, false}, nullptr,
-                          nullptr, s, nullptr, nullptr, kRestNow, nullptr);
+    int rc = ht_fill_impl(ht, input, num_input, count_of(num_input), di, false, area, nullptr, nullptr, s, nullptr, nullptr,
+                          kRestNow, nullptr);
     if (rc != GGMS_OK) return rc;
   }
   if (unique_out) {

@@ -109,7 +109,7 @@ static size_t sampler_ws_words(int sample_type, const BatchCaps &c, const size_t
 
 // ---- workspace layout of one batch (uint32 words; every piece starts 16-byte aligned) --------------------------
 struct BatchLayout {
-  size_t seed_local, samp_ws, tmp_dst[16], cand, lost, scan, total;
+  size_t seed_local, samp_ws, tmp_dst[16], cand, lost, scan, chunk, total;
   size_t dedup_items; // entries of cand / lost
   size_t scan_tiles;  // descriptors the scans of the batch may use (cleared by the batch prologue)
 };
@@ -134,6 +134,10 @@ static BatchLayout layout_of(int sample_type, size_t num_seeds, const size_t *fa
   if (sample_type == GGMS_RANDOM_WALK) l.scan_tiles = std::max(l.scan_tiles, walk_scan_tiles(c.max_in_all));
   l.scan = w;
   w += up4(std::max(tile_scan_words(std::max(c.max_e_all, c.max_in_all)), 8 + 2 * l.scan_tiles + 4) + 16);
+  // the chunked owner scan's 32-bit descriptors + one ticket set per ticketed sampler launch: a piece of their own,
+  // cleared by the batch prologue too
+  l.chunk = w;
+  w += up4(chunk_desc_words() + (size_t)kTicketSets * kTicketWords);
   l.total = w;
   return l;
 }
@@ -192,6 +196,8 @@ int ggms_sample_batch(int sample_type, const ggms_graph_t *graph, const ggms_id_
   // every ordered scan of the batch (seed offsets, owner flags) shares one control/descriptor area that is
   // cleared once here: descriptors are epoch-tagged, the control words re-arm themselves
   ScanArea scan{w + lay.scan, true};
+  scan.chunk = w + lay.chunk;
+  scan.tickets = scan.chunk + chunk_desc_words(); // chunk_desc_words() is a multiple of 4: the sets stay 16-byte aligned
 
   const GraphView g = view_of(graph);
   // hash_table->Reset (dist_loops.cc:105): a new version stamp; the item count is zeroed by the prologue below
@@ -205,7 +211,8 @@ int ggms_sample_batch(int sample_type, const ggms_graph_t *graph, const ggms_id_
   // scan-area clear, item count reset, num_dst of the first layer = |seeds| (dist_loops.cc:305).
   const size_t clear_words = scan_mode() == 1 ? 8 + 2 * (num_tiles_for(std::max(c.max_e_all, c.max_in_all)) + 1) : 0;
   const BatchPrologue pro{scan_align(scan.words), (uint32_t)std::max<size_t>(8 + 2 * lay.scan_tiles, clear_words),
-                          ht->num_items_dev, counts_dev + 3 * (num_layer - 1) + 2};
+                          scan.chunk, (uint32_t)(chunk_desc_words() + (size_t)kTicketSets * kTicketWords), ht->num_items_dev,
+                          counts_dev + 3 * (num_layer - 1) + 2};
   // direct table = batch mode of the dedup protocol (ggms_device.h): one index space for the whole batch, seeds first
   DedupInsert di{};
   di.cand = item_pos;

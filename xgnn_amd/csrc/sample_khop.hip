@@ -92,7 +92,8 @@ __global__ __launch_bounds__(128 * (4 / GPW)) void k_khop3_fused(GraphView g, co
   __shared__ uint32_t set_tab[8][128]; // one open-addressing set per group; set_mask + 1 slots in use
   __shared__ const uint32_t *s_ptr[128];
   __shared__ uint32_t s_len[128], s_rid[128], s_off[129];
-  __shared__ uint32_t s_tile, s_prefix;
+  __shared__ uint64_t s_tile;
+  __shared__ uint32_t s_prefix;
   const uint32_t lane = threadIdx.x & 63u;
   const bool active = GPW == 4 || lane < 16u * GPW; // lanes that belong to a group
   const uint64_t n = n_arg.get();
@@ -107,7 +108,7 @@ __global__ __launch_bounds__(128 * (4 / GPW)) void k_khop3_fused(GraphView g, co
   bool dirty = false; // group-uniform: the set holds entries
 
   for (;;) {
-    if (threadIdx.x == 0) s_tile = atomicAdd(&fs.ctl[0], 1u);
+    if (threadIdx.x == 0) s_tile = take_ticket(fs.tick);
     __syncthreads();
     const uint64_t b = s_tile;
     if (b >= num_tiles) break;
@@ -288,13 +289,7 @@ __global__ __launch_bounds__(128 * (4 / GPW)) void k_khop3_fused(GraphView g, co
     }
     __syncthreads(); // LDS is rewritten by the next tile
   }
-  if (threadIdx.x == 0) {
-    if (num_tiles == 0 && blockIdx.x == 0) *fs.num_out = 0;
-    if (atomicAdd(&fs.ctl[1], 1u) == gridDim.x - 1) { // the last block out re-arms the ticket
-      fs.ctl[0] = 0;
-      fs.ctl[1] = 0;
-    }
-  }
+  if (threadIdx.x == 0 && num_tiles == 0 && blockIdx.x == 0) *fs.num_out = 0;
 }
 
 // ---- khop0 (reservoir) -------------------------------------------------------
@@ -661,7 +656,9 @@ static int khop3_groups_per_wave(size_t blocks) {
   return 4;
 }
 
-size_t sample_ws_words(size_t num_input) { return num_input + tile_scan_words(num_input) + 16 + 2 * (num_input / 128 + 2); }
+size_t sample_ws_words(size_t num_input) {
+  return num_input + tile_scan_words(num_input) + 16 + 2 * (num_input / 128 + 2) + kTicketWords + 16;
+}
 
 template <int GPW, bool INSERT>
 static int launch_khop3_fused(int grid, size_t lds, hipStream_t s, GraphView g, const uint32_t *input, Count n,
@@ -687,9 +684,17 @@ int sample_khop3_impl(GraphView g, const uint32_t *input, size_t n_max, Count n,
                       const DedupInsert *insert) {
   const size_t tiles = (n_max + 127) / 128;
   uint32_t *ctl = scan_align(shared_scan ? shared_scan->words : workspace);
-  if (!shared_scan || !shared_scan->cleared)
+  // tickets: the batch's next set (zeroed by the batch prologue); a private area keeps its set behind the descriptors
+  uint32_t *tick = shared_scan ? take_ticket_set(shared_scan) : ctl + 8 + 2 * (tiles + 1) + 2;
+  if (!tick) {
+    set_error("sample_khop3: the shared scan area has no ticket set left");
+    return GGMS_ERR_INVALID;
+  }
+  if (!shared_scan)
+    GGMS_HIP(hipMemsetAsync(ctl, 0, (8 + 2 * (tiles + 1) + 2 + kTicketWords) * sizeof(uint32_t), s));
+  else if (!shared_scan->cleared)
     GGMS_HIP(hipMemsetAsync(ctl, 0, (8 + 2 * (tiles + 1)) * sizeof(uint32_t), s));
-  const FusedScan fs{ctl, reinterpret_cast<unsigned long long *>(ctl + 8), next_scan_epoch(), num_out_dev,
+  const FusedScan fs{tick, reinterpret_cast<unsigned long long *>(ctl + 8), next_scan_epoch(), num_out_dev,
                      device_status_word()};
   const SrcMode sm{seed_local, src_local};
   // 64 slots up to fanout 31 (load < 0.5), else the reference's 128 (HASHTABLE_SIZE, khop3.cu:43)

@@ -90,12 +90,13 @@ __global__ __launch_bounds__(T) void k_walk_topk_emit(uint32_t *tmp_src, uint32_
   extern __shared__ uint32_t lds[]; // uniq[per][T], cnt[per][T], stage_dst[Kc * T], stage_cnt[Kc * T]
   uint32_t *const uniq = SPILL ? tmp_dst : lds, *const cnt = SPILL ? tmp_src : lds + per * T;
   uint32_t *const stage_dst = lds + 2 * per * T, *const stage_cnt = stage_dst + Kc * T; // !SPILL only
-  __shared__ uint32_t s_wsum[W], s_tile, s_prefix;
+  __shared__ uint32_t s_wsum[W], s_prefix;
+  __shared__ uint64_t s_tile;
   const uint64_t n = n_arg.get();
   const uint64_t num_tiles = (n + T - 1) / T;
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
   for (;;) {
-    if (tid == 0) s_tile = atomicAdd(&fs.ctl[0], 1u);
+    if (tid == 0) s_tile = take_ticket(fs.tick);
     __syncthreads();
     const uint64_t b = s_tile;
     if (b >= num_tiles) break;
@@ -202,13 +203,7 @@ __global__ __launch_bounds__(T) void k_walk_topk_emit(uint32_t *tmp_src, uint32_
     }
     __syncthreads(); // LDS is rewritten by the next tile
   }
-  if (tid == 0) {
-    if (num_tiles == 0 && blockIdx.x == 0) *fs.num_out = 0;
-    if (atomicAdd(&fs.ctl[1], 1u) == gridDim.x - 1) { // the last block out re-arms the ticket
-      fs.ctl[0] = 0;
-      fs.ctl[1] = 0;
-    }
-  }
+  if (tid == 0 && num_tiles == 0 && blockIdx.x == 0) *fs.num_out = 0;
 }
 
 static void walk_block_shape(uint32_t num_walk, uint32_t &bx, uint32_t &by) {
@@ -227,7 +222,7 @@ size_t walk_scan_tiles(size_t num_input) { return (num_input + 63) / 64 + 2; }
 
 size_t random_walk_ws_words(size_t num_input, size_t walk_length, size_t num_walk, size_t K) {
   (void)K;
-  return 2 * num_input * walk_length * num_walk + 8 + 2 * walk_scan_tiles(num_input) + 64;
+  return 2 * num_input * walk_length * num_walk + 8 + 2 * walk_scan_tiles(num_input) + 64 + kTicketWords + 16;
 }
 
 // tmp_src / tmp_dst: [walk_length * num_walk][n_max], visit-major
@@ -275,9 +270,17 @@ int sample_random_walk_impl(GraphView g, const uint32_t *input, size_t n_max, Co
   const uint32_t T = per > kLdsVisits ? 64u : walk_tile(per, Kc);
   const size_t tiles = (n_max + T - 1) / T;
   uint32_t *ctl = scan_align(shared_scan ? shared_scan->words : w);
-  if (!shared_scan || !shared_scan->cleared)
+  // tickets: the batch's next set (zeroed by the batch prologue); a private area keeps its set behind the descriptors
+  uint32_t *tick = shared_scan ? take_ticket_set(shared_scan) : ctl + 8 + 2 * (tiles + 1) + 2;
+  if (!tick) {
+    set_error("sample_random_walk: the shared scan area has no ticket set left");
+    return GGMS_ERR_INVALID;
+  }
+  if (!shared_scan)
+    GGMS_HIP(hipMemsetAsync(ctl, 0, (8 + 2 * (tiles + 1) + 2 + kTicketWords) * sizeof(uint32_t), s));
+  else if (!shared_scan->cleared)
     GGMS_HIP(hipMemsetAsync(ctl, 0, (8 + 2 * (tiles + 1)) * sizeof(uint32_t), s));
-  const FusedScan fs{ctl, reinterpret_cast<unsigned long long *>(ctl + 8), next_scan_epoch(), num_out_dev,
+  const FusedScan fs{tick, reinterpret_cast<unsigned long long *>(ctl + 8), next_scan_epoch(), num_out_dev,
                      device_status_word()};
   const SrcMode sm{seed_local, src_local};
   const bool spill = per > kLdsVisits;

@@ -191,17 +191,28 @@ int sample_weighted_impl(const uint32_t *indptr, const uint32_t *indices, const 
 }
 
 // ---- weighted_khop_hash_dedup --------------------------------------------------------------------------
-// Thread t of block b owns stream 256 b + t and seeds 1024 b + t + 256 r (hash_dedup.cu:69-80).  The
-// reference keeps the per-thread 50-slot table {value, round id} in local memory; here it sits in LDS,
-// slot-major ([slot][thread]: a wave's accesses to one slot are 64 consecutive words, conflict-free), and is
-// keyed by round id = the seed's id exactly as there, so it is initialised once per thread.
+// Thread t of block b owns stream 256 b + t and seeds 1024 b + t + 256 r (hash_dedup.cu:69-80); a seed with more than
+// `fanout` neighbours draws alias-method candidates (two draws each) until `fanout` DISTINCT ids are found.  The
+// reference keeps the stream's 50-slot table {value, round id} in local memory, keyed by round id = the seed's id and
+// therefore never cleared; the table lives in LDS here and is kept exactly as the reference would leave it (an
+// earlier seed of the stream with the same id still counts).
+//
+// The stream <-> seed map and the order of a stream's draws are the reference's; how the draws are RESOLVED is not.
+// A try consumes exactly two draws whatever its outcome, so the stream's next tries are known in advance.  One lane
+// per stream (round 2) had the slowest list of the launch set its time: a 26-neighbour list asked for 25 distinct
+// picks takes a couple of thousand tries, eight per memory round trip -- 885 us per products step.  Now the 16 lanes
+// of a group serve ONE stream: every lane steps the generator through the round's 16 R tries (9 ALU ops per draw) and
+// keeps tries lig, lig + 16, ...; the 3 x 16 R loads (neighbour, acceptance probability, alias) of the round are in
+// flight together; a read-only probe of the table then drops the tries whose candidate is already there (most of
+// them, in a long rejection run -- a present entry stays present, entries are only ever added), and the rest go
+// through the reference's insert one after the other in try order, so that accepted picks, their order and the
+// table's layout are exactly the sequential ones.  If the seed completes at try t*, the generator is put back to just
+// after it.
 constexpr uint32_t kDedupSlots = 50;       // hash_dedup.cu:42
 constexpr uint32_t kDedupMaxTries = 65536; // the reference spins forever on a list without `fanout` distinct ids
-constexpr uint32_t kDedupMaxProbes = 64;   // ... and on a full table (a seed id met twice by one thread, fanout >= 25)
+constexpr uint32_t kDedupMaxProbes = 64;   // ... and on a full table (a seed id met twice by one stream, fanout >= 25)
 
-// One wave per workgroup (a quarter of a reference block), as in k_sample_khop2: every load here touches 64 different
-// lines and a workgroup's waves share the CU's address path.  A try is ONE round trip: the neighbour, its acceptance
-// probability and its alias are loaded together (the alias unconditionally), not the alias after the comparison.
+template <uint32_t R> // tries per lane and round
 __global__ __launch_bounds__(kWave) void k_weighted_hash_dedup(const uint32_t *__restrict__ indptr,
                                                                 const uint32_t *__restrict__ indices,
                                                                 const float *__restrict__ prob,
@@ -211,14 +222,16 @@ __global__ __launch_bounds__(kWave) void k_weighted_hash_dedup(const uint32_t *_
                                                                 uint32_t *__restrict__ out_src,
                                                                 uint32_t *__restrict__ out_dst,
                                                                 uint32_t *__restrict__ states, SrcMode sm) {
-  __shared__ uint32_t val[kDedupSlots][kWave], round_of[kDedupSlots][kWave];
+  __shared__ uint32_t val[4][kDedupSlots], round_of[4][kDedupSlots]; // one table per group = per stream
   const uint64_t n = n_arg.get();
-  const uint32_t t = threadIdx.x; // lane: column of the LDS tables
+  const uint32_t lane = threadIdx.x, g = lane >> 4, lig = lane & 15u, grp_shift = lane & ~15u;
+  uint32_t *const tv = val[g], *const tr = round_of[g];
   const uint64_t num_tiles = (n + 1023) / 1024;
-  for (uint64_t q = blockIdx.x; q < 4 * num_tiles; q += gridDim.x) {
-    const uint64_t b = q >> 2;                          // reference block
-    const uint32_t tb = (uint32_t)(q & 3u) * kWave + t; // thread of that block
-    for (uint32_t z = 0; z < kDedupSlots; ++z) { val[z][t] = kEmptyKey; round_of[z][t] = kEmptyKey; } // :72-76
+  for (uint64_t q = blockIdx.x; q < 64 * num_tiles; q += gridDim.x) { // 64 waves x 4 streams = one reference block
+    const uint64_t b = q >> 6;                      // reference block
+    const uint32_t tb = (uint32_t)(q & 63u) * 4u + g; // thread of that block = the stream this group serves
+    for (uint32_t z = lig; z < kDedupSlots; z += 16) { tv[z] = kEmptyKey; tr[z] = kEmptyKey; } // :72-76
+    __builtin_amdgcn_wave_barrier();
     const uint64_t sid = b * kBlock + tb;
     Xorwow st;
     st.load(states + 6 * sid);
@@ -231,62 +244,104 @@ __global__ __launch_bounds__(kWave) void k_weighted_hash_dedup(const uint32_t *_
       const uint32_t o = offset[index];
       const uint32_t sv = sm.value(rid, index);
       if (len <= fanout) {
-        for (uint32_t j = 0; j < len; ++j) {
+        for (uint32_t j = lig; j < len; j += 16) {
           out_src[o + j] = sv;
           out_dst[o + j] = indices[off + j];
         }
         continue;
       }
       drew = true;
-      // A try consumes exactly two draws whatever its outcome, so the next B tries' positions and uniforms are known
-      // in advance: their 3 B loads go out together and the tries are then resolved in order against the LDS table.
-      // If the seed completes inside a batch, the generator is put back to just after the last try used.
-      constexpr uint32_t B = 8;
       uint32_t got = 0, tries = 0;
       while (got < fanout) {
         const Xorwow st0 = st;
-        uint32_t kk[B], nb[B], al[B];
-        float uu[B], pr[B];
+        uint32_t kraw[R] = {}, uraw[R] = {};
 #pragma unroll
-        for (uint32_t i = 0; i < B; ++i) {
-          kk[i] = st.next() % len;
-          uu[i] = st.uniform();
+        for (uint32_t i = 0; i < R; ++i) {
+#pragma unroll
+          for (uint32_t l = 0; l < 16; ++l) { // try 16 i + l of the round: position draw, then acceptance draw
+            const uint32_t a = st.next(), u = st.next();
+            kraw[i] = (l == lig) ? a : kraw[i];
+            uraw[i] = (l == lig) ? u : uraw[i];
+          }
         }
+        uint32_t cand[R];
+        {
+          uint32_t nb[R], al[R];
+          float pr[R];
 #pragma unroll
-        for (uint32_t i = 0; i < B; ++i) {
-          nb[i] = indices[off + kk[i]];
-          al[i] = alias[off + kk[i]];
-          pr[i] = prob[off + kk[i]];
+          for (uint32_t i = 0; i < R; ++i) { // one round trip: the alias is loaded unconditionally, with the rest
+            const uint32_t k = kraw[i] % len;
+            nb[i] = indices[off + k];
+            al[i] = alias[off + k];
+            pr[i] = prob[off + k];
+          }
+#pragma unroll
+          for (uint32_t i = 0; i < R; ++i) cand[i] = (Xorwow::to_uniform(uraw[i]) > pr[i]) ? al[i] : nb[i]; // strict >, :101-103
         }
-        uint32_t used = B;
+        // read-only probe: a candidate that is in the table now is in it whenever its turn comes
+        bool need[R];
 #pragma unroll
-        for (uint32_t i = 0; i < B; ++i) {
-          if (got < fanout) {
-            const bool give_up = ++tries > kDedupMaxTries;
-            const uint32_t cand = (uu[i] > pr[i]) ? al[i] : nb[i]; // strict >, :101-103
-            uint32_t pos = cand % kDedupSlots, gap = 1;            // insert_hash_table, :41-57
+        for (uint32_t i = 0; i < R; ++i) {
+          uint32_t pos = cand[i] % kDedupSlots, gap = 1;
+          bool present = false;
+          for (uint32_t probe = 0; probe < kDedupMaxProbes; ++probe) {
+            if (tr[pos] != rid) break;
+            if (tv[pos] == cand[i]) { present = true; break; }
+            pos = (pos + gap) % kDedupSlots;
+            ++gap;
+          }
+          need[i] = !present;
+        }
+        // the others, in try order, through insert_hash_table (:41-57) as the reference runs it
+        const bool all_serial = tries + 16 * R > kDedupMaxTries; // the give-up rule looks at every try: no shortcut
+        uint32_t used = 16 * R;
+        bool done = false;
+#pragma unroll
+        for (uint32_t i = 0; i < R; ++i) {
+          uint32_t m = done ? 0u : (uint32_t)(__ballot(need[i] || all_serial) >> grp_shift) & 0xffffu;
+          while (m != 0) {
+            const uint32_t t = (uint32_t)__ffs(m) - 1u;
+            m &= m - 1u;
+            const uint32_t c = __shfl(cand[i], (int)(grp_shift + t), 64);
+            const bool give_up = tries + 16 * i + t + 1 > kDedupMaxTries;
+            uint32_t pos = c % kDedupSlots, gap = 1;
             bool is_new = true; // a probe sequence that finds neither a free slot nor the value takes the candidate
             for (uint32_t probe = 0; probe < kDedupMaxProbes; ++probe) {
-              if (round_of[pos][t] != rid) { round_of[pos][t] = rid; val[pos][t] = cand; break; }
-              if (val[pos][t] == cand) { is_new = false; break; }
+              if (tr[pos] != rid) {
+                if (lig == 0) { tr[pos] = rid; tv[pos] = c; }
+                break;
+              }
+              if (tv[pos] == c) { is_new = false; break; }
               pos = (pos + gap) % kDedupSlots;
               ++gap;
             }
+            __builtin_amdgcn_wave_barrier();
             if (is_new || give_up) {
-              out_src[o + got] = sv;
-              out_dst[o + got] = cand;
+              if (lig == 0) {
+                out_src[o + got] = sv;
+                out_dst[o + got] = c;
+              }
               ++got;
-              if (got == fanout) used = i + 1;
+              if (got == fanout) {
+                used = 16 * i + t + 1;
+                done = true;
+                m = 0;
+              }
             }
           }
         }
-        if (used < B) { // two draws per try actually made
-          st = st0;
-          for (uint32_t i = 0; i < 2 * used; ++i) (void)st.next();
+        if (done) {
+          if (used < 16 * R) { // two draws per try actually made
+            st = st0;
+            for (uint32_t d = 0; d < 2 * used; ++d) (void)st.next();
+          }
+        } else {
+          tries += 16 * R;
         }
       }
     }
-    if (drew) st.store(states + 6 * sid);
+    if (drew && lig == 0) st.store(states + 6 * sid);
+    __builtin_amdgcn_wave_barrier(); // the tables are re-initialised by the next pass
   }
 }
 
@@ -300,9 +355,19 @@ int sample_weighted_hash_dedup_impl(const uint32_t *indptr, const uint32_t *indi
   int rc = tile_scan(MinDegFanout{indptr, input, fanout}, StoreWord{offset}, n_max, n, sa, nullptr, nullptr,
                      num_out_dev, s);
   if (rc != GGMS_OK) return rc;
-  hipLaunchKernelGGL(k_weighted_hash_dedup, dim3(grid_for(4 * ((n_max + 1023) / 1024), 1)), dim3(kWave), 0, s, indptr,
-                     indices, prob, alias, input, n, fanout, offset, out_src, out_dst, states,
-                     SrcMode{seed_local, src_local});
+  // one wave per workgroup, four streams per wave; up to 8192 waves stay resident (32 per CU)
+  const dim3 grid((unsigned)std::min<size_t>(64 * ((n_max + 1023) / 1024), 8192)), block(kWave);
+  const SrcMode sm{seed_local, src_local};
+  // tries per round = 16 R: about 1.5 x fanout, so that an ordinary seed is done in one round trip
+  if (fanout <= 8)
+    hipLaunchKernelGGL(k_weighted_hash_dedup<1>, grid, block, 0, s, indptr, indices, prob, alias, input, n, fanout, offset,
+                       out_src, out_dst, states, sm);
+  else if (fanout <= 20)
+    hipLaunchKernelGGL(k_weighted_hash_dedup<2>, grid, block, 0, s, indptr, indices, prob, alias, input, n, fanout, offset,
+                       out_src, out_dst, states, sm);
+  else
+    hipLaunchKernelGGL(k_weighted_hash_dedup<4>, grid, block, 0, s, indptr, indices, prob, alias, input, n, fanout, offset,
+                       out_src, out_dst, states, sm);
   GGMS_LAUNCH_CHECK();
   return GGMS_OK;
 }

@@ -48,7 +48,34 @@ struct ScanArea {
   uint32_t *words;
   bool cleared;
   uint32_t *stash = nullptr; // optional n_max words: value(i) is evaluated ONCE (reduce pass) and re-read from here
+  uint32_t *chunk = nullptr; // optional chunk_desc_words() words for the chunked owner scan (hashtable.hip); zeroed
+                             // with the area (`cleared`), never shared with the 64-bit descriptors of the other scans
+  uint32_t *tickets = nullptr; // optional kTicketSets ticket sets (below), zeroed with the area; a ticketed sampler
+  uint32_t next_ticket_set = 0; // launch of the batch takes the next one (take_ticket_set)
 };
+
+// ---- tickets without a hot word ----------------------------------------------------------------------------------
+// Atomics on ONE address are served one after the other at the memory side: 11 ns each, returning or not
+// (tools/micro_ticket.hip, profiles/r03_micro_ticket.txt).  A layer of 800 K seeds is 6250 tiles: tickets from a single
+// counter, one failing ticket per workgroup at the end and a "last one out re-arms the counter" atomic on the
+// neighbouring word come to 10 K atomics on one line = 114 us of a 200-us kernel.  So the tickets of a launch come from
+// kTicketLanes counters 64 bytes apart: workgroup w draws from lane w % S, lane l hands out the tiles l, l + S,
+// l + 2 S, ...  A tile's predecessors are still either finished, or owned by a running workgroup, or the next ticket
+// of a lane whose workgroups only ever wait for LOWER tiles -- the smallest unfinished tile is never waited for by
+// the workgroups that could take it -- so the look-back keeps its forward progress.  Nothing is re-armed: every
+// ticketed launch of a batch has a ticket set of its own, all of them zeroed by the batch prologue.
+constexpr uint32_t kTicketLanes = 32, kTicketStride = 16;
+constexpr uint32_t kTicketWords = kTicketLanes * kTicketStride; // one set
+constexpr uint32_t kTicketSets = 20;                             // per batch: one per ticketed sampler launch (<= 16 layers)
+__device__ __forceinline__ uint64_t take_ticket(uint32_t *set) { // one thread of the workgroup
+  const uint32_t lanes = gridDim.x < kTicketLanes ? gridDim.x : kTicketLanes;
+  const uint32_t l = blockIdx.x % lanes;
+  return (uint64_t)l + (uint64_t)lanes * atomicAdd(&set[kTicketStride * l], 1u);
+}
+inline uint32_t *take_ticket_set(ScanArea *a) {
+  if (!a || !a->tickets || a->next_ticket_set >= kTicketSets) return nullptr;
+  return a->tickets + (size_t)kTicketWords * a->next_ticket_set++;
+}
 
 inline uint32_t next_scan_epoch() {
   static std::atomic<uint32_t> g{0};
@@ -99,7 +126,7 @@ __device__ __forceinline__ uint32_t scan_lookback(const unsigned long long *desc
 
 // what a sampler kernel that scans its own tiles (k_khop3_fused, k_walk_topk_emit) needs of a scan area
 struct FusedScan {
-  uint32_t *ctl;             // {ticket, done}
+  uint32_t *tick;            // this launch's ticket set (kTicketWords zeroed words), see take_ticket
   unsigned long long *desc;  // one descriptor per tile
   uint32_t epoch;
   uint64_t *num_out;         // total number of edges

@@ -142,20 +142,26 @@ def build_prob_prefix_table(indptr, weights, num_threads=8):
     return out
 
 
-def write_dataset(path, graph, feat=None, label=None, valid_frac=0.02, test_frac=0.05, feat_dtype="F32", weights=None):
+def write_dataset(path, graph, feat=None, label=None, valid_frac=0.02, test_frac=0.05, feat_dtype="F32", weights=None,
+                  minimal=False):
     """Write a dataset directory in the reference's on-disk format (datagen/README.md:37-51,
     samgraph/common/constant.cc:23-51, engine.cc:109-443): meta.txt (tab separated) + raw little-endian
     arrays: indptr/indices/train_set/test_set/valid_set/cache_by_* uint32, feat row-major, label int64;
-    weights (one float per edge) adds prob_table.bin / alias_table.bin / prob_prefix_table.bin."""
+    weights (one float per edge) adds prob_table.bin / alias_table.bin / prob_prefix_table.bin.
+    minimal: what a sampling + extract run needs and nothing that costs minutes at papers100M size -- one-node
+    valid / test sets instead of random slices of the complement, no cache_by_random.bin."""
     import os
     os.makedirs(path, exist_ok=True)
     ip, ix, train, meta = graph["indptr"], graph["indices"], graph["train_set"], graph["meta"]
     n = ip.size - 1
-    rng = np.random.RandomState(7)
-    rest = np.setdiff1d(np.arange(n, dtype=np.uint32), train, assume_unique=False)
-    rng.shuffle(rest)
-    nv, nt = int(n * valid_frac), int(n * test_frac)
-    valid, test = rest[:nv].astype(np.uint32), rest[nv:nv + nt].astype(np.uint32)
+    if minimal:
+        valid = test = np.zeros(1, np.uint32)
+    else:
+        rng = np.random.RandomState(7)
+        rest = np.setdiff1d(np.arange(n, dtype=np.uint32), train, assume_unique=False)
+        rng.shuffle(rest)
+        nv, nt = int(n * valid_frac), int(n * test_frac)
+        valid, test = rest[:nv].astype(np.uint32), rest[nv:nv + nt].astype(np.uint32)
     ip.astype(np.uint32).tofile(os.path.join(path, "indptr.bin"))
     ix.astype(np.uint32).tofile(os.path.join(path, "indices.bin"))
     train.astype(np.uint32).tofile(os.path.join(path, "train_set.bin"))
@@ -171,7 +177,8 @@ def write_dataset(path, graph, feat=None, label=None, valid_frac=0.02, test_frac
         alias.tofile(os.path.join(path, "alias_table.bin"))
         build_prob_prefix_table(ip, weights).tofile(os.path.join(path, "prob_prefix_table.bin"))
     degree_rank(ip).tofile(os.path.join(path, "cache_by_degree.bin"))
-    np.random.RandomState(11).permutation(n).astype(np.uint32).tofile(os.path.join(path, "cache_by_random.bin"))
+    if not minimal:
+        np.random.RandomState(11).permutation(n).astype(np.uint32).tofile(os.path.join(path, "cache_by_random.bin"))
     with open(os.path.join(path, "meta.txt"), "w") as f:
         for k, v in [("NUM_NODE", n), ("NUM_EDGE", ix.size), ("FEAT_DIM", meta["feat_dim"]),
                      ("NUM_CLASS", meta["num_class"]), ("NUM_TRAIN_SET", train.size), ("NUM_TEST_SET", test.size),

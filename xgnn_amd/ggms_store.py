@@ -9,7 +9,8 @@ not cached stay in host memory.  Two interchangeable ways to bring a batch's row
                cuda_cache_manager_device.cu:277-299).  No exchange step, no staging.
   mode "a2a"   one exchange: bucket the batch by owner -> all-to-all of row ids -> every owner gathers the
                rows asked of it from its own HBM -> all-to-all of rows -> scatter into the batch.  Fewer,
-               larger xGMI transfers through RCCL; one host sync per batch for the split sizes.
+               larger xGMI transfers through RCCL; ONE host wait per batch (the split sizes are host arguments of
+               the collective), no concatenations.  The measured alternative to "peer", not the default.
 
 Both produce the bytes `extract(full_table, nodes)` would.  The device work goes through `leaf` (default:
 the HIP operators of xgnn_amd.ops); tests exercise the host logic on CPU ranks by passing their own leaf.
@@ -72,19 +73,23 @@ class HipLeaf:
         from . import ops
         self.ops = ops
 
-    def split_by_owner(self, table, nodes, num, num_part, num_dev=None):
-        """-> (bucket_row, bucket_pos, counts[num_part + 1] on the host).  One host sync.
+    def split_by_owner(self, table, nodes, num, num_part, order, num_dev=None):
+        """Group the batch by owning shard.  -> (bucket_row, bucket_pos, counts) with counts[p] = rows owned by
+        shard p (p = num_part: host tier) as an int64 DEVICE tensor; the buckets lie in `bucket_row` / `bucket_pos`
+        in the sequence `order` (a device int64 permutation of 0..num_part).  No host round trip: the bucket
+        cursors are the exclusive prefix of the histogram taken in that sequence, computed on the device.
         num is an upper bound when the batch size lives on the device (num_dev)."""
         ops, dev = self.ops, nodes.device
         counts = torch.zeros(num_part + 1, dtype=torch.int64, device=dev)
         slots = torch.empty(max(1, num), dtype=torch.int32, device=dev)
         ops.owner_histogram(table, nodes, num_part, slots, counts, num=num, num_dev=num_dev)
-        counts_h = counts.cpu()
-        cursor = (torch.cumsum(counts_h, 0) - counts_h).to(dev)
+        in_order = counts[order]
+        cursor = torch.empty_like(counts)
+        cursor[order] = torch.cumsum(in_order, 0) - in_order
         row = torch.empty(max(1, num), dtype=torch.int32, device=dev)
         pos = torch.empty(max(1, num), dtype=torch.int32, device=dev)
-        ops.owner_bucket(slots, nodes, num_part, cursor, row, pos, num=num, num_dev=num_dev)
-        return row, pos, counts_h
+        ops.owner_bucket(slots, nodes, num_part, cursor, row, pos, num=num, num_dev=num_dev)  # advances `cursor`
+        return row, pos, counts
 
     def gather(self, src, index):
         return self.ops.extract(src, index)
@@ -135,6 +140,7 @@ class FeatureShards:
         self.leaf = leaf if leaf is not None else HipLeaf()
         self.parts_table = None
         self._shared = None
+        self._order = None  # a2a: bucket sequence [ranks ascending without me | me | host], on the device
 
     # ---- mode "peer": publish / map the shards ------------------------------------------------------
     def connect_peers(self, shared_shard):
@@ -191,31 +197,55 @@ class FeatureShards:
         return self._extract_a2a(nodes, num, out, num_dev)
 
     def _extract_a2a(self, nodes, num, out, num_dev=None):
+        """One exchange, ONE host wait (the split sizes are host arguments of the collective):
+        histogram -> bucket cursors on the device -> buckets laid out as [ranks ascending without me | me | host] so
+        that the remote part is one contiguous block in rank order (no concatenation) -> request counts exchanged
+        on the device (RCCL) -> the only device-to-host copy of the batch brings both count vectors -> ids out,
+        rows gathered at their owners, rows back, scattered into the batch."""
         P, me, leaf, dist = self.world, self.rank, self.leaf, self.dist
-        row, pos, counts = leaf.split_by_owner(self.table, nodes, num, P, **({"num_dev": num_dev} if num_dev is not None else {}))
-        counts = [int(c) for c in counts.tolist()]
-        start = np.concatenate([[0], np.cumsum(counts)]).tolist()
-        # my own bucket and the host bucket never leave the GPU
-        leaf.gather_scatter(out, self.shard, row[start[me]:start[me + 1]], pos[start[me]:start[me + 1]])
-        if counts[P]:
+        dev = nodes.device
+        if self._order is None or self._order.device != dev:
+            self._order = torch.tensor([p for p in range(P) if p != me] + [me, P], dtype=torch.int64, device=dev)
+        row, pos, counts = leaf.split_by_owner(self.table, nodes, num, P, self._order,
+                                               **({"num_dev": num_dev} if num_dev is not None else {}))
+        send_dev = counts[:P].clone()
+        send_dev[me] = 0  # my own bucket never leaves the GPU
+        if P > 1 and dist.get_backend(self.group) == "nccl":
+            recv_dev = torch.empty_like(send_dev)
+            dist.all_to_all_single(recv_dev, send_dev, group=self.group)
+            both = torch.stack([counts[:P], recv_dev, counts[P:P + 1].expand(P)]).cpu()  # the batch's one host wait
+            counts_h, recv, n_host = both[0].tolist(), both[1].tolist(), int(both[2][0])
+        else:  # other backends (gloo: tests, one-GPU boxes) exchange the counts through host memory
+            c = counts.cpu()  # the batch's one host wait
+            counts_h, n_host = c[:P].tolist(), int(c[P])
+            recv = [0] * P
+            if P > 1:
+                s_h = c[:P].clone()
+                s_h[me] = 0
+                r_h = torch.zeros_like(s_h)
+                dist.all_to_all_single(r_h, s_h, group=self.group)
+                recv = r_h.tolist()
+        send = [0 if p == me else int(counts_h[p]) for p in range(P)]
+        recv = [int(x) for x in recv]
+        n_remote, n_mine = sum(send), int(counts_h[me])
+        # my own bucket and the host bucket: local gathers
+        leaf.gather_scatter(out, self.shard, row[n_remote:n_remote + n_mine], pos[n_remote:n_remote + n_mine])
+        if n_host:
             assert self.host_feat is not None, "batch has uncached nodes but no host tier was given"
-            leaf.gather_scatter(out, self.host_feat, row[start[P]:start[P + 1]], pos[start[P]:start[P + 1]])
+            lo = n_remote + n_mine
+            leaf.gather_scatter(out, self.host_feat, row[lo:lo + n_host], pos[lo:lo + n_host])
         if P == 1:
             return out
-        send = [0 if p == me else counts[p] for p in range(P)]  # ids I ask of each owner
-        recv = self._exchange_counts(send)  # ids each requester asks of me
-        # request ids, grouped by owner (my own bucket cut out)
-        ids_out = torch.cat([row[start[p]:start[p + 1]] for p in range(P) if p != me]) if sum(send) else row[:0]
-        pos_out = torch.cat([pos[start[p]:start[p + 1]] for p in range(P) if p != me]) if sum(send) else pos[:0]
         ids_in = torch.empty(sum(recv), dtype=row.dtype, device=row.device)
-        _all_to_all(dist, ids_in, ids_out.contiguous(), recv, send, self.group)
+        _all_to_all(dist, ids_in, row[:n_remote], recv, send, self.group)  # remote buckets: contiguous, rank order
         rows_out = leaf.gather(self.shard, ids_in) if sum(recv) else self.shard[:0]
-        rows_in = torch.empty((sum(send),) + tuple(self.shard.shape[1:]), dtype=self.shard.dtype, device=row.device)
+        rows_in = torch.empty((n_remote,) + tuple(self.shard.shape[1:]), dtype=self.shard.dtype, device=row.device)
         _all_to_all(dist, rows_in, rows_out.contiguous(), send, recv, self.group)
-        leaf.gather_scatter(out, rows_in, None, pos_out.contiguous())
+        leaf.gather_scatter(out, rows_in, None, pos[:n_remote])
         return out
 
     def _exchange_counts(self, send):
+        """send[p] = ids this rank asks of rank p -> ids every rank asks of this one (on the device under RCCL)."""
         on_dev = self.dist.get_backend(self.group) == "nccl"
         s = torch.tensor(send, dtype=torch.int64, device=self.shard.device if on_dev else "cpu")
         r = torch.zeros_like(s)
