@@ -71,6 +71,49 @@ def coo_properties(ip, ix, seeds, fanouts, inp, layers):
         assert (np.diff(first_pos[np.arange(ndst, nsrc)]) > 0).all()
 
 
+def test_papers100m_hub_skewed_neighbours_oracle_exact(ops):
+    """north_star's "degree-skewed neighbour selection": the papers100M-shaped CSR with every neighbour drawn with
+    probability proportional to its degree (datagen.make_graph neighbour_skew = 1.0 -- hubs turn up in thousands of
+    lists and hundreds of times in one frontier, so the same dedup words are hit by many lanes at once).  One full
+    batch, GCN [5,10,15], both table layouts: COO, input nodes and RNG pool equal to the oracle's, bit for bit."""
+    from xgnn_amd import datagen
+    g = datagen.make_graph("papers100M", seed=42, neighbour_skew=1.0)
+    ip, ix = g["indptr"], g["indices"]
+    hits = np.bincount(ix[: 50_000_000], minlength=ip.size - 1)
+    assert hits.max() > 2000  # a hub: ~0.02 % of all edge slots point at the heaviest node (uniform: a handful)
+    graph = ops.DeviceGraph(dev(ip), dev(ix))
+    fanouts, L = [5, 10, 15], 3
+    seeds = g["train_set"][:BATCH]
+    runs = []
+    for direct in (True, False):
+        bs = ops.BatchSampler(graph, fanouts, BATCH, sample_type=ops.KHOP3, seed=0x5EED, direct_table=direct)
+        bs.sample(dev(seeds))
+        r = bs.result()
+        runs.append(dict(inp=u32(r["input_nodes"]).copy(),
+                         layers=[(u32(l["row"]).copy(), u32(l["col"]).copy(), l["num_src"], l["num_dst"]) for l in r["layers"]],
+                         states=bs.states.cpu().numpy().copy()))
+        num_states = bs.states.shape[0]
+        del bs, r
+        torch.cuda.empty_cache()
+    a, b = runs
+    assert np.array_equal(a["inp"], b["inp"]) and np.array_equal(a["states"], b["states"])
+    orc_states = oracle.random_states(num_states, 0x5EED)
+    want = oracle.do_sample(oracle.KHOP3, ip, ix, seeds, fanouts, orc_states)
+    assert np.array_equal(a["inp"], want["input_nodes"])
+    edges = 0
+    for i in range(L):
+        for run in runs:
+            assert np.array_equal(run["layers"][i][0], want["layers"][i]["row"])
+            assert np.array_equal(run["layers"][i][1], want["layers"][i]["col"])
+            assert run["layers"][i][2:] == (want["layers"][i]["num_src"], want["layers"][i]["num_dst"])
+        edges += want["layers"][i]["row"].size
+    got_states = a["states"].view(np.uint32)
+    assert np.array_equal(got_states[:, 0], orc_states["d"]) and np.array_equal(got_states[:, 1:], orc_states["v"])
+    # the skew shows: far more duplicates than the 12 % of the uniform graph
+    assert a["inp"].size < 0.85 * edges  # (uniform neighbours: 0.88)
+    coo_properties(ip, ix, seeds, fanouts, a["inp"], a["layers"])
+
+
 def test_papers100m_gcn_host_tier_and_hbm_tier(ops):
     from xgnn_amd import datagen
     g = datagen.make_graph("papers100M", seed=42)

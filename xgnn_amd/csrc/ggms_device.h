@@ -86,10 +86,19 @@ struct GraphView {
   uint32_t num_part;
   uint32_t num_cache_node;
 
+  // indptr[v], indptr[v + 1] with ONE 8-byte load (4-byte aligned: global_load_dwordx2 only needs dword alignment):
+  // one request at the memory side instead of two -- the sampler is bounded by requests, not bytes
+  typedef uint32_t u32x2_a4 __attribute__((ext_vector_type(2), aligned(4)));
+  static __device__ __forceinline__ void bounds(const uint32_t *ip, uint32_t v, uint32_t &b, uint32_t &e) {
+    const u32x2_a4 be = *reinterpret_cast<const u32x2_a4 *>(ip + v);
+    b = be.x;
+    e = be.y;
+  }
   // neighbour list of v: pointer + length
   __device__ __forceinline__ const uint32_t *neighbours(uint32_t v, uint32_t &len) const {
     if (num_part == 0) {
-      const uint32_t b = indptr[v], e = indptr[v + 1];
+      uint32_t b, e;
+      bounds(indptr, v, b, e);
       len = e - b;
       return indices + b;
     }
@@ -101,8 +110,8 @@ struct GraphView {
       part = num_part; // whole CSR (host tier) in the last slot
       real = v;
     }
-    const uint32_t *ip = part_indptr[part];
-    const uint32_t b = ip[real], e = ip[real + 1];
+    uint32_t b, e;
+    bounds(part_indptr[part], real, b, e);
     len = e - b;
     return part_indices[part] + b;
   }

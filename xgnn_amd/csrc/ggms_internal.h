@@ -50,7 +50,7 @@ int sample_weighted_hash_dedup_impl(const uint32_t *indptr, const uint32_t *indi
                                     const uint32_t *alias, const uint32_t *input, size_t n_max, Count n,
                                     uint32_t fanout, uint32_t *out_src, uint32_t *out_dst, uint64_t *num_out_dev,
                                     uint32_t *states, uint32_t *workspace, const uint32_t *seed_local, int src_local,
-                                    hipStream_t s, ScanArea *shared_scan = nullptr);
+                                    hipStream_t s, ScanArea *shared_scan = nullptr, const DedupInsert *insert = nullptr);
 
 // hashtable.hip
 size_t ht_ws_words(size_t num_input);

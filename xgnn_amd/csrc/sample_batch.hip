@@ -283,9 +283,12 @@ int ggms_sample_batch(int sample_type, const ggms_graph_t *graph, const ggms_id_
                                 (uint32_t)fanouts[i], col[i], tmp_dst, num_edge, (uint32_t *)states, samp_ws,
                                 first ? seed_local : nullptr, 1, s, &scan, graph->num_node, inserted ? &di : nullptr);
     } else if (sample_type == GGMS_WEIGHTED_KHOP_HASH_DEDUP) {
+      inserted = ht->direct != 0 && e_max != 0; // a seed's picks are entered by its 16 lanes once the seed is done
+      if (inserted) di.tag = next_dedup_tag();
       rc = sample_weighted_hash_dedup_impl(graph->indptr, graph->indices, extra->prob_table, extra->alias_table, input,
                                            n_max, n, (uint32_t)fanouts[i], col[i], tmp_dst, num_edge,
-                                           (uint32_t *)states, samp_ws, first ? seed_local : nullptr, 1, s, &scan);
+                                           (uint32_t *)states, samp_ws, first ? seed_local : nullptr, 1, s, &scan,
+                                           inserted ? &di : nullptr);
     } else if (sample_type == GGMS_WEIGHTED_KHOP) {
       inserted = ht->direct != 0 && e_max != 0;
       if (inserted) di.tag = next_dedup_tag();

@@ -221,8 +221,10 @@ __global__ __launch_bounds__(kWave) void k_weighted_hash_dedup(const uint32_t *_
                                                                 uint32_t fanout, const uint32_t *__restrict__ offset,
                                                                 uint32_t *__restrict__ out_src,
                                                                 uint32_t *__restrict__ out_dst,
-                                                                uint32_t *__restrict__ states, SrcMode sm) {
+                                                                uint32_t *__restrict__ states, SrcMode sm,
+                                                                DedupInsert di) {
   __shared__ uint32_t val[4][kDedupSlots], round_of[4][kDedupSlots]; // one table per group = per stream
+  __shared__ uint32_t picked[4][kDedupSlots];                        // the current seed's accepted picks, in order
   const uint64_t n = n_arg.get();
   const uint32_t lane = threadIdx.x, g = lane >> 4, lig = lane & 15u, grp_shift = lane & ~15u;
   uint32_t *const tv = val[g], *const tr = round_of[g];
@@ -245,8 +247,10 @@ __global__ __launch_bounds__(kWave) void k_weighted_hash_dedup(const uint32_t *_
       const uint32_t sv = sm.value(rid, index);
       if (len <= fanout) {
         for (uint32_t j = lig; j < len; j += 16) {
+          const uint32_t nbr = indices[off + j];
           out_src[o + j] = sv;
-          out_dst[o + j] = indices[off + j];
+          out_dst[o + j] = nbr;
+          if (di.w) di.enter(nbr, o + j); // direct dedup table of the batch: entered where it is produced
         }
         continue;
       }
@@ -320,6 +324,7 @@ __global__ __launch_bounds__(kWave) void k_weighted_hash_dedup(const uint32_t *_
               if (lig == 0) {
                 out_src[o + got] = sv;
                 out_dst[o + got] = c;
+                picked[g][got] = c;
               }
               ++got;
               if (got == fanout) {
@@ -339,6 +344,12 @@ __global__ __launch_bounds__(kWave) void k_weighted_hash_dedup(const uint32_t *_
           tries += 16 * R;
         }
       }
+      // the seed's picks into the batch's dedup table, by all 16 lanes at once (an atomic per accepted pick inside
+      // the serial loop above would put its round trip on the stream's critical path)
+      if (di.w) {
+        __builtin_amdgcn_wave_barrier(); // lane 0's LDS writes above come first: LDS operations of a wave stay in order
+        for (uint32_t j = lig; j < fanout; j += 16) di.enter(picked[g][j], o + j);
+      }
     }
     if (drew && lig == 0) st.store(states + 6 * sid);
     __builtin_amdgcn_wave_barrier(); // the tables are re-initialised by the next pass
@@ -349,7 +360,7 @@ int sample_weighted_hash_dedup_impl(const uint32_t *indptr, const uint32_t *indi
                                     const uint32_t *alias, const uint32_t *input, size_t n_max, Count n,
                                     uint32_t fanout, uint32_t *out_src, uint32_t *out_dst, uint64_t *num_out_dev,
                                     uint32_t *states, uint32_t *workspace, const uint32_t *seed_local, int src_local,
-                                    hipStream_t s, ScanArea *shared_scan) {
+                                    hipStream_t s, ScanArea *shared_scan, const DedupInsert *insert) {
   uint32_t *offset = workspace;
   const ScanArea sa = shared_scan ? *shared_scan : ScanArea{offset + n_max, false};
   int rc = tile_scan(MinDegFanout{indptr, input, fanout}, StoreWord{offset}, n_max, n, sa, nullptr, nullptr,
@@ -358,16 +369,17 @@ int sample_weighted_hash_dedup_impl(const uint32_t *indptr, const uint32_t *indi
   // one wave per workgroup, four streams per wave; up to 8192 waves stay resident (32 per CU)
   const dim3 grid((unsigned)std::min<size_t>(64 * ((n_max + 1023) / 1024), 8192)), block(kWave);
   const SrcMode sm{seed_local, src_local};
+  const DedupInsert di = insert ? *insert : DedupInsert{};
   // tries per round = 16 R: about 1.5 x fanout, so that an ordinary seed is done in one round trip
   if (fanout <= 8)
     hipLaunchKernelGGL(k_weighted_hash_dedup<1>, grid, block, 0, s, indptr, indices, prob, alias, input, n, fanout, offset,
-                       out_src, out_dst, states, sm);
+                       out_src, out_dst, states, sm, di);
   else if (fanout <= 20)
     hipLaunchKernelGGL(k_weighted_hash_dedup<2>, grid, block, 0, s, indptr, indices, prob, alias, input, n, fanout, offset,
-                       out_src, out_dst, states, sm);
+                       out_src, out_dst, states, sm, di);
   else
     hipLaunchKernelGGL(k_weighted_hash_dedup<4>, grid, block, 0, s, indptr, indices, prob, alias, input, n, fanout, offset,
-                       out_src, out_dst, states, sm);
+                       out_src, out_dst, states, sm, di);
   GGMS_LAUNCH_CHECK();
   return GGMS_OK;
 }
@@ -468,7 +480,7 @@ int ggms_sample_weighted_khop_hash_dedup(const ggms_graph_t *graph, const float 
   GGMS_CHECK_ARG((num_input + 1023) / 1024 * 256 <= num_states); // assert(i < num_random_states), hash_dedup.cu:70
   return sample_weighted_hash_dedup_impl(graph->indptr, graph->indices, prob_table, alias_table, input, num_input,
                                          count_of(num_input), (uint32_t)fanout, out_src, out_dst, num_out_dev,
-                                         (uint32_t *)states, (uint32_t *)workspace, nullptr, 0, s);
+                                         (uint32_t *)states, (uint32_t *)workspace, nullptr, 0, s, nullptr, nullptr);
 }
 
 } // extern "C"
