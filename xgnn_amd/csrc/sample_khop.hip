@@ -86,7 +86,7 @@ __global__ __launch_bounds__(128 * (4 / GPW)) void k_khop3_fused(GraphView g, co
                                                                  uint32_t *__restrict__ out_src,
                                                                  uint32_t *__restrict__ out_dst, SrcMode sm,
                                                                  uint32_t *__restrict__ states, uint32_t set_mask,
-                                                                 FusedScan fs, DedupInsert di) {
+                                                                 uint32_t multi, FusedScan fs, DedupInsert di) {
   constexpr uint32_t HASH_EMPTY = 0xffffffffu, NT = 128 * (4 / GPW), FLAG_A = 1, FLAG_P = 2;
   extern __shared__ uint32_t s_pos[];  // [128][fanout]: sampled positions of the tile's seeds
   __shared__ uint32_t set_tab[8][128]; // one open-addressing set per group; set_mask + 1 slots in use
@@ -270,22 +270,55 @@ __global__ __launch_bounds__(128 * (4 / GPW)) void k_khop3_fused(GraphView g, co
     // for a "take them all" seed and the sampler's pick otherwise; written out as (src value, neighbour id)
     const uint32_t prefix = s_prefix;
     const uint32_t slots = 128u * fanout;
-    // (one slot per lane and round: handling four at a time -- loads, then atomics, in flight together -- costs
-    // registers and measured 5 % SLOWER sampling on papers100M when applied everywhere, and as a launch-time choice
-    // for frontiers that fit the chip at once +1.3 % per step on products, nothing on papers100M: not kept)
-    for (uint32_t t = threadIdx.x; t < slots; t += NT) {
+    const auto slot_of = [&](uint32_t t, uint32_t &sd, uint32_t &e, uint32_t &pos) -> bool {
       // s = t / fanout (t < 2^14): mulhi by ceil(2^32 / fanout), one fix-up
-      uint32_t sd = fanout == 1 ? t : __umulhi(t, fanout_magic);
+      sd = fanout == 1 ? t : __umulhi(t, fanout_magic);
       if (sd * fanout > t) --sd;
       const uint32_t j = t - sd * fanout;
       const uint32_t len = s_len[sd];
-      if (j >= min(len, fanout)) continue;
-      const uint32_t e = prefix + s_off[sd] + j;
-      const uint32_t pos = len <= fanout ? j : s_pos[t];
-      const uint32_t nbr = s_ptr[sd][pos];
-      out_src[e] = sm.value(s_rid[sd], 128 * b + sd);
-      out_dst[e] = nbr;
-      if (INSERT) di.enter(nbr, e);
+      if (j >= (len < fanout ? len : fanout)) return false;
+      e = prefix + s_off[sd] + j;
+      pos = len <= fanout ? j : s_pos[t];
+      return true;
+    };
+    if (multi) {
+      // a frontier that fits the chip at once (every workgroup has ONE tile): the sweep runs at latency, so a lane keeps
+      // four slots in flight -- loads together, then the atomics together, then their bookkeeping
+      for (uint32_t t0 = threadIdx.x; t0 < slots; t0 += 4 * NT) {
+        uint32_t sd[4], e[4], pos[4], nbr[4];
+        bool ok[4];
+#pragma unroll
+        for (uint32_t u = 0; u < 4; ++u) {
+          const uint32_t t = t0 + u * NT;
+          ok[u] = t < slots && slot_of(t, sd[u], e[u], pos[u]);
+          nbr[u] = ok[u] ? s_ptr[sd[u]][pos[u]] : 0u;
+        }
+        unsigned long long old[4];
+#pragma unroll
+        for (uint32_t u = 0; u < 4; ++u) {
+          if (ok[u]) {
+            out_src[e[u]] = sm.value(s_rid[sd[u]], 128 * b + sd[u]);
+            out_dst[e[u]] = nbr[u];
+            if (INSERT) old[u] = di.issue(nbr[u], e[u]);
+          }
+        }
+        if (INSERT) {
+#pragma unroll
+          for (uint32_t u = 0; u < 4; ++u)
+            if (ok[u]) di.finish(old[u], e[u]);
+        }
+      }
+    } else {
+      // (one slot per lane and round on the large frontiers: four at a time costs registers and measured 5 % SLOWER
+      // sampling on papers100M when applied everywhere -- those launches are bounded by requests, not by latency)
+      for (uint32_t t = threadIdx.x; t < slots; t += NT) {
+        uint32_t sd, e, pos;
+        if (!slot_of(t, sd, e, pos)) continue;
+        const uint32_t nbr = s_ptr[sd][pos];
+        out_src[e] = sm.value(s_rid[sd], 128 * b + sd);
+        out_dst[e] = nbr;
+        if (INSERT) di.enter(nbr, e);
+      }
     }
     __syncthreads(); // LDS is rewritten by the next tile
   }
@@ -663,7 +696,7 @@ size_t sample_ws_words(size_t num_input) {
 template <int GPW, bool INSERT>
 static int launch_khop3_fused(int grid, size_t lds, hipStream_t s, GraphView g, const uint32_t *input, Count n,
                                uint32_t fanout, uint32_t *out_src, uint32_t *out_dst, SrcMode sm, uint32_t *states,
-                               uint32_t set_mask, FusedScan fs, DedupInsert di) {
+                               uint32_t set_mask, uint32_t multi, FusedScan fs, DedupInsert di) {
   const uint32_t fanout_magic = (uint32_t)((0x100000000ull + fanout - 1) / fanout); // ceil(2^32 / fanout)
   if (lds > (48u << 10)) { // large fan-outs: more dynamic LDS than the default per-kernel limit (gfx950 has 160 KB)
     static const int raised = raise_dynamic_lds(reinterpret_cast<const void *>(&k_khop3_fused<GPW, INSERT>), 128 * 127 * 4,
@@ -671,7 +704,7 @@ static int launch_khop3_fused(int grid, size_t lds, hipStream_t s, GraphView g, 
     if (raised != GGMS_OK) return raised;
   }
   hipLaunchKernelGGL((k_khop3_fused<GPW, INSERT>), dim3(grid), dim3(128 * (4 / GPW)), lds, s, g, input, n, fanout,
-                     fanout_magic, out_src, out_dst, sm, states, set_mask, fs, di);
+                     fanout_magic, out_src, out_dst, sm, states, set_mask, multi, fs, di);
   return GGMS_OK;
 }
 
@@ -701,17 +734,20 @@ int sample_khop3_impl(GraphView g, const uint32_t *input, size_t n_max, Count n,
   const uint32_t set_mask = fanout < 32 ? 63u : 127u;
   const int gpw = khop3_groups_per_wave(tiles);
   const int grid = grid_for(tiles, 1);
+  // every workgroup has at most one tile: the sweep keeps four slots per lane in flight (GGMS_KHOP3_MULTI=0/1 pins it)
+  static const int pin_multi = [] { const char *e = getenv("GGMS_KHOP3_MULTI"); return e ? atoi(e) : -1; }();
+  const uint32_t multi = pin_multi >= 0 ? (uint32_t)(pin_multi != 0) : (tiles <= grid_cap() ? 1u : 0u);
   const size_t lds = 128 * (size_t)fanout * sizeof(uint32_t);
   const DedupInsert none{};
   int rc_l = GGMS_OK;
   if (insert) {
-    if (gpw == 1) rc_l = launch_khop3_fused<1, true>(grid, lds, s, g, input, n, fanout, out_src, out_dst, sm, states, set_mask, fs, *insert);
-    else if (gpw == 2) rc_l = launch_khop3_fused<2, true>(grid, lds, s, g, input, n, fanout, out_src, out_dst, sm, states, set_mask, fs, *insert);
-    else rc_l = launch_khop3_fused<4, true>(grid, lds, s, g, input, n, fanout, out_src, out_dst, sm, states, set_mask, fs, *insert);
+    if (gpw == 1) rc_l = launch_khop3_fused<1, true>(grid, lds, s, g, input, n, fanout, out_src, out_dst, sm, states, set_mask, multi, fs, *insert);
+    else if (gpw == 2) rc_l = launch_khop3_fused<2, true>(grid, lds, s, g, input, n, fanout, out_src, out_dst, sm, states, set_mask, multi, fs, *insert);
+    else rc_l = launch_khop3_fused<4, true>(grid, lds, s, g, input, n, fanout, out_src, out_dst, sm, states, set_mask, multi, fs, *insert);
   } else {
-    if (gpw == 1) rc_l = launch_khop3_fused<1, false>(grid, lds, s, g, input, n, fanout, out_src, out_dst, sm, states, set_mask, fs, none);
-    else if (gpw == 2) rc_l = launch_khop3_fused<2, false>(grid, lds, s, g, input, n, fanout, out_src, out_dst, sm, states, set_mask, fs, none);
-    else rc_l = launch_khop3_fused<4, false>(grid, lds, s, g, input, n, fanout, out_src, out_dst, sm, states, set_mask, fs, none);
+    if (gpw == 1) rc_l = launch_khop3_fused<1, false>(grid, lds, s, g, input, n, fanout, out_src, out_dst, sm, states, set_mask, multi, fs, none);
+    else if (gpw == 2) rc_l = launch_khop3_fused<2, false>(grid, lds, s, g, input, n, fanout, out_src, out_dst, sm, states, set_mask, multi, fs, none);
+    else rc_l = launch_khop3_fused<4, false>(grid, lds, s, g, input, n, fanout, out_src, out_dst, sm, states, set_mask, multi, fs, none);
   }
   if (rc_l != GGMS_OK) return rc_l;
   GGMS_LAUNCH_CHECK();

@@ -145,10 +145,17 @@ __global__ __launch_bounds__(kBlock) void k_tile_scan(ValueF value, EmitF emit, 
   const uint64_t n = n_arg.get();
   const uint64_t num_tiles = (n + kTile - 1) / kTile;
   const uint32_t base = base_in ? *base_in : 0u; // read before anybody can overwrite it (total32_out may alias)
-  for (;;) {
-    if (threadIdx.x == 0) s_tile = atomicAdd(&ctl[0], 1u);
-    __syncthreads();
-    const uint64_t tile = s_tile;
+  // Up to kSinglePassTiles workgroups (the default use of this kernel) take tile = workgroup id: a ticket and an exit
+  // count from one word are 2 x 256 same-address atomics, 11 ns each (tools/micro_ticket.hip) -- most of an 8-us launch.
+  // That many workgroups are resident together and are dispatched in id order, so a tile's predecessors are running;
+  // the bounded look-back turns anything else into the status word.  Larger grids (GGMS_SCAN=1) keep the ticket.
+  const bool ticketed = gridDim.x > kSinglePassTiles;
+  for (uint64_t round = 0;; ++round) {
+    if (ticketed) {
+      if (threadIdx.x == 0) s_tile = atomicAdd(&ctl[0], 1u);
+      __syncthreads();
+    }
+    const uint64_t tile = ticketed ? (uint64_t)s_tile : (uint64_t)blockIdx.x + round * gridDim.x;
     if (tile >= num_tiles) break;
     uint32_t v[ROUNDS], excl[ROUNDS];
     uint32_t running = 0;
@@ -203,7 +210,7 @@ __global__ __launch_bounds__(kBlock) void k_tile_scan(ValueF value, EmitF emit, 
       if (mirror_b) *mirror_b = (uint64_t)base;
     }
     // the last block out re-arms the control words for the next launch on this scratch
-    if (atomicAdd(&ctl[1], 1u) == gridDim.x - 1) {
+    if (ticketed && atomicAdd(&ctl[1], 1u) == gridDim.x - 1) {
       ctl[0] = 0;
       ctl[1] = 0;
     }
