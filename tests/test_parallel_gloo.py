@@ -3,6 +3,7 @@ import os
 import socket
 
 import numpy as np
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -142,8 +143,9 @@ def _hybrid_worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_two_rank_hybrid_store_tier_map():
-    world = 2
+@pytest.mark.parametrize("world", [2, 8])
+def test_hybrid_store_tier_map(world):
+    """replica + 2-way and 8-way shards + host rows behind one gather: the tier map and its counters"""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
@@ -154,7 +156,7 @@ def test_two_rank_hybrid_store_tier_map():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    assert res == [(0, True), (1, True)]
+    assert res == [(r, True) for r in range(world)]
 
 
 def _shard_worker(rank, world, port, q):
@@ -177,9 +179,9 @@ def _shard_worker(rank, world, port, q):
         store.extract(nodes, nodes.numel(), out)
         ok = ok and torch.equal(out[:nodes.numel()], feat[nodes.long()]) and bool((out[nodes.numel():] == 0).all())
     # a batch whose rows all live on ONE owner (empty buckets elsewhere), and an empty batch
-    only0 = rank_list[0:num_cached:world][:40].to(torch.int32)
-    out = torch.zeros(40, dim)
-    store.extract(only0, 40, out)
+    only0 = rank_list[0:num_cached:world][:min(40, (num_cached + world - 1) // world)].to(torch.int32)
+    out = torch.zeros(only0.numel(), dim)
+    store.extract(only0, only0.numel(), out)
     ok = ok and torch.equal(out, feat[only0.long()])
     store.extract(only0[:0], 0, torch.zeros(1, dim))
     dist.barrier()
@@ -187,8 +189,10 @@ def _shard_worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_two_rank_feature_shards_all_to_all():
-    world = 2
+@pytest.mark.parametrize("world", [2, 8])
+def test_feature_shards_all_to_all(world):
+    """The exchange form on 2 and on EIGHT CPU ranks (the node size north_star names): 8-way owner buckets laid out
+    [ranks ascending without me | me | host], split sizes with a zero for the own bucket, ids out / rows back."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
@@ -199,7 +203,7 @@ def test_two_rank_feature_shards_all_to_all():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    assert res == [(0, True), (1, True)]
+    assert res == [(r, True) for r in range(world)]
 
 
 def test_plan_replication_fills_the_budget():
