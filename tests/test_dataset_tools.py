@@ -94,3 +94,24 @@ def test_cpu_hashtable2_openmp_port(threads):
         prev = u
     ht.reset()
     assert ht.fill_with_duplicates(fills[0]) == np.unique(fills[0]).size
+
+
+def test_graph_generator_is_thread_independent_and_skew_is_degree_proportional():
+    """make_graph fills its edge chunks on a thread pool: the result must not depend on the number of threads (every
+    chunk has its own seed), the default (uniform neighbour ids) must not change when the skewed variant
+    is added, and neighbour_skew = 1 must draw neighbours in proportion to their degree."""
+    from xgnn_amd import datagen
+    preset = dict(num_node=60_000, mean_deg=20.0, alpha=0.75, dmax=3_000, feat_dim=4, num_class=3, num_train=100)
+    a = datagen.make_graph(preset, seed=42, chunk=1 << 16, threads=1)
+    b = datagen.make_graph(preset, seed=42, chunk=1 << 16, threads=4)
+    assert np.array_equal(a["indices"], b["indices"]) and np.array_equal(a["indptr"], b["indptr"])
+    s1 = datagen.make_graph(preset, seed=42, chunk=1 << 16, threads=1, neighbour_skew=1.0)
+    s4 = datagen.make_graph(preset, seed=42, chunk=1 << 16, threads=4, neighbour_skew=1.0)
+    assert np.array_equal(s1["indices"], s4["indices"]) and np.array_equal(s1["indptr"], a["indptr"])
+    deg = np.diff(a["indptr"].astype(np.int64))
+    hits_uniform = np.bincount(a["indices"], minlength=deg.size)
+    hits_skewed = np.bincount(s1["indices"], minlength=deg.size)
+    assert np.corrcoef(hits_skewed, deg)[0, 1] > 0.95 and abs(np.corrcoef(hits_uniform, deg)[0, 1]) < 0.05
+    half = datagen.make_graph(preset, seed=42, chunk=1 << 16, neighbour_skew=0.5)
+    changed = (half["indices"] != a["indices"]).mean()
+    assert 0.4 < changed < 0.6  # every neighbour is a degree-proportional pick with probability p, else the uniform one
