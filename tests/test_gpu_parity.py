@@ -550,6 +550,60 @@ def test_partition_cache_paths(ops, P, dim):
     assert int(nmiss.item()) == wms.size
 
 
+def test_tier_counters_over_many_tiles_per_workgroup(ops):
+    """The gather counts rows per tier in registers per wave, combines them per workgroup in LDS and adds to the
+    caller's counters once per workgroup: with 300 K rows on a 256-workgroup grid every wave sweeps several tiles.
+    Counters are ADDED to (two calls = twice the rows); the rows themselves equal the table's."""
+    N, dim, n, P, me, R = 50_000, 32, 300_000, 4, 1, 6_000
+    rng = np.random.RandomState(3)
+    feat = exact_features(N, dim, np.float32)
+    rank = rng.permutation(N).astype(np.int64)
+    num_cached = 30_000
+    table = np.full(N, -1, np.int32)
+    table[rank[:num_cached]] = np.arange(num_cached, dtype=np.int32)
+    replica = dev(feat[rank[:R]])
+    parts = [dev(feat[rank[R + p:num_cached:P]]) for p in range(P)]
+    ptab = ops.part_pointer_table(parts, "cuda")
+    nodes = rng.randint(0, N, n).astype(np.uint32)
+    out = torch.zeros((n, dim), dtype=torch.float32, device="cuda")
+    counters = torch.zeros(4, dtype=torch.int64, device="cuda")
+    t_feat, t_table, t_nodes = dev(feat), dev(table), dev(nodes)
+    for _ in range(2):
+        ops.extract_tiered(out, t_nodes, t_table, replica, ptab, P, me, t_feat, tier_rows=counters)
+    assert out.cpu().numpy().tobytes() == feat[nodes].tobytes()
+    slots = table[nodes]
+    shard = (slots - R) % P
+    want = [int((slots < 0).sum()), int(((slots >= R) & (shard != me)).sum()), int(((slots >= R) & (shard == me)).sum()),
+            int(((slots >= 0) & (slots < R)).sum())]
+    assert counters.cpu().tolist() == [2 * w for w in want] and sum(want) == n
+    # the plain cached gather's miss counter takes the same route
+    nmiss = torch.zeros(1, dtype=torch.int64, device="cuda")
+    full = dev(feat[rank[:num_cached]])
+    ops.extract_cached(out, t_nodes, t_table, ops.part_pointer_table([full], "cuda"), 0, t_feat, num_miss=nmiss)
+    assert int(nmiss.item()) == want[0] and out.cpu().numpy().tobytes() == feat[nodes].tobytes()
+
+
+def test_fabric_probe_runs_and_updates_the_table(ops):
+    """ggms_fabric_probe (bench.py's memory-side ceilings): the three request kinds launch, the atomics are real
+    updates (a decreasing salt lowers the words), loads leave the table alone."""
+    import ctypes as C
+    from xgnn_amd import lib
+    words, reqs = 1 << 20, 200_000
+    tab = torch.full((words,), -1, dtype=torch.int64, device="cuda")
+    sink = torch.zeros(1, dtype=torch.int32, device="cuda")
+    s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    assert lib().ggms_fabric_probe(1, C.c_void_p(tab.data_ptr()), words, reqs, 0x7fffff00, C.c_void_p(sink.data_ptr()), s) == 0
+    assert bool((tab == -1).all())
+    assert lib().ggms_fabric_probe(0, C.c_void_p(tab.data_ptr()), words, reqs, 0x7fffff00, C.c_void_p(sink.data_ptr()), s) == 0
+    touched = int((tab != -1).sum().item())
+    assert 0.8 * reqs < touched <= reqs  # random keys: a few collisions
+    before = tab.cpu().numpy().view(np.uint64).copy()
+    assert lib().ggms_fabric_probe(2, C.c_void_p(tab.data_ptr()), words, reqs, 0x7ffffeff, C.c_void_p(sink.data_ptr()), s) == 0
+    after = tab.cpu().numpy().view(np.uint64)
+    assert (after <= before).all() and (after < before).any()
+    assert lib().ggms_fabric_probe(7, C.c_void_p(tab.data_ptr()), words, reqs, 1, C.c_void_p(sink.data_ptr()), s) != 0  # unknown kind
+
+
 # ------------------------------------------- per-list limits and long lists
 @pytest.mark.parametrize("sampler,fanout", [("khop3", 127), ("khop3", 100), ("khop0", 2048), ("khop0", 100), ("khop0", 4000),
                                             ("khop0", 7), ("khop2", 300), ("khop1", 40)])
