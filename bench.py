@@ -213,11 +213,13 @@ def launch_ranks(args):
     sys.exit(rc)
 
 
-def engine_record(datagen, graph, fanouts, args, log):
+def engine_record(datagen, graph, fanouts, args, log, workers=0, force_device=None):
     """The same workload through the operator surface north_star names (samgraph.torch: config / init / sample_once /
     get_next_batch) in a CHILD process: the graph is written in the reference's on-disk format without feat.bin /
     label.bin (the loader then maps zero-filled tables, engine.cc:199-235 -- topology and sizes are the real ones), one
-    warm-up epoch, one reported epoch; rates from the reference's own log items (tools/engine_epoch.py)."""
+    warm-up epoch, one reported epoch; rates from the reference's own log items (tools/engine_epoch.py).
+    workers > 0: the multi-GPU deployment (arch6) -- the child forks one engine worker per GPU, feature shards across
+    the workers' GPUs behind hipIpc (part_cache + gpu_extract), every worker samples its slice of the epoch."""
     import shutil
     import subprocess
     import tempfile
@@ -226,10 +228,17 @@ def engine_record(datagen, graph, fanouts, args, log):
         t0 = time.perf_counter()
         datagen.write_dataset(d, graph, minimal=True)
         log(f"engine: dataset written in {time.perf_counter() - t0:.1f} s")
+        env = dict(os.environ)
+        env.setdefault("SAMGRAPH_IPC_TIMEOUT_S", "90")  # a worker that cannot reach its peers ends the child, not the bench
+        for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):  # the child is not a rank of this job
+            env.pop(k, None)
+        if force_device is not None:  # one-GPU rehearsal: every engine worker on that device
+            env["SAMGRAPH_FORCE_DEVICE"] = str(force_device)
         r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "engine_epoch.py"), d, "--fanout"]
                            + [str(f) for f in fanouts]
-                           + ["--batch-size", str(args.batch), "--sample-type", args.sample_type, "--cache-percentage", "1.0"],
-                           capture_output=True, text=True, timeout=args.engine_timeout)
+                           + ["--batch-size", str(args.batch), "--sample-type", args.sample_type, "--cache-percentage", "1.0"]
+                           + (["--arch6", str(workers)] if workers else []),
+                           capture_output=True, text=True, timeout=args.engine_timeout, env=env)
         lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
         if r.returncode != 0 or not lines:
             return {"error": f"engine child rc {r.returncode}: {r.stderr[-300:]}"}
@@ -237,7 +246,11 @@ def engine_record(datagen, graph, fanouts, args, log):
         e["surface"] = ("samgraph.torch config / init / sample_once / get_next_batch (arch1, cache_percentage 1.0) on the "
                         "same graph written to disk in the reference's format, zero-filled feature table; second epoch; "
                         "sample_edges_per_s and feature_GBps from kLogEpochNumSample / kLogEpochSampleTime and "
-                        "kLogEpochFeatureBytes / kLogEpochCopyTime")
+                        "kLogEpochFeatureBytes / kLogEpochCopyTime" if not workers else
+                        f"samgraph.torch arch6: data_init in the parent, {workers} forked workers (sample_init / train_init / "
+                        "sample_once / get_next_batch), feature table sharded over the workers' GPUs (part_cache, gpu_extract, "
+                        "hipIpc peers), whole CSR on every GPU; second epoch, the slowest worker's wall time; rates summed "
+                        "over the workers from the reference's log items")
         return e
     except subprocess.TimeoutExpired:
         return {"error": f"engine child exceeded {args.engine_timeout} s"}
@@ -661,10 +674,16 @@ def main():
             except (RuntimeError, MemoryError) as e:
                 stores[kind] = {"error": f"{type(e).__name__}: {str(e)[:200]}"}
 
-    # ---- N = 1: the same workload through the samgraph.torch surface (child process) --------------------------------
+    # ---- the same workload through the samgraph.torch surface (child process): arch1 at N = 1, arch6 with N workers ----
     engine = None
-    if world == 1 and full and not args.no_engine and args.sample_type.startswith("khop"):
-        engine = engine_record(datagen, graph, fanouts, args, log)
+    if full and not args.no_engine and args.sample_type.startswith("khop"):
+        if world == 1:
+            engine = engine_record(datagen, graph, fanouts, args, log)
+        else:  # rank 0 runs the child (which forks one engine worker per GPU), the other ranks wait
+            if rank == 0:
+                engine = engine_record(datagen, graph, fanouts, args, log, workers=world,
+                                       force_device=os.environ.get("GGMS_BENCH_DEVICE"))
+            barrier()
         log("engine sub-record done")
 
     # ---- N = 1: BASELINE configs[2], every row in pinned host DRAM (cache_ratio 0) -----------------------------

@@ -76,6 +76,10 @@ def test_gpus_flag_alone_starts_the_ranks():
     assert r.returncode == 0, r.stderr[-3000:]
     d = _last_json(r.stdout)
     assert KEYS <= set(d) and d["n_gpus"] == 2 and d["config"]["parallelism"] == "dp2" and d["rows_verified"]
+    # N > 1: the engine sub-record is the multi-GPU deployment -- a child process that forks one arch6 worker per GPU
+    en = d["engine"]
+    assert "error" not in en, en
+    assert en["arch"] == "arch6" and en["workers"] == 2 and en["edges_per_s"] > 0 and en["feature_GBps"] > 0
 
 
 def test_five_ranks_one_gpu_peer_and_hybrid():
@@ -85,7 +89,7 @@ def test_five_ranks_one_gpu_peer_and_hybrid():
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
     env.update(GGMS_BENCH_DEVICE="0", GGMS_BENCH_BACKEND="gloo")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "5", "--preset", "tiny", "--steps", "3",
-                        "--warmup", "1", "--batch", "128", "--repeats", "1", "--other-stores", "hybrid"],
+                        "--warmup", "1", "--batch", "128", "--repeats", "1", "--other-stores", "hybrid", "--no-engine"],
                        capture_output=True, text=True, timeout=1200, cwd=ROOT, env=env)
     assert r.returncode == 0, r.stderr[-3000:]
     d = _last_json(r.stdout)

@@ -26,7 +26,13 @@ def main():
     ap.add_argument("--cache-percentage", type=float, default=1.0)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--pipelined", action="store_true", help="extract_start(0): the background thread samples ahead")
+    ap.add_argument("--arch6", type=int, default=0, metavar="WORKERS",
+                    help="the multi-GPU deployment instead of arch1: config + data_init here, one forked worker per GPU "
+                         "(sample_init / train_init on cuda:<worker>), feature shards across the workers' GPUs "
+                         "(part_cache + gpu_extract), every worker samples its slice of the epoch")
     a = ap.parse_args()
+    if a.arch6:
+        return main_arch6(a)
     import samgraph.torch as sam
     cfg = {"dataset_path": a.dataset, "_arch": sam.builtin_archs["arch1"]["arch"], "_sample_type": sam.sample_types[a.sample_type],
            "batch_size": a.batch_size, "num_epoch": a.num_epoch, "_cache_policy": sam.cache_policies["degree"],
@@ -55,6 +61,67 @@ def main():
                "feature_GBps": fb / tc / 1e9 if tc else None, "feature_bytes": fb,
                "log_items": {"kLogEpochSampleTime": ts, "kLogEpochCopyTime": tc}, "init_s": t_init}
     sam.shutdown()
+    print(json.dumps(out), flush=True)
+
+
+def main_arch6(a):
+    """example/samgraph/sgnn/train_graphsage.py:106-108,136-155,397-412: the parent configures and loads the dataset
+    (no GPU), forks one worker per GPU, every worker initialises its sampler + partitioned cache and runs the epochs
+    over its slice of the shuffled train set.  Workers meet at the engine's barrier before every epoch, so the epoch's
+    wall time is the slowest worker's."""
+    import tempfile
+    import samgraph.torch as sam
+    W = a.arch6
+    cfg = {"dataset_path": a.dataset, "_arch": sam.builtin_archs["arch6"]["arch"], "_sample_type": sam.sample_types[a.sample_type],
+           "batch_size": a.batch_size, "num_epoch": a.num_epoch, "_cache_policy": sam.cache_policies["degree"],
+           "cache_percentage": a.cache_percentage, "max_sampling_jobs": 10, "max_copying_jobs": 1, "omp_thread_num": 40,
+           "num_layer": len(a.fanout), "num_hidden": 256, "lr": 0.003, "dropout": 0.5, "num_fanout": len(a.fanout),
+           "fanout": a.fanout, "num_worker": W, "part_cache": "True", "gpu_extract": "True", "seed": a.seed}
+    sam.config(cfg)
+    sam.data_init()  # host only: the GPUs are first touched in the workers
+    out_dir = tempfile.mkdtemp(prefix="ggms_engine_")
+    pids = []
+    for w in range(W):
+        pid = os.fork()
+        if pid == 0:
+            code = 1
+            try:
+                t0 = time.perf_counter()
+                sam.sample_init(w, f"cuda:{w}")
+                sam.train_init(w, f"cuda:{w}")
+                t_init = time.perf_counter() - t0
+                steps = sam.num_local_step()
+                rec = None
+                for e in range(sam.num_epoch()):
+                    sam.forward_barrier()
+                    t0 = time.perf_counter()
+                    for _ in range(steps):
+                        sam.sample_once()
+                        sam.get_next_batch()
+                    wall = time.perf_counter() - t0
+                    rec = {"steps": steps, "wall_s": wall, "init_s": t_init,
+                           "edges": sam.get_log_epoch_value(e, sam.kLogEpochNumSample),
+                           "sample_s": sam.get_log_epoch_value(e, sam.kLogEpochSampleTime),
+                           "copy_s": sam.get_log_epoch_value(e, sam.kLogEpochCopyTime),
+                           "feature_bytes": sam.get_log_epoch_value(e, sam.kLogEpochFeatureBytes)}
+                json.dump(rec, open(os.path.join(out_dir, f"w{w}.json"), "w"))
+                sam.shutdown()
+                code = 0
+            except BaseException as ex:  # noqa: BLE001
+                print("worker", w, "failed:", repr(ex), file=sys.stderr, flush=True)
+            os._exit(code)
+        pids.append(pid)
+    bad = sum(sam.wait_one_child() for _ in pids)
+    if bad:
+        sys.exit(1)
+    recs = [json.load(open(os.path.join(out_dir, f"w{w}.json"))) for w in range(W)]
+    wall = max(r["wall_s"] for r in recs)
+    edges = sum(r["edges"] for r in recs)
+    out = {"arch": "arch6", "workers": W, "steps": recs[0]["steps"], "wall_s": wall, "ms_per_step": wall / recs[0]["steps"] * 1e3,
+           "edges": edges, "edges_per_s": edges / wall,
+           "sample_edges_per_s": sum(r["edges"] / r["sample_s"] for r in recs if r["sample_s"]),
+           "feature_GBps": sum(r["feature_bytes"] / r["copy_s"] / 1e9 for r in recs if r["copy_s"]),
+           "feature_bytes": sum(r["feature_bytes"] for r in recs), "init_s": max(r["init_s"] for r in recs)}
     print(json.dumps(out), flush=True)
 
 
