@@ -200,10 +200,10 @@ int sample_weighted_impl(const uint32_t *indptr, const uint32_t *indices, const 
 // The stream <-> seed map and the order of a stream's draws are the reference's; how the draws are RESOLVED is not.
 // A try consumes exactly two draws whatever its outcome, so the stream's next tries are known in advance.  One lane
 // per stream (round 2) had the slowest list of the launch set its time: a 26-neighbour list asked for 25 distinct
-// picks takes a couple of thousand tries, eight per memory round trip -- 885 us per products step.  Now the 16 lanes
-// of a group serve ONE stream: every lane steps the generator through the round's 16 R tries (9 ALU ops per draw) and
-// keeps tries lig, lig + 16, ...; the 3 x 16 R loads (neighbour, acceptance probability, alias) of the round are in
-// flight together; a read-only probe of the table then drops the tries whose candidate is already there (most of
+// picks takes hundreds of tries, eight per memory round trip -- 885 us per products step.  Now the G lanes of a group
+// serve ONE stream: every lane steps the generator through the round's G R tries (9 ALU ops per draw) and keeps tries
+// lig, lig + G, ...; the 3 x G R loads (neighbour, acceptance probability, alias) of the round are in flight
+// together; a read-only probe of the table then drops the tries whose candidate is already there (most of
 // them, in a long rejection run -- a present entry stays present, entries are only ever added), and the rest go
 // through the reference's insert one after the other in try order, so that accepted picks, their order and the
 // table's layout are exactly the sequential ones.  If the seed completes at try t*, the generator is put back to just
@@ -212,7 +212,7 @@ constexpr uint32_t kDedupSlots = 50;       // hash_dedup.cu:42
 constexpr uint32_t kDedupMaxTries = 65536; // the reference spins forever on a list without `fanout` distinct ids
 constexpr uint32_t kDedupMaxProbes = 64;   // ... and on a full table (a seed id met twice by one stream, fanout >= 25)
 
-template <uint32_t R> // tries per lane and round
+template <uint32_t G, uint32_t R> // lanes per stream (a power of two <= 16), tries per lane and round
 __global__ __launch_bounds__(kWave) void k_weighted_hash_dedup(const uint32_t *__restrict__ indptr,
                                                                 const uint32_t *__restrict__ indices,
                                                                 const float *__restrict__ prob,
@@ -223,16 +223,18 @@ __global__ __launch_bounds__(kWave) void k_weighted_hash_dedup(const uint32_t *_
                                                                 uint32_t *__restrict__ out_dst,
                                                                 uint32_t *__restrict__ states, SrcMode sm,
                                                                 DedupInsert di) {
-  __shared__ uint32_t val[4][kDedupSlots], round_of[4][kDedupSlots]; // one table per group = per stream
-  __shared__ uint32_t picked[4][kDedupSlots];                        // the current seed's accepted picks, in order
+  constexpr uint32_t SPW = kWave / G; // streams per wave
+  __shared__ uint32_t val[SPW][kDedupSlots], round_of[SPW][kDedupSlots]; // one table per group = per stream
+  __shared__ uint32_t picked[SPW][kDedupSlots];                          // the current seed's accepted picks, in order
   const uint64_t n = n_arg.get();
-  const uint32_t lane = threadIdx.x, g = lane >> 4, lig = lane & 15u, grp_shift = lane & ~15u;
+  const uint32_t lane = threadIdx.x, g = lane / G, lig = lane % G, grp_shift = lane & ~(G - 1u);
+  constexpr uint32_t GMASK = (1u << G) - 1u, WPB = kBlock / SPW; // waves per reference block of 256 streams
   uint32_t *const tv = val[g], *const tr = round_of[g];
   const uint64_t num_tiles = (n + 1023) / 1024;
-  for (uint64_t q = blockIdx.x; q < 64 * num_tiles; q += gridDim.x) { // 64 waves x 4 streams = one reference block
-    const uint64_t b = q >> 6;                      // reference block
-    const uint32_t tb = (uint32_t)(q & 63u) * 4u + g; // thread of that block = the stream this group serves
-    for (uint32_t z = lig; z < kDedupSlots; z += 16) { tv[z] = kEmptyKey; tr[z] = kEmptyKey; } // :72-76
+  for (uint64_t q = blockIdx.x; q < WPB * num_tiles; q += gridDim.x) { // WPB waves x SPW streams = one reference block
+    const uint64_t b = q / WPB;                            // reference block
+    const uint32_t tb = (uint32_t)(q % WPB) * SPW + g;     // thread of that block = the stream this group serves
+    for (uint32_t z = lig; z < kDedupSlots; z += G) { tv[z] = kEmptyKey; tr[z] = kEmptyKey; } // :72-76
     __builtin_amdgcn_wave_barrier();
     const uint64_t sid = b * kBlock + tb;
     Xorwow st;
@@ -246,7 +248,7 @@ __global__ __launch_bounds__(kWave) void k_weighted_hash_dedup(const uint32_t *_
       const uint32_t o = offset[index];
       const uint32_t sv = sm.value(rid, index);
       if (len <= fanout) {
-        for (uint32_t j = lig; j < len; j += 16) {
+        for (uint32_t j = lig; j < len; j += G) {
           const uint32_t nbr = indices[off + j];
           out_src[o + j] = sv;
           out_dst[o + j] = nbr;
@@ -262,7 +264,7 @@ __global__ __launch_bounds__(kWave) void k_weighted_hash_dedup(const uint32_t *_
 #pragma unroll
         for (uint32_t i = 0; i < R; ++i) {
 #pragma unroll
-          for (uint32_t l = 0; l < 16; ++l) { // try 16 i + l of the round: position draw, then acceptance draw
+          for (uint32_t l = 0; l < G; ++l) { // try G i + l of the round: position draw, then acceptance draw
             const uint32_t a = st.next(), u = st.next();
             kraw[i] = (l == lig) ? a : kraw[i];
             uraw[i] = (l == lig) ? u : uraw[i];
@@ -297,17 +299,17 @@ __global__ __launch_bounds__(kWave) void k_weighted_hash_dedup(const uint32_t *_
           need[i] = !present;
         }
         // the others, in try order, through insert_hash_table (:41-57) as the reference runs it
-        const bool all_serial = tries + 16 * R > kDedupMaxTries; // the give-up rule looks at every try: no shortcut
-        uint32_t used = 16 * R;
+        const bool all_serial = tries + G * R > kDedupMaxTries; // the give-up rule looks at every try: no shortcut
+        uint32_t used = G * R;
         bool done = false;
 #pragma unroll
         for (uint32_t i = 0; i < R; ++i) {
-          uint32_t m = done ? 0u : (uint32_t)(__ballot(need[i] || all_serial) >> grp_shift) & 0xffffu;
+          uint32_t m = done ? 0u : (uint32_t)(__ballot(need[i] || all_serial) >> grp_shift) & GMASK;
           while (m != 0) {
             const uint32_t t = (uint32_t)__ffs(m) - 1u;
             m &= m - 1u;
             const uint32_t c = __shfl(cand[i], (int)(grp_shift + t), 64);
-            const bool give_up = tries + 16 * i + t + 1 > kDedupMaxTries;
+            const bool give_up = tries + G * i + t + 1 > kDedupMaxTries;
             uint32_t pos = c % kDedupSlots, gap = 1;
             bool is_new = true; // a probe sequence that finds neither a free slot nor the value takes the candidate
             for (uint32_t probe = 0; probe < kDedupMaxProbes; ++probe) {
@@ -328,7 +330,7 @@ __global__ __launch_bounds__(kWave) void k_weighted_hash_dedup(const uint32_t *_
               }
               ++got;
               if (got == fanout) {
-                used = 16 * i + t + 1;
+                used = G * i + t + 1;
                 done = true;
                 m = 0;
               }
@@ -336,19 +338,19 @@ __global__ __launch_bounds__(kWave) void k_weighted_hash_dedup(const uint32_t *_
           }
         }
         if (done) {
-          if (used < 16 * R) { // two draws per try actually made
+          if (used < G * R) { // two draws per try actually made
             st = st0;
             for (uint32_t d = 0; d < 2 * used; ++d) (void)st.next();
           }
         } else {
-          tries += 16 * R;
+          tries += G * R;
         }
       }
       // the seed's picks into the batch's dedup table, by all 16 lanes at once (an atomic per accepted pick inside
       // the serial loop above would put its round trip on the stream's critical path)
       if (di.w) {
         __builtin_amdgcn_wave_barrier(); // lane 0's LDS writes above come first: LDS operations of a wave stay in order
-        for (uint32_t j = lig; j < fanout; j += 16) di.enter(picked[g][j], o + j);
+        for (uint32_t j = lig; j < fanout; j += G) di.enter(picked[g][j], o + j);
       }
     }
     if (drew && lig == 0) st.store(states + 6 * sid);
@@ -366,20 +368,30 @@ int sample_weighted_hash_dedup_impl(const uint32_t *indptr, const uint32_t *indi
   int rc = tile_scan(MinDegFanout{indptr, input, fanout}, StoreWord{offset}, n_max, n, sa, nullptr, nullptr,
                      num_out_dev, s);
   if (rc != GGMS_OK) return rc;
-  // one wave per workgroup, four streams per wave; up to 8192 waves stay resident (32 per CU)
-  const dim3 grid((unsigned)std::min<size_t>(64 * ((n_max + 1023) / 1024), 8192)), block(kWave);
   const SrcMode sm{seed_local, src_local};
   const DedupInsert di = insert ? *insert : DedupInsert{};
-  // tries per round = 16 R: about 1.5 x fanout, so that an ordinary seed is done in one round trip
-  if (fanout <= 8)
-    hipLaunchKernelGGL(k_weighted_hash_dedup<1>, grid, block, 0, s, indptr, indices, prob, alias, input, n, fanout, offset,
-                       out_src, out_dst, states, sm, di);
-  else if (fanout <= 20)
-    hipLaunchKernelGGL(k_weighted_hash_dedup<2>, grid, block, 0, s, indptr, indices, prob, alias, input, n, fanout, offset,
-                       out_src, out_dst, states, sm, di);
-  else
-    hipLaunchKernelGGL(k_weighted_hash_dedup<4>, grid, block, 0, s, indptr, indices, prob, alias, input, n, fanout, offset,
-                       out_src, out_dst, states, sm, di);
+  const size_t blocks = (n_max + 1023) / 1024; // reference blocks of 256 streams
+  // Tries per round = G R: about 1.5 x fanout, so that an ordinary seed is done in one round trip.  G = lanes that
+  // share a stream: 16.  Four lanes per stream with 16 tries each (a quarter of the generator instructions per
+  // stream) were built and measured SLOWER on the large products layer (kernel 350 -> 440 us): a wave then waits for
+  // the slowest of 16 streams instead of 4, and the try-order loop runs 16 rounds of 4-lane ballots.
+  // GGMS_HASH_DEDUP_G=4 selects that variant (measurement hook; same results).
+  static const int pin_g = [] { const char *e = getenv("GGMS_HASH_DEDUP_G"); return e ? atoi(e) : 0; }();
+  const bool narrow = pin_g == 4;
+#define GGMS_HD(GG, RR)                                                                                              \
+  hipLaunchKernelGGL((k_weighted_hash_dedup<GG, RR>), dim3((unsigned)std::min<size_t>((256 / (64 / GG)) * blocks, 8192)), \
+                     dim3(kWave), 0, s, indptr, indices, prob, alias, input, n, fanout, offset, out_src, out_dst, states, \
+                     sm, di)
+  if (narrow) {
+    if (fanout <= 8) GGMS_HD(4, 4);
+    else if (fanout <= 20) GGMS_HD(4, 8);
+    else GGMS_HD(4, 16);
+  } else {
+    if (fanout <= 8) GGMS_HD(16, 1);
+    else if (fanout <= 20) GGMS_HD(16, 2);
+    else GGMS_HD(16, 4);
+  }
+#undef GGMS_HD
   GGMS_LAUNCH_CHECK();
   return GGMS_OK;
 }
