@@ -258,6 +258,7 @@ __global__ __launch_bounds__(kWave) void k_weighted_hash_dedup(const uint32_t *_
       }
       drew = true;
       uint32_t got = 0, tries = 0;
+      const uint32_t len_magic = (uint32_t)(4294967296.0 / (double)len); // floor(2^32 / len), exact (len > fanout >= 1)
       while (got < fanout) {
         const Xorwow st0 = st;
         uint32_t kraw[R] = {}, uraw[R] = {};
@@ -276,7 +277,10 @@ __global__ __launch_bounds__(kWave) void k_weighted_hash_dedup(const uint32_t *_
           float pr[R];
 #pragma unroll
           for (uint32_t i = 0; i < R; ++i) { // one round trip: the alias is loaded unconditionally, with the rest
-            const uint32_t k = kraw[i] % len;
+            // kraw % len: q' = mulhi(x, floor(2^32 / len)) is q or q - 1 (two fix-ups for safety)
+            uint32_t k = kraw[i] - __umulhi(kraw[i], len_magic) * len;
+            k = min(k, k - len);
+            k = min(k, k - len);
             nb[i] = indices[off + k];
             al[i] = alias[off + k];
             pr[i] = prob[off + k];
@@ -338,9 +342,31 @@ __global__ __launch_bounds__(kWave) void k_weighted_hash_dedup(const uint32_t *_
           }
         }
         if (done) {
-          if (used < G * R) { // two draws per try actually made
-            st = st0;
-            for (uint32_t d = 0; d < 2 * used; ++d) (void)st.next();
+          if (used < G * R) {
+            // Two draws per try actually made: the state after m = 2 * used draws.  The generator's v-array is a
+            // sliding window over the sequence (old v0..v4, then the raw xorshift word of draw 0, 1, ...), so
+            // v_j = window element m + j: five lane reads instead of replaying m steps.  Draw k of the round is
+            // try k / 2 = G i + l: lane l holds it in kraw[i] (k even) or uraw[i] (k odd); its raw word is the
+            // draw minus the Weyl counter after k + 1 steps.
+            const uint32_t m = 2 * used;
+            uint32_t v[5];
+#pragma unroll
+            for (uint32_t j = 0; j < 5; ++j) {
+              const uint32_t e = m + j;                       // window element, >= 2
+              const uint32_t k = e >= 5 ? e - 5 : 0;          // draw of the round (if e >= 5)
+              const uint32_t ti = (k >> 1) / G, tl = (k >> 1) % G;
+              uint32_t mine = 0;
+#pragma unroll
+              for (uint32_t i = 0; i < R; ++i) mine = (i == ti) ? ((k & 1u) ? uraw[i] : kraw[i]) : mine;
+              const uint32_t x = __shfl(mine, (int)(grp_shift + tl), 64);
+              const uint32_t from_draw = x - (st0.d + (k + 1) * 362437u);
+              uint32_t from_old = st0.v4;
+              from_old = (e == 3) ? st0.v3 : from_old;
+              from_old = (e == 2) ? st0.v2 : from_old;
+              v[j] = (e >= 5) ? from_draw : from_old;
+            }
+            st.v0 = v[0]; st.v1 = v[1]; st.v2 = v[2]; st.v3 = v[3]; st.v4 = v[4];
+            st.d = st0.d + m * 362437u;
           }
         } else {
           tries += G * R;
