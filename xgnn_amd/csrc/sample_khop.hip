@@ -677,7 +677,10 @@ __global__ __launch_bounds__(kWave) void k_sample_khop2(const uint32_t *__restri
 }
 
 // groups per wave of the khop3 kernel: sparse waves while the frontier leaves SIMDs idle (1024 SIMDs; a block
-// is 8 groups).  GGMS_KHOP3_GPW=1|2|4 pins it (measurement hook).
+// is 8 groups): one group per wave (512 threads per tile) for the first layers of a batch, two (256 threads) beyond.
+// Four groups per wave (128 threads per tile: the densest draws phase) measured 5 % slower on products [25,10], 14 % on
+// papers100M [25,10] and 1 % on the papers100M GCN layers: the sweep of a tile is a latency chain, twice the lanes
+// halve its rounds (profiles/r03_ab_khop3_groups_per_wave.txt).  GGMS_KHOP3_GPW=1|2|4 pins it (measurement hook).
 static int khop3_groups_per_wave(size_t blocks) {
   static const int pinned = [] {
     const char *e = getenv("GGMS_KHOP3_GPW");
@@ -685,8 +688,7 @@ static int khop3_groups_per_wave(size_t blocks) {
   }();
   if (pinned == 1 || pinned == 2 || pinned == 4) return pinned;
   if (blocks * 8 <= 2048) return 1;
-  if (blocks * 4 <= 2048) return 2;
-  return 4;
+  return 2;
 }
 
 size_t sample_ws_words(size_t num_input) {
