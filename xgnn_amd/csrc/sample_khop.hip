@@ -107,10 +107,18 @@ __global__ __launch_bounds__(128 * (4 / GPW)) void k_khop3_fused(GraphView g, co
     for (uint32_t s = lig; s <= set_mask; s += 16) tab[s] = HASH_EMPTY;
   bool dirty = false; // group-uniform: the set holds entries
 
-  for (;;) {
-    if (threadIdx.x == 0) s_tile = take_ticket(fs.tick);
-    __syncthreads();
-    const uint64_t b = s_tile;
+  // A launch with a workgroup per tile (every layer but the largest ones) needs no ticket: tile = workgroup id, one
+  // memory round trip less on the tile's latency chain.  Workgroups are dispatched in id order, so a tile's predecessors
+  // run or are done when it looks back (the bounded wait covers anything else).
+  const bool one_tile_each = gridDim.x >= num_tiles; // uniform
+  for (uint32_t turn = 0;; ++turn) {
+    if (one_tile_each) {
+      if (turn != 0) break;
+    } else {
+      if (threadIdx.x == 0) s_tile = take_ticket(fs.tick);
+      __syncthreads();
+    }
+    const uint64_t b = one_tile_each ? (uint64_t)blockIdx.x : s_tile;
     if (b >= num_tiles) break;
     // ---- 1: lane lig of group y fetches seed k = lig of the group: id -> (list, degree, 2^32/deg)
     uint32_t my_len = 0, my_magic = 0;

@@ -95,10 +95,18 @@ __global__ __launch_bounds__(T) void k_walk_topk_emit(uint32_t *tmp_src, uint32_
   const uint64_t n = n_arg.get();
   const uint64_t num_tiles = (n + T - 1) / T;
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
-  for (;;) {
-    if (tid == 0) s_tile = take_ticket(fs.tick);
-    __syncthreads();
-    const uint64_t b = s_tile;
+  // A launch with a workgroup per tile (every layer but the largest ones) needs no ticket: tile = workgroup id, one
+  // memory round trip less on the tile's latency chain.  Workgroups are dispatched in id order, so a tile's predecessors
+  // run or are done when it looks back (the bounded wait covers anything else).
+  const bool one_tile_each = gridDim.x >= num_tiles; // uniform
+  for (uint32_t turn = 0;; ++turn) {
+    if (one_tile_each) {
+      if (turn != 0) break;
+    } else {
+      if (tid == 0) s_tile = take_ticket(fs.tick);
+      __syncthreads();
+    }
+    const uint64_t b = one_tile_each ? (uint64_t)blockIdx.x : s_tile;
     if (b >= num_tiles) break;
     const uint64_t s = b * T + tid;
     const auto col = [&](uint32_t u) -> uint64_t { return SPILL ? (uint64_t)u * stride + s : (uint64_t)u * T + tid; };
