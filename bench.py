@@ -116,6 +116,22 @@ def measured_traffic(preset):
     return d
 
 
+def measured_sampler_traffic(preset):
+    """HBM-side bytes of the sampler chain per sampled edge from the committed PMC passes
+    (profiles/*_sampler_traffic_<preset>.json, tools/summarize_profiles.py); void when the sampler sources changed."""
+    import glob
+    import hashlib
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"*_sampler_traffic_{preset}.json")))
+    if not files:
+        return None
+    d = json.load(open(files[-1]))
+    d["source"] = os.path.relpath(files[-1], ROOT)
+    csrc = os.path.join(ROOT, "xgnn_amd", "csrc")
+    now = hashlib.sha256(b"".join(open(os.path.join(csrc, f), "rb").read() for f in d.get("sources", []))).hexdigest()
+    d["stale"] = d.get("sources_sha256") != now
+    return d
+
+
 def cpu_baseline(graph, fanouts, batch, feat, seconds):
     """CPU leg on the same graph: the reference's own CPU leaves (oracle/_ref: CPUSampleKHop0, CPUExtract) where
     shipped, else the oracle's port; dedup/remap = the oracle's OpenMP restatement of CPUHashTable2 (the reference's
@@ -802,12 +818,21 @@ def main():
             # request floor: one (neighbour load, dedup atomic) pair per edge + one indptr sector per seed, at the
             # rates this device sustains for exactly those requests (measured above, same process, same table size)
             floor_s = E_step / probe["load_atomic_pairs_per_s"] + S_step / probe["loads_per_s"]
+            st = measured_sampler_traffic(args.preset) if args.sample_type == "khop3" and not args.neighbour_skew else None
+            s_traffic = None
+            if st is not None and not st["stale"]:  # PMC bytes per edge (profiled run of this command) x this run's edges / time
+                s_traffic = st["hbm_bytes_per_batch"] / st["edges_per_batch"] * E_step / t / 1e9
             res["roofline_sampler"] = {
                 "kernel": f"sampler chain of one batch alone on one stream: k_ht_insert, k_khop3_fused x {L}, "
                           f"k_owner_scan_chunked x {L + 1}, k_map_rest_all x 2" if args.sample_type == "khop3" else
                           f"sampler chain of one batch ({args.sample_type}) alone on one stream",
                 "bound": "hbm", "achieved": algo / t / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": algo / t / 8e12,
-                "traffic": None,
+                # bytes at the L2's memory side (FETCH_SIZE + WRITE_SIZE of the chain's kernels): 64-byte lines for 4-byte
+                # reads and 32-byte atomic payloads -- 3.5 x the algorithmic figure; the table line's read / write-back
+                # behind every atomic is not in these counters
+                "traffic": s_traffic,
+                "traffic_source": None if st is None else st["source"] + (" (stale: sampler sources changed since; traffic nulled)"
+                                                                          if st["stale"] else ""),
                 "algorithmic_bytes_per_step": algo, "alone_ms": sampler_alone_ms,
                 "edges_per_step": E_step, "seeds_per_step": S_step, "edges_per_s_alone": E_step / t,
                 # the chain is bounded by REQUESTS at the memory side, not by bytes: its atomics and

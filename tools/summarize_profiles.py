@@ -135,6 +135,39 @@ def main():
     print(json.dumps(out, indent=1))
     print(open(f"{dst}_kernel_timeline.csv").read())
 
+    # ---- the sampler chain: bytes at the L2's memory side per batch, from the same PMC passes
+    # batches of the run = launches of the seed insert (one per batch, every sampler launch of the run included);
+    # FETCH_SIZE is doubled for the kernels whose reads are wide coalesced streams (the guide's gfx950 note: 128-byte
+    # requests tallied at 64 B) and taken as it is for the samplers' 4-byte neighbour / indptr loads (one 64-byte
+    # request each, counted exactly -- the probe kernels in the same file: 3.37 M random loads = 209 MB = 64 B each).
+    # Atomics show up as 32 bytes of WRITE_SIZE each and no FETCH_SIZE: the table line's read and write-back at the
+    # DRAM are not in these counters.
+    def per_batch(match, counter, corr):
+        ks = [k for (k, c) in pmc if c == counter and match in k]
+        return sum(sum(pmc[(k, counter)]) for k in ks) * corr * 1024
+    batches = sum(len(v) for (k, c), v in pmc.items() if c == "FETCH_SIZE" and "k_ht_insert" in k)
+    if batches:
+        parts = {}
+        for name, match, corr in (("fused samplers", "k_khop3_fused", 1.0), ("owner scans", "k_owner_scan", 2.0),
+                                  ("look-ups", "k_map_rest_all", 2.0), ("seed insert", "k_ht_insert", 1.0)):
+            parts[name] = {"fetch_bytes": per_batch(match, "FETCH_SIZE", corr) / batches,
+                           "write_bytes": per_batch(match, "WRITE_SIZE", 1.0) / batches, "fetch_correction": corr}
+        total = sum(p["fetch_bytes"] + p["write_bytes"] for p in parts.values())
+        E, S = bench["per_gpu"]["edges_per_step"], (bench.get("roofline_sampler") or {}).get("seeds_per_step")
+        st = {"batches": batches, "per_kernel_group": parts, "hbm_bytes_per_batch": total,
+              "edges_per_batch": E, "seeds_per_batch": S,
+              "algorithmic_bytes_per_batch": (12 * S + 28 * E) if S else None,
+              "traffic_over_algorithmic": total / (12 * S + 28 * E) if S else None,
+              "note": "64-byte lines for the 4-byte neighbour and indptr reads and 32-byte atomic payloads against SURVEY "
+                      "8d's 4 + 16 bytes per edge; the dedup table's line read and write-back per atomic are not counted here"}
+        srcs = ["sample_khop.hip", "hashtable.hip", "sample_batch.hip", "ggms_device.h", "tile_scan.h"]
+        root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "xgnn_amd", "csrc")
+        st["sources_sha256"] = hashlib.sha256(b"".join(open(os.path.join(root, f), "rb").read() for f in srcs)).hexdigest()
+        st["sources"] = srcs
+        with open(f"{dst}_sampler_traffic_{preset}.json", "w") as f:
+            json.dump(st, f, indent=1)
+        print(json.dumps(st, indent=1))
+
 
 if __name__ == "__main__":
     main()
