@@ -229,6 +229,20 @@ def launch_ranks(args):
     sys.exit(rc)
 
 
+def scratch_dir(need_bytes, prefix):
+    """A directory for a few GB of short-lived files: memory-backed /dev/shm when it has the room (a container may
+    cap it at 64 MB), else the temp directory."""
+    import shutil
+    import tempfile
+    for base in ("/dev/shm", tempfile.gettempdir()):
+        try:
+            if os.path.isdir(base) and shutil.disk_usage(base).free > 1.2 * need_bytes:
+                return tempfile.mkdtemp(prefix=prefix, dir=base)
+        except OSError:
+            pass
+    return tempfile.mkdtemp(prefix=prefix)
+
+
 def engine_record(datagen, graph, fanouts, args, log, workers=0, force_device=None):
     """The same workload through the operator surface north_star names (samgraph.torch: config / init / sample_once /
     get_next_batch) in a CHILD process: the graph is written in the reference's on-disk format without feat.bin /
@@ -239,7 +253,7 @@ def engine_record(datagen, graph, fanouts, args, log, workers=0, force_device=No
     import shutil
     import subprocess
     import tempfile
-    d = tempfile.mkdtemp(prefix="ggms_bench_ds_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    d = scratch_dir(graph["indptr"].nbytes + graph["indices"].nbytes + 8 * graph["indptr"].size, "ggms_bench_ds_")
     try:
         t0 = time.perf_counter()
         datagen.write_dataset(d, graph, minimal=True)
@@ -282,22 +296,23 @@ def shared_graph(datagen, args, world, local_rank, dist):
     if world == 1:
         return datagen.make_graph(args.preset, **kw)
     import shutil
-    d = f"/dev/shm/ggms_bench_{os.environ.get('MASTER_PORT', '0')}_{os.getuid()}"
+    g = d = None
     try:
         if local_rank == 0:
-            shutil.rmtree(d, ignore_errors=True)
-            os.makedirs(d)
             g = datagen.make_graph(args.preset, **kw)
+            d = scratch_dir(g["indptr"].nbytes + g["indices"].nbytes, "ggms_bench_graph_")
             for k in ("indptr", "indices", "train_set"):
                 np.save(os.path.join(d, k + ".npy"), g[k])
             json.dump(g["meta"], open(os.path.join(d, "meta.json"), "w"))
-        dist.barrier()
+        where = [d]
+        dist.broadcast_object_list(where, src=0)  # also the meeting point: the files are complete
+        d = where[0]
         if local_rank != 0:
             g = {k: np.load(os.path.join(d, k + ".npy"), mmap_mode="r") for k in ("indptr", "indices", "train_set")}
             g["meta"] = json.load(open(os.path.join(d, "meta.json")))
         dist.barrier()  # everybody holds its mappings: the files can go
     finally:
-        if local_rank == 0:
+        if local_rank == 0 and d:
             shutil.rmtree(d, ignore_errors=True)
     return g
 
