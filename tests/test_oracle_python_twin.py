@@ -1,0 +1,259 @@
+"""A second, independent restatement of the reference's khop3 path -- plain Python loops written against the CUDA text,
+not against oracle/ggms_oracle.c -- and the C oracle must agree with it on small cases.
+
+What this adds: the oracle is one reading of racy CUDA code; this twin is the same canonical reading
+(lock-step draw, first-occurrence dedup) restated from the sources a second time, structured like the kernels themselves
+(blocks of 128 seeds, 8 groups, a 128-slot open-addressing set with triangular probing, the padded tmp arrays and their
+compaction), so a slip in either restatement shows up as a difference.  It cannot pin the four curand_init constants
+(both read tests/golden/xorwow_constants.json).
+
+    sample_khop3 / _SetInsert        cuda/cuda_sampling_khop3.cu:51-146
+    count_edge / compact_edge        :148-230 (keep entries whose src is not kEmptyKey, in (seed, slot) order)
+    GPUSampleKHop3 launch geometry   :234-318 (GROUP_SIZE 16, BLOCK_WARP 8, TILE_SIZE 128; state i = 8 b + y)
+    DoGPUSample layer loop           dist/dist_loops.cc:100-368
+    OrderedHashTable contract        cuda/cuda_hashtable.cu:744-912 (contiguous local ids, prefix-stable; canonical:
+                                     first occurrence owns the key)
+    curand_init / curand             cuRAND XORWOW, constants of tests/golden/xorwow_constants.json
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+from graphgen import hub_csr, powerlaw_csr
+
+EMPTY = 0xFFFFFFFF
+M32 = 0xFFFFFFFF
+
+
+class Xorwow:
+    """curandStateXORWOW with subsequence = offset = 0."""
+
+    def __init__(self, seed, const):
+        c = const["curand_init_scramble"]
+        b = const["base_state"]
+        s0 = (seed & M32) ^ c["salt_lo"]
+        s1 = ((seed >> 32) & M32) ^ c["salt_hi"]
+        t0 = (c["mul_lo"] * s0) & M32
+        t1 = (c["mul_hi"] * s1) & M32
+        v = list(b["v"])
+        self.v = [(v[0] + t0) & M32, v[1] ^ t0, (v[2] + t1) & M32, v[3] ^ t1, (v[4] + t0) & M32]
+        self.d = (b["d"] + t1 + t0) & M32
+        self.weyl = const["weyl_increment"]["value"]
+
+    def next(self):
+        v = self.v
+        t = v[0] ^ (v[0] >> 2)
+        v[0], v[1], v[2], v[3] = v[1], v[2], v[3], v[4]
+        v[4] = (v[4] ^ ((v[4] << 4) & M32)) ^ (t ^ ((t << 1) & M32))
+        self.d = (self.d + self.weyl) & M32
+        return (v[4] + self.d) & M32
+
+
+def khop3_twin(indptr, indices, inp, fanout, states):
+    """sample_khop3 + count_edge + compact_edge.  states: list of Xorwow, advanced in place."""
+    n = len(inp)
+    tmp_src = [[EMPTY] * fanout for _ in range(n)]
+    tmp_dst = [[EMPTY] * fanout for _ in range(n)]
+    for b in range((n + 127) // 128):            # blockIdx.x
+        for y in range(8):                       # threadIdx.y: one group of 16 lanes, one shared generator
+            st = states[8 * b + y]
+            table = [EMPTY] * 128                # DeviceSet.hashtable
+            for index in range(128 * b + y, 128 * (b + 1), 8):
+                if index >= n:
+                    continue
+                rid = int(inp[index])
+                lo, hi = int(indptr[rid]), int(indptr[rid + 1])
+                ln = hi - lo
+                if ln <= fanout:
+                    for j in range(ln):
+                        tmp_src[index][j] = rid
+                        tmp_dst[index][j] = int(indices[lo + j])
+                    continue
+                items = []                        # mark_pos: table positions in insertion order
+                while len(items) < fanout:
+                    rand = st.next() % ln         # the 16 lanes read one state: one draw per iteration
+                    pos, offset = rand & 127, 1   # _SetInsert
+                    while True:
+                        if table[pos] == EMPTY:
+                            table[pos] = rand
+                            items.append(pos)
+                            break
+                        if table[pos] == rand:
+                            break
+                        pos = (pos + offset) & 127
+                        offset += 1
+                        assert offset < 128
+                for j, p in enumerate(items):
+                    tmp_src[index][j] = rid
+                    tmp_dst[index][j] = int(indices[lo + table[p]])
+                    table[p] = EMPTY              # "reset the hashtable values"
+    src = [s for row in tmp_src for s in row if s != EMPTY]
+    dst = [d for rs, rd in zip(tmp_src, tmp_dst) for s, d in zip(rs, rd) if s != EMPTY]
+    return src, dst
+
+
+def do_sample_twin(indptr, indices, seeds, fanouts, states):
+    """DoGPUSample with khop3: layers from the last fanout to the first; the next layer's input is the table's
+    unique list (seeds first, then every new node in first-occurrence order)."""
+    local = {}                                    # OrderedHashTable: global id -> local id
+    for s in seeds:                               # FillWithDupRevised(output_nodes)
+        local.setdefault(int(s), len(local))
+    cur = [int(s) for s in seeds]
+    layers = [None] * len(fanouts)
+    for i in range(len(fanouts) - 1, -1, -1):
+        src, dst = khop3_twin(indptr, indices, cur, fanouts[i], states)
+        for d in dst:                             # FillWithDuplicates(out_dst)
+            local.setdefault(d, len(local))
+        layers[i] = dict(col=[local[s] for s in src], row=[local[d] for d in dst],  # GPUMapEdges; col = new_src, row = new_dst
+                         num_src=len(local), num_dst=len(cur))
+        cur = list(local)                         # unique: insertion order of the dict = local id order
+    return dict(layers=layers, input_nodes=cur)
+
+
+def khop0_twin(indptr, indices, inp, fanout, const):
+    """sample_khop0, NEW_ALGO (cuda/cuda_sampling_khop0.cu:102-153; launch :279-288: 32 lanes x 4 warps, 64 seeds per
+    block).  Lane x of warp w of block b re-seeds its generator per launch from (b * 128 + x * 4 + w) + num_input and
+    draws for the positions j >= fanout, j = x (mod 32), of the warp's seeds in turn: slot curand % (j + 1), taken if
+    < fanout.  Colliding atomicExch on one slot resolve as if the positions came in ascending order (canonical:
+    highest j wins).  Output compacted like khop3's."""
+    n = len(inp)
+    src, dst = [], []
+    rows = [None] * n
+    for b in range((n + 63) // 64):
+        for w in range(4):
+            lanes = [Xorwow(b * 128 + x * 4 + w + n, const) for x in range(32)]
+            for index in range(64 * b + w, min(64 * (b + 1), n), 4):
+                rid = int(inp[index])
+                lo, hi = int(indptr[rid]), int(indptr[rid + 1])
+                ln = hi - lo
+                if ln <= fanout:
+                    rows[index] = [int(indices[lo + j]) for j in range(ln)]
+                    continue
+                slots = [int(indices[lo + j]) for j in range(fanout)]
+                for j in range(fanout, ln):        # ascending j: per lane its own order, across lanes highest j wins
+                    k = lanes[j % 32].next() % (j + 1)
+                    if k < fanout:
+                        slots[k] = int(indices[lo + j])
+                rows[index] = slots
+    for index in range(n):
+        for d in rows[index]:
+            src.append(int(inp[index]))
+            dst.append(d)
+    return src, dst
+
+
+def curand_uniform_twin(x):
+    """curand_uniform: float(x) * 2^-32 + 2^-33, one rounding after the conversion of x (an fma in f32)."""
+    xf = float(np.float32(x))                      # cvt.rn.f32.u32
+    return np.float32(xf * 2.0 ** -32 + 2.0 ** -33)  # exact in f64 (24-bit factor), rounded once
+
+
+def weighted_khop_twin(indptr, indices, prob, alias, inp, fanout, states):
+    """sample_weighted_khop + stable SortPairs by src + count_edge / compact_edge
+    (cuda/cuda_sampling_weighted_khop.cu:41-128, launch :156-181): task t -> seed t / fanout; thread t of a grid-stride
+    launch over min(tasks, 512 K) threads rounded up to whole 256-thread blocks keeps generator t; a task takes TWO
+    draws (position, acceptance); an entry equal to its successor after the sort is dropped (partial dedup by design)."""
+    n = len(inp)
+    num_task = n * fanout
+    threads = min(num_task, 512 * 1024)             # Constant::kWeightedKHopMaxThreads, constant.h:72
+    span = (threads + 255) // 256 * 256
+    src = [EMPTY] * num_task
+    dst = [0] * num_task
+    for t in range(min(span, num_task)):
+        st = states[t]
+        for task in range(t, num_task, span):
+            rid = int(inp[task // fanout])
+            lo, hi = int(indptr[rid]), int(indptr[rid + 1])
+            ln = hi - lo
+            if ln == 0:
+                continue                             # tmp_src = kEmptyKey, tmp_dst never written
+            k = st.next() % ln
+            r = curand_uniform_twin(st.next())
+            src[task] = rid
+            dst[task] = int(indices[lo + k]) if r < np.float32(prob[lo + k]) else int(alias[lo + k])
+    order = sorted(range(num_task), key=lambda i: src[i])  # stable; kEmptyKey sorts last
+    s_src, s_dst = [src[i] for i in order], [dst[i] for i in order]
+    out_src, out_dst = [], []
+    for i in range(num_task):
+        if s_src[i] == EMPTY:
+            continue
+        if i + 1 < num_task and s_src[i] == s_src[i + 1] and s_dst[i] == s_dst[i + 1]:
+            continue
+        out_src.append(s_src[i])
+        out_dst.append(s_dst[i])
+    return out_src, out_dst
+
+
+@pytest.fixture(scope="module")
+def const(golden_dir):
+    return json.load(open(os.path.join(golden_dir, "xorwow_constants.json")))
+
+
+def test_xorwow_twin_matches_the_oracle_stream(const):
+    for seed in (0, 1, 0x5EED, (7 << 32) | 123):
+        st = Xorwow(seed, const)
+        want = oracle.xorwow_stream(seed, 200)
+        assert [st.next() for _ in range(200)] == want.tolist()
+
+
+@pytest.mark.parametrize("gname,nseed,fanouts,seed", [
+    ("powerlaw", 300, [5, 4], 11),          # two blocks of 128 + a ragged third, short and long lists mixed
+    ("powerlaw", 97, [3, 7, 5], 2),         # three layers, frontier grows past one block
+    ("hub", 150, [25, 10], 5),              # 6000-neighbour lists: long rejection runs, probing in the 128-slot set
+    ("hub", 40, [100], 9),                  # fanout near the set's capacity (< 128)
+    ("powerlaw", 64, [1], 3),               # fanout 1
+])
+def test_c_oracle_agrees_with_the_python_twin(const, gname, nseed, fanouts, seed):
+    ip, ix = powerlaw_csr(2500, mean_deg=12, seed=4) if gname == "powerlaw" else hub_csr()
+    rng = np.random.RandomState(seed)
+    seeds = rng.randint(0, ip.size - 1, nseed).astype(np.uint32)  # repeated seeds allowed, as in a raw batch
+    nstates = 8 * 64
+    orc_states = oracle.random_states(nstates, seed)
+    twin_states = [Xorwow(seed + t, const) for t in range(nstates)]  # curand_init(seed + tid, 0, 0), cuda_random_states.cu:44
+    want = do_sample_twin(ip, ix, seeds, fanouts, twin_states)
+    got = oracle.do_sample(oracle.KHOP3, ip, ix, seeds, fanouts, orc_states)
+    assert got["input_nodes"].tolist() == want["input_nodes"]
+    for i in range(len(fanouts)):
+        assert got["layers"][i]["row"].tolist() == want["layers"][i]["row"], f"layer {i} row"
+        assert got["layers"][i]["col"].tolist() == want["layers"][i]["col"], f"layer {i} col"
+        assert (got["layers"][i]["num_src"], got["layers"][i]["num_dst"]) == (want["layers"][i]["num_src"], want["layers"][i]["num_dst"])
+    # the generators end where the twin's do: same number of draws per stream
+    for t in range(nstates):
+        assert int(orc_states["d"][t]) == twin_states[t].d and orc_states["v"][t].tolist() == twin_states[t].v
+
+
+@pytest.mark.parametrize("gname,n,fanout", [("powerlaw", 333, 5), ("powerlaw", 64, 1), ("hub", 200, 25), ("hub", 70, 300)])
+def test_c_oracle_khop0_agrees_with_the_python_twin(const, gname, n, fanout):
+    ip, ix = powerlaw_csr(2500, mean_deg=12, seed=4) if gname == "powerlaw" else hub_csr()
+    inp = np.random.RandomState(fanout).permutation(ip.size - 1)[:n].astype(np.uint32)
+    want_src, want_dst = khop0_twin(ip, ix, inp, fanout, const)
+    got_src, got_dst = oracle.sample_khop0(ip, ix, inp, fanout)
+    assert got_src.tolist() == want_src and got_dst.tolist() == want_dst
+
+
+@pytest.mark.parametrize("n,fanout,seed", [(200, 5, 1), (77, 12, 2), (3000, 3, 3)])
+def test_c_oracle_weighted_khop_agrees_with_the_python_twin(const, n, fanout, seed):
+    from xgnn_amd import datagen
+    ip, ix = powerlaw_csr(1500, mean_deg=9, seed=6)            # includes nodes without neighbours
+    w = np.random.RandomState(seed).randint(1, 11, ix.size).astype(np.float32)
+    prob, alias = datagen.build_alias_tables(ip, ix, w, num_threads=2)
+    inp = np.random.RandomState(seed + 10).randint(0, ip.size - 1, n).astype(np.uint32)  # repeated seeds allowed
+    nstates = min(n * fanout, 512 * 1024)
+    nstates = (nstates + 255) // 256 * 256
+    orc_states = oracle.random_states(nstates, seed)
+    twin_states = [Xorwow(seed + t, const) for t in range(nstates)]
+    want_src, want_dst = weighted_khop_twin(ip, ix, prob, alias, inp, fanout, twin_states)
+    got_src, got_dst = oracle.sample_weighted_khop(ip, ix, prob, alias, inp, fanout, orc_states)
+    assert got_src.tolist() == want_src and got_dst.tolist() == want_dst
+    for t in range(0, nstates, 7):
+        assert int(orc_states["d"][t]) == twin_states[t].d and orc_states["v"][t].tolist() == twin_states[t].v
+
+
+def test_curand_uniform_twin_against_the_oracle(const):
+    xs = [0, 1, 2, 0xFFFFFFFF, 0xFFFFFF7F, 0xFFFFFF80, 0x80000000, 0x7FFFFFFF, 123456789, 0x01000001, 0x00FFFFFF]
+    got = [float(curand_uniform_twin(x)) for x in xs]
+    assert all(0.0 < g <= 1.0 for g in got)
+    assert got[0] == 2.0 ** -33 and got[3] == 1.0  # the open-closed interval of cuRAND: (0, 1]
