@@ -1,4 +1,5 @@
-"""A second, independent restatement of the reference's khop3 path -- plain Python loops written against the CUDA text,
+"""A second, independent restatement of the reference's sampling paths (khop3 + the layer loop, khop0, weighted_khop,
+random walk + top-K) -- plain Python loops written against the CUDA text,
 not against oracle/ggms_oracle.c -- and the C oracle must agree with it on small cases.
 
 What this adds: the oracle is one reading of racy CUDA code; this twin is the same canonical reading
@@ -187,6 +188,60 @@ def weighted_khop_twin(indptr, indices, prob, alias, inp, fanout, states):
     return out_src, out_dst
 
 
+def random_walk_twin(indptr, indices, inp, walk_length, restart_prob, num_walk, K, states):
+    """sample_random_walk (cuda/cuda_sampling_random_walk.cu:43-112; block shape :128-133: 256 threads reshaped to
+    (bx, by) with bx halved while bx >= 2 * num_walk) + FrequencyHashmap::GetTopK's contract
+    (cuda_frequency_hashmap.cu:643-841): per input POSITION the distinct visited nodes with their visit counts, the K
+    most visited first, ties in first-visit order (canonical reading of the racy `index` field: the smallest position
+    of the padded visit array), positions in input order; data = the count."""
+    n = len(inp)
+    bx, by = 256, 1
+    while bx >= 2 * num_walk:
+        bx //= 2
+        by *= 2
+    per = num_walk * walk_length
+    visits = [[None] * per for _ in range(n)]       # tmp_dst by (position, step * num_walk + walk); None = kEmptyKey src
+    for b in range((n + by - 1) // by):
+        for x in range(bx):
+            for y in range(by):
+                node_idx = b * by + y
+                if node_idx >= n:
+                    continue
+                st = states[256 * b + by * x + y]
+                start = int(inp[node_idx])
+                for walk in range(x, num_walk, bx):
+                    node = start
+                    for step in range(walk_length):
+                        if node is None:
+                            continue
+                        lo, hi = int(indptr[node]), int(indptr[node + 1])
+                        if hi == lo:
+                            node = None
+                            continue
+                        k = st.next() % (hi - lo)
+                        node = int(indices[lo + k])
+                        visits[node_idx][step * num_walk + walk] = node
+                        xx, yy = st.next(), st.next()  # curand_uniform_double: two draws, 53 bits
+                        z = xx ^ (yy << 21)
+                        if z * 2.0 ** -53 + 2.0 ** -54 < restart_prob:
+                            node = None
+    src, dst, data = [], [], []
+    for node_idx in range(n):
+        first, count = {}, {}
+        for p, v in enumerate(visits[node_idx]):
+            if v is None:
+                continue
+            first.setdefault(v, p)
+            count[v] = count.get(v, 0) + 1
+        order = sorted(first, key=lambda v: first[v])          # first-visit order ...
+        order = sorted(order, key=lambda v: -count[v])[:K]     # ... kept among equal counts (stable sort, descending)
+        for v in order:
+            src.append(int(inp[node_idx]))
+            dst.append(v)
+            data.append(count[v])
+    return src, dst, data
+
+
 @pytest.fixture(scope="module")
 def const(golden_dir):
     return json.load(open(os.path.join(golden_dir, "xorwow_constants.json")))
@@ -257,3 +312,21 @@ def test_curand_uniform_twin_against_the_oracle(const):
     got = [float(curand_uniform_twin(x)) for x in xs]
     assert all(0.0 < g <= 1.0 for g in got)
     assert got[0] == 2.0 ** -33 and got[3] == 1.0  # the open-closed interval of cuRAND: (0, 1]
+
+
+@pytest.mark.parametrize("n,wl,p,nw,K,seed", [(150, 3, 0.5, 4, 5, 1), (70, 4, 0.2, 3, 2, 2), (33, 2, 0.0, 9, 10, 3), (40, 3, 0.5, 130, 5, 4)])
+def test_c_oracle_random_walk_agrees_with_the_python_twin(const, n, wl, p, nw, K, seed):
+    ip, ix = powerlaw_csr(1200, mean_deg=7, seed=8)            # includes nodes without neighbours (walks that die)
+    inp = np.random.RandomState(seed).randint(0, ip.size - 1, n).astype(np.uint32)  # repeated positions are separate
+    bx, by = 256, 1
+    while bx >= 2 * nw:
+        bx //= 2
+        by *= 2
+    nstates = (n + by - 1) // by * 256
+    orc_states = oracle.random_states(nstates, seed)
+    twin_states = [Xorwow(seed + t, const) for t in range(nstates)]
+    want = random_walk_twin(ip, ix, inp, wl, p, nw, K, twin_states)
+    got = oracle.sample_random_walk(ip, ix, inp, wl, p, nw, K, orc_states)
+    assert [a.tolist() for a in got] == [list(w) for w in want]
+    for t in range(0, nstates, 5):
+        assert int(orc_states["d"][t]) == twin_states[t].d and orc_states["v"][t].tolist() == twin_states[t].v
