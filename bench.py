@@ -57,7 +57,7 @@ def parse():
     ap.add_argument("--no-sampler-roofline", action="store_true",
                     help="skip the sampler-alone timing and the memory-side rate probe (roofline_sampler)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline: keep sampling mini-batches this long")
-    ap.add_argument("--host-steps", type=int, default=5, help="timed steps of the host-tier sub-record")
+    ap.add_argument("--host-steps", type=int, default=10, help="timed steps of the host-tier sub-record")
     ap.add_argument("--host-profile", action="store_true", help="print host enqueue time per section to stderr")
     ap.add_argument("--pipelines", type=int, default=1,
                     help="sampling batches in flight (each on its own stream with its own dedup table)")
