@@ -65,6 +65,38 @@ def test_two_ranks_default_is_the_sharded_store():
     assert 0 < st["hybrid"]["remote_row_fraction"] < st["peer"]["remote_row_fraction"]
 
 
+_BROKEN_IPC = """
+import runpy, sys
+sys.path.insert(0, {root!r})
+from xgnn_amd import ops
+def refuse(self, handle):
+    raise RuntimeError("hipIpcOpenMemHandle: invalid argument (test)")
+ops.SharedShard.import_peer = refuse
+sys.argv = [{bench!r}] + sys.argv[1:]
+runpy.run_path({bench!r}, run_name="__main__")
+"""
+
+
+def test_two_ranks_whose_shards_cannot_be_mapped_report_replicas_and_say_so(tmp_path):
+    """hipIpcOpenMemHandle returns an error on every rank: all ranks learn of it together, the line is measured on
+    whole-table replicas and carries what was asked for and why it was not measured."""
+    bench = os.path.join(ROOT, "bench.py")
+    script = tmp_path / "broken_ipc_bench.py"
+    script.write_text(_BROKEN_IPC.format(root=os.path.abspath(ROOT), bench=os.path.abspath(bench)))
+    env = dict(os.environ, GGMS_BENCH_DEVICE="0", GGMS_BENCH_BACKEND="gloo")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), str(script),
+                        "--gpus", "2", "--preset", "tiny", "--steps", "3", "--warmup", "1", "--batch", "512", "--no-engine"],
+                       capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = _last_json(r.stdout)
+    assert d["n_gpus"] == 2 and "feature store: replica" in d["config"]["workload"]
+    assert d["config"]["store_requested"] == "peer" and "invalid argument (test)" in d["config"]["store_error"]
+    assert "rank 0 of 2" in d["config"]["store_error"] and "rank 1 of 2" in d["config"]["store_error"]
+    assert "error" in d["stores"]["hybrid"] and d["stores"]["replica"]["edges_per_s"] > 0
+    assert "cannot be built" in r.stderr
+
+
 def test_gpus_flag_alone_starts_the_ranks():
     """The bare command `python bench.py --gpus 2` (no launcher around it, as the driver runs N = 1): the script
     starts its two ranks itself and the line says n_gpus: 2 -- here both pinned to the box's one GPU by the hooks."""

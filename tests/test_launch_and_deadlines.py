@@ -109,3 +109,54 @@ def test_a_rank_that_never_publishes_its_shard_ends_the_others_with_a_message(tm
         stuck.wait()
     assert r.returncode == 3 and time.time() - t0 < 30, (r.returncode, r.stderr[-1000:])
     assert "rank 0 of 2" in r.stderr and "never published its shard" in r.stderr and "not reached" not in r.stdout
+
+
+_REFUSED_SCRIPT = """
+import os, sys
+sys.path.insert(0, {root!r})
+import torch, torch.distributed as dist
+from xgnn_amd import ggms_store
+
+rank = int(sys.argv[1])
+
+class HostShard:
+    def __init__(self):
+        self.tensor = torch.zeros((8, 4)); self.shape = (8, 4); self.ptr = self.tensor.data_ptr()
+    def export_handle(self):
+        if sys.argv[3] == "export" and rank == 1:
+            raise RuntimeError("hipIpcGetMemHandle: invalid argument")
+        return b"h" * 64
+    def import_peer(self, h):
+        if sys.argv[3] == "import" and rank == 1:
+            raise RuntimeError("hipIpcOpenMemHandle: invalid device pointer")
+        return 1234
+
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=sys.argv[2])
+dist.init_process_group("gloo", rank=rank, world_size=2)
+sh = HostShard()
+st = ggms_store.FeatureShards(sh.tensor, None, 2, rank, mode="peer", dist=dist, leaf=object())
+try:
+    st.connect_peers(sh)
+    print("MAPPED")
+except ggms_store.PeerConnectError as e:
+    print("REFUSED", e)
+dist.barrier()   # both ranks are still in step: the failure did not strand the other one
+print("in step")
+"""
+
+
+@pytest.mark.parametrize("where", ["import", "export"])
+def test_a_refused_ipc_call_on_one_rank_is_raised_on_every_rank(tmp_path, where):
+    """An IPC call that returns an error on ONE rank: every rank gets PeerConnectError with that rank's message, and
+    the group stays in step (the caller may then take the same turn everywhere, as bench.py does)."""
+    script = tmp_path / "refused.py"
+    script.write_text(_REFUSED_SCRIPT.format(root=ROOT))
+    port = str(_free_port())
+    env = dict(os.environ, GGMS_IPC_TIMEOUT_S="30")
+    ps = [subprocess.Popen([sys.executable, str(script), str(r), port, where], env=env, stdout=subprocess.PIPE,
+                           stderr=subprocess.PIPE, text=True) for r in (0, 1)]
+    outs = [p.communicate(timeout=120) for p in ps]
+    for p, (out, err) in zip(ps, outs):
+        assert p.returncode == 0, err[-1000:]
+        assert "REFUSED" in out and "rank 1 of 2" in out and "in step" in out and "MAPPED" not in out
+        assert ("hipIpcOpenMemHandle: invalid device pointer" if where == "import" else "hipIpcGetMemHandle") in out

@@ -66,6 +66,11 @@ def with_deadline(fn, what, seconds=None, on_timeout=None):
     return box.get("value")
 
 
+class PeerConnectError(RuntimeError):
+    """A peer's shard could not be mapped (hipIpcOpenMemHandle / hipIpcGetMemHandle returned an error).  Raised on
+    EVERY rank of the group with the failures of all of them, so the caller may decide together what to do."""
+
+
 class HipLeaf:
     """The device operators the store needs, on HIP (xgnn_amd.ops)."""
 
@@ -151,9 +156,13 @@ class FeatureShards:
         # fill kernels are asynchronous), and meet the peers again once everybody has mapped everybody (below)
         if shared_shard.tensor.is_cuda:
             torch.cuda.synchronize(shared_shard.tensor.device)
-        mine = shared_shard.export_handle()
         nbytes = int(np.prod(shared_shard.shape)) * self.shard.element_size()
         me = f"rank {self.rank} of {self.world} (device {self.shard.device})"
+        failed = None
+        try:
+            mine = shared_shard.export_handle()
+        except Exception as e:  # noqa: BLE001 -- published as "no handle"; reported with the verdicts below
+            mine, failed = None, f"{me}: hipIpcGetMemHandle of its own shard ({nbytes} bytes): {type(e).__name__}: {e}"
         if self.world == 1:
             handles = [(mine, nbytes)]
         else:
@@ -162,17 +171,29 @@ class FeatureShards:
             with_deadline(lambda: self.dist.all_gather_object(handles, (mine, nbytes), group=self.group),
                           f"{me} waiting for the peers' shard handles (all_gather): a rank never published its shard")
         ptrs = []
-        for r in range(self.world):
-            if r == self.rank:
-                ptrs.append(shared_shard.ptr)
-                continue
-            h, peer_bytes = handles[r]
-            ptrs.append(with_deadline(lambda h=h: shared_shard.import_peer(h),
-                                      f"{me}: hipIpcOpenMemHandle of rank {r}'s shard ({peer_bytes} bytes) did not return"))
-        self.parts_table = torch.tensor(ptrs, dtype=torch.int64, device=self.shard.device)
+        try:
+            for r in range(self.world):
+                if r == self.rank:
+                    ptrs.append(shared_shard.ptr)
+                    continue
+                h, peer_bytes = handles[r]
+                if h is None:  # that rank could not export: it says so itself
+                    ptrs.append(0)
+                    continue
+                ptrs.append(with_deadline(lambda h=h: shared_shard.import_peer(h),
+                                          f"{me}: hipIpcOpenMemHandle of rank {r}'s shard ({peer_bytes} bytes) did not return"))
+        except Exception as e:  # noqa: BLE001 -- an open that FAILED (one that hangs ends the process above)
+            failed = failed or f"{me}: shard of rank {r} ({peer_bytes} bytes): {type(e).__name__}: {e}"
         if self.world > 1:
-            with_deadline(lambda: self.dist.barrier(group=self.group),
-                          f"{me} waiting at the barrier after mapping the peers' shards: a rank is stuck opening one")
+            # the meeting point after the mapping doubles as the verdict: every rank learns of every failure and all
+            # of them leave together (a rank raising alone would strand the others in the next collective)
+            verdicts = [None] * self.world
+            with_deadline(lambda: self.dist.all_gather_object(verdicts, failed, group=self.group),
+                          f"{me} waiting for the peers after mapping their shards: a rank is stuck opening one")
+            failed = "; ".join(v for v in verdicts if v) or None
+        if failed:
+            raise PeerConnectError(failed)
+        self.parts_table = torch.tensor(ptrs, dtype=torch.int64, device=self.shard.device)
         return self
 
     # ---- one batch ----------------------------------------------------------------------------------
