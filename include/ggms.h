@@ -78,8 +78,14 @@ int ggms_device_status(uint32_t *status_host, int clear);
 int ggms_fabric_probe(int kind, void *table, size_t table_words, size_t num_requests, uint32_t salt, void *sink,
                       ggms_stream_t stream);
 /* Test aid: the next ordered scan of a direct-layout table fill (this process) starts with a poisoned ticket, so
- * that its look-back runs into its bound and sets GGMS_STATUS_SCAN_SPIN.  One shot. */
+ * that its look-back runs into its bound and sets GGMS_STATUS_SCAN_SPIN (the launch waits without helping itself).
+ * One shot. */
 void ggms_debug_poison_next_scan(void);
+/* The ordered scans chain their tiles by look-back.  A look-back waits `polls` polls (default 2048, about a
+ * millisecond) for a predecessor's word and then computes it from the scan's input itself, so that no workgroup's
+ * progress depends on when or where another one runs (two processes or two batches sharing a GPU).  0: never wait
+ * (tests: every look-back that finds a word missing takes the self-serve path); 0xffffffff: never help. */
+void ggms_debug_set_scan_patience(uint32_t polls);
 size_t ggms_dtype_bytes(int dtype);
 
 /* ---------------------------------------------------------------------------

@@ -23,6 +23,18 @@ def pytest_sessionstart(session):
         subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle")])
 
 
+@pytest.fixture(scope="session", autouse=True)
+def scan_patience_of_this_run():
+    """GGMS_TEST_SCAN_PATIENCE=0 pytest -m gpu: the whole GPU suite with look-backs that never wait -- every ordered scan
+    that finds a predecessor's word missing computes it itself (include/ggms.h, ggms_debug_set_scan_patience).  Results
+    must not change.  A test aid of the test session, not of the library: the product reads no environment for this."""
+    v = os.environ.get("GGMS_TEST_SCAN_PATIENCE")
+    if v is not None:
+        from xgnn_amd import lib
+        lib().ggms_debug_set_scan_patience(int(v))
+    yield
+
+
 @pytest.fixture(scope="session")
 def golden_dir():
     return os.path.join(ROOT, "tests", "golden")

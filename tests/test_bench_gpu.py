@@ -183,6 +183,20 @@ def test_two_ranks_one_gpu(store):
     assert store in d["config"]["workload"]
 
 
+def test_two_ranks_sharing_the_gpu_at_full_size_never_stall_each_other():
+    """Two processes, each with its own look-back chains (fused samplers, owner scans), on ONE GPU at papers100M size:
+    the waiting workgroups of one used to hold the slots the other's next workgroup needed (GGMS_STATUS_SCAN_SPIN in 3 of
+    6 runs, profiles/r03_two_ranks_one_gpu_before_selfserve_lookback.txt).  A look-back now computes a predecessor
+    that does not show up itself, so both ranks always finish."""
+    env = dict(os.environ, GGMS_BENCH_DEVICE="0", GGMS_BENCH_BACKEND="gloo")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--store", "replica",
+                        "--other-stores", "", "--no-engine", "--steps", "30"],
+                       capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = _last_json(r.stdout)
+    assert d["n_gpus"] == 2 and d["rows_verified"] and "device status" not in r.stderr
+
+
 def _two_ranks_full_size(flags, timeout=900):
     env = dict(os.environ, GGMS_BENCH_DEVICE="0", GGMS_BENCH_BACKEND="gloo")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",

@@ -473,10 +473,12 @@ __global__ __launch_bounds__(kBlock) void k_owner_scan_chunked(unsigned long lon
                                                                Count n_arg, unsigned long long *desc0,
                                                                uint32_t *chunk_desc, uint32_t epoch, uint32_t epoch16,
                                                                uint32_t *num_items, uint64_t *mirror_a,
-                                                               uint64_t *mirror_b, uint32_t *err, uint32_t skip_below) {
+                                                               uint64_t *mirror_b, uint32_t *err, uint32_t skip_below,
+                                                               uint32_t patience) {
   constexpr uint32_t FLAG_P = 2;
   __shared__ uint32_t smem[kBlock / kWave];
   __shared__ uint32_t s_total;
+  __shared__ uint32_t s_miss[kChunkGrid / 32]; // chunks this workgroup counts itself (their word did not show up)
   __shared__ uint32_t s_seg[kChunkRegTiles * kOwnSegs];  // owners per (tile, round, wave) segment, then their prefix
   __shared__ uint32_t s_keys[kChunkRegTiles * kOwnTile]; // the owners' keys of a chunk (or of one tile), in rank order
   const uint64_t n = n_arg.get();
@@ -487,10 +489,17 @@ __global__ __launch_bounds__(kBlock) void k_owner_scan_chunked(unsigned long lon
   // caller's sliced tensor may not be)
   const bool vec_ok = (((((uintptr_t)items) | ((uintptr_t)cand) | ((uintptr_t)mapped)) & 7u) | (((uintptr_t)lost) & 15u)) == 0;
   // chunk = workgroup id, no ticket: 1024 tickets from one counter are 11 us of same-address atomics
-  // (tools/micro_ticket.hip), and a chunk only ever waits for LOWER chunks, which publish before they wait for anybody
-  // -- with workgroups dispatched in id order a waiting chunk's predecessors are running or done.  Should a
-  // predecessor ever not show up, the bounded wait below turns that into the status word, not into a hang.
+  // (tools/micro_ticket.hip).  A chunk only ever waits for LOWER chunks, which publish before they wait for anybody;
+  // nothing is assumed about when their workgroups run -- a chunk that has waited `patience` polls counts the missing
+  // ones itself (below), so every resident workgroup finishes whatever else holds the device's slots.
   const uint32_t c = blockIdx.x;
+  uint32_t base_seen = 0;
+  unsigned long long d0_seen = 0;
+  if (c == 0) { // the table's item count, and THEN whether somebody has computed this chunk's word already (see below)
+    base_seen = __hip_atomic_load(num_items, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    d0_seen = __hip_atomic_load(desc0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
   if (c < chunks && c >= skip_below) { // skip_below: 0; ggms_debug_poison_next_scan drops chunk 0 (tests of the bound)
     const uint64_t t0 = (uint64_t)c * per;
     const uint32_t my_tiles = (uint32_t)min((uint64_t)per, tiles - t0);
@@ -528,13 +537,19 @@ __global__ __launch_bounds__(kBlock) void k_owner_scan_chunked(unsigned long lon
     // publish this chunk's count; chunk 0 carries the table's item count in
     uint32_t prefix = 0;
     if (c == 0) {
-      prefix = *num_items; // nobody writes it before chunk 0's descriptor is out (the total needs that descriptor)
+      // base_seen was read before d0_seen: a chunk-0 word that is still missing then means the total (which needs that
+      // word) had not replaced *num_items when it was read; a word that is there was computed by somebody who could
+      // not wait for this workgroup -- from the same count, so the base is what it holds minus this chunk's owners
+      prefix = base_seen;
+      if ((uint32_t)(d0_seen >> 34) == epoch && ((uint32_t)(d0_seen >> 32) & 3u) == FLAG_P) prefix = (uint32_t)d0_seen - running;
       if (threadIdx.x == 0)
         __hip_atomic_store(desc0, scan_desc(epoch, FLAG_P, prefix + running), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     } else {
       if (threadIdx.x == 0)
         __hip_atomic_store(&chunk_desc[c], (epoch16 << 16) | running, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      // every earlier chunk's count: first all loads in flight together, then wait for the stragglers (bounded)
+      // every earlier chunk's count: first all loads in flight together, then wait for the stragglers -- `patience`
+      // polls; after that the workgroup counts the chunks that have not shown up itself (nothing is promised about
+      // when their workgroups run, and this one holds a slot they may need)
       constexpr uint32_t kLook = kChunkGrid / kBlock;
       uint32_t got[kLook];
       bool ready[kLook];
@@ -549,34 +564,84 @@ __global__ __launch_bounds__(kBlock) void k_owner_scan_chunked(unsigned long lon
           got[r] = d & 0xffffu;
         }
       }
-      uint32_t sum = 0;
-#pragma unroll
-      for (uint32_t r = 0; r < kLook; ++r) {
-        const uint32_t j = threadIdx.x + r * kBlock;
-        for (uint32_t spins = 0; !ready[r]; ++spins) {
-          if (spins > (1u << 22)) { // a protocol error must not hang the GPU
-            if (err) atomicOr(err, kErrScanSpin);
-            got[r] = 0;
-            break;
-          }
-          __builtin_amdgcn_s_sleep(1);
-          const uint32_t d = __hip_atomic_load(&chunk_desc[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          ready[r] = (d >> 16) == epoch16;
-          got[r] = d & 0xffffu;
-        }
-        sum += got[r];
-      }
-      if (threadIdx.x == 0) { // chunk 0: absolute count (the base included), 64-bit descriptor
-        for (uint32_t spins = 0;; ++spins) {
+      uint32_t got0 = 0; // thread 0: chunk 0's 64-bit word = absolute count (the base included)
+      bool ready0 = threadIdx.x != 0;
+      for (uint32_t spins = 0;; ++spins) {
+        if (!ready0) {
           const unsigned long long d = __hip_atomic_load(desc0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          if ((uint32_t)(d >> 34) == epoch && ((uint32_t)(d >> 32) & 3u) == FLAG_P) { sum += (uint32_t)d; break; }
-          if (spins > (1u << 22)) {
-            if (err) atomicOr(err, kErrScanSpin);
-            break;
-          }
-          __builtin_amdgcn_s_sleep(1);
+          if ((uint32_t)(d >> 34) == epoch && ((uint32_t)(d >> 32) & 3u) == FLAG_P) { got0 = (uint32_t)d; ready0 = true; }
         }
+        bool all = ready0;
+#pragma unroll
+        for (uint32_t r = 0; r < kLook; ++r) all &= ready[r];
+        if (__syncthreads_and(all)) break;
+        if (spins >= patience) { // uniform: serve ourselves
+          if (threadIdx.x < kChunkGrid / 32) s_miss[threadIdx.x] = 0;
+          __syncthreads();
+#pragma unroll
+          for (uint32_t r = 0; r < kLook; ++r) {
+            const uint32_t j = threadIdx.x + r * kBlock;
+            if (!ready[r]) atomicOr(&s_miss[j >> 5], 1u << (j & 31u));
+          }
+          if (!ready0) atomicOr(&s_miss[0], 1u);
+          __syncthreads();
+          for (uint32_t wd = 0; wd < kChunkGrid / 32; ++wd) {
+            uint32_t m = s_miss[wd];
+            while (m) {
+              const uint32_t j = wd * 32 + (uint32_t)__builtin_ctz(m);
+              m &= m - 1u;
+              // chunk j's owners, counted by this workgroup from the scan's input (nobody rewrites cand / lost)
+              const uint64_t tj = (uint64_t)j * per;
+              const uint32_t ntj = (uint32_t)min((uint64_t)per, tiles - tj);
+              uint32_t mine = 0, cnt_j;
+              for (uint32_t k = 0; k < ntj; ++k) {
+                OwnTile t;
+                own_tile_load(t, items, cand, lost, tag, (tj + k) * kOwnTile, n, vec_ok, false);
+                mine += __popc(t.flags);
+              }
+              (void)block_exclusive_scan(mine, smem, cnt_j);
+              if (j == 0) {
+                if (threadIdx.x == 0) {
+                  const uint32_t v1 = __hip_atomic_load(num_items, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); // the count was READ before the word is looked at again
+                  const unsigned long long d = __hip_atomic_load(desc0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                  if ((uint32_t)(d >> 34) == epoch && ((uint32_t)(d >> 32) & 3u) == FLAG_P) {
+                    got0 = (uint32_t)d;
+                  } else { // still missing: the total (which needs this word) had not replaced *num_items at v1's time
+                    got0 = v1 + cnt_j;
+                    __hip_atomic_store(desc0, scan_desc(epoch, FLAG_P, got0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                  }
+                  ready0 = true;
+                }
+              } else {
+#pragma unroll
+                for (uint32_t r = 0; r < kLook; ++r)
+                  if (threadIdx.x + r * kBlock == j) {
+                    got[r] = cnt_j;
+                    ready[r] = true;
+                    __hip_atomic_store(&chunk_desc[j], (epoch16 << 16) | cnt_j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                  }
+              }
+            }
+          }
+          break;
+        }
+        if (spins > (1u << 22)) { // no help possible (patience switched off) and a predecessor never showed up
+          if (!all && err) atomicOr(err, kErrScanSpin);
+          break;
+        }
+        __builtin_amdgcn_s_sleep(1);
+#pragma unroll
+        for (uint32_t r = 0; r < kLook; ++r)
+          if (!ready[r]) {
+            const uint32_t d = __hip_atomic_load(&chunk_desc[threadIdx.x + r * kBlock], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            ready[r] = (d >> 16) == epoch16;
+            got[r] = ready[r] ? (d & 0xffffu) : 0u;
+          }
       }
+      uint32_t sum = got0;
+#pragma unroll
+      for (uint32_t r = 0; r < kLook; ++r) sum += got[r];
       (void)block_exclusive_scan(sum, smem, prefix);
     }
     if (c + 1 == chunks && threadIdx.x == 0) { // the last chunk knows the total
@@ -722,15 +787,16 @@ int ht_fill_impl(const ggms_hashtable_t *ht, const uint32_t *input, size_t n_max
     const uint32_t epoch = next_scan_epoch();
     const uint32_t epoch16 = epoch % 65535u + 1u; // never 0: a cleared descriptor is "not written"
     const uint32_t skip_below = poisoned ? 1u : 0u;
+    const uint32_t patience = poisoned ? kNoPatienceLimit : scan_patience(); // the poisoned launch tests the BOUND
     unsigned long long *desc0 = desc;             // chunk 0: 64-bit, carries the table's item count in
     if (di.batch)
       hipLaunchKernelGGL(k_owner_scan_chunked<true>, dim3(cgrid), dim3(kBlock), 0, s, di.w, di.version, ht->n2o, input,
                          di.cand, di.lost, di.tag, mapped, n, desc0, scratch.chunk, epoch, epoch16, ht->num_items_dev,
-                         mirror_a, mirror_b, err, skip_below);
+                         mirror_a, mirror_b, err, skip_below, patience);
     else
       hipLaunchKernelGGL(k_owner_scan_chunked<false>, dim3(cgrid), dim3(kBlock), 0, s, di.w, di.version, ht->n2o, input,
                          di.cand, di.lost, di.tag, mapped, n, desc0, scratch.chunk, epoch, epoch16, ht->num_items_dev,
-                         mirror_a, mirror_b, err, skip_below);
+                         mirror_a, mirror_b, err, skip_below, patience);
   } else {
     // Fewer workgroups than tiles on purpose: a workgroup takes tiles from the ticket one after the other, so by the
     // time tile t is taken the tiles before t - grid have finished and the look-back finds a published prefix in
@@ -765,6 +831,7 @@ extern "C" {
 
 // TableSize(num, scale = kDefaultScale = 2): cuda_hashtable.cu:146-149, cuda_hashtable.h:105
 void ggms_debug_poison_next_scan(void) { g_poison_next_scan.store(true); }
+void ggms_debug_set_scan_patience(uint32_t polls) { scan_patience_word().store(polls); }
 
 size_t ggms_hashtable_num_buckets(size_t capacity) {
   size_t half = capacity >> 1;

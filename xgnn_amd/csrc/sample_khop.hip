@@ -80,6 +80,29 @@ __device__ __forceinline__ uint32_t row_shr(uint32_t v) {
 // draws.  GPW = groups per wave64: 4 packs the lanes (large frontiers: the loop is issue-bound), 1 gives every
 // group a wave of its own (small frontiers: the chip has idle SIMDs and a group no longer waits for its three
 // neighbours); the idle lanes of a sparse wave still work in phase 5.
+// what tile t's descriptor holds -- the edges its 128 seeds will produce -- computed by one wave from the kernel's input
+// (scan_lookback's Help: a look-back that has waited long enough no longer depends on tile t's workgroup running)
+struct Khop3TileHelp {
+  static constexpr bool kCan = true;
+  const GraphView &g;
+  const uint32_t *input;
+  uint64_t n;
+  uint32_t fanout;
+  __device__ __forceinline__ uint32_t operator()(uint64_t t) const {
+    uint32_t acc = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < 2; ++k) {
+      const uint64_t i = 128 * t + 64 * k + (threadIdx.x & 63u);
+      if (i < n) {
+        uint32_t len;
+        (void)g.neighbours(input[i], len);
+        acc += len < fanout ? len : fanout;
+      }
+    }
+    return wave_reduce_sum(acc);
+  }
+};
+
 template <int GPW, bool INSERT>
 __global__ __launch_bounds__(128 * (4 / GPW)) void k_khop3_fused(GraphView g, const uint32_t *__restrict__ input,
                                                                  Count n_arg, uint32_t fanout, uint32_t fanout_magic,
@@ -108,8 +131,8 @@ __global__ __launch_bounds__(128 * (4 / GPW)) void k_khop3_fused(GraphView g, co
   bool dirty = false; // group-uniform: the set holds entries
 
   // A launch with a workgroup per tile (every layer but the largest ones) needs no ticket: tile = workgroup id, one
-  // memory round trip less on the tile's latency chain.  Workgroups are dispatched in id order, so a tile's predecessors
-  // run or are done when it looks back (the bounded wait covers anything else).
+  // memory round trip less on the tile's latency chain.  Nothing is assumed about when a predecessor's workgroup runs:
+  // a look-back that has waited long enough computes the missing aggregates itself (Khop3TileHelp).
   const bool one_tile_each = gridDim.x >= num_tiles; // uniform
   for (uint32_t turn = 0;; ++turn) {
     if (one_tile_each) {
@@ -263,7 +286,7 @@ __global__ __launch_bounds__(128 * (4 / GPW)) void k_khop3_fused(GraphView g, co
     if (threadIdx.x < kWave) {
       uint32_t prefix = 0;
       if (b != 0) {
-        prefix = scan_lookback(fs.desc, b, fs.epoch, fs.err);
+        prefix = scan_lookback(fs.desc, b, fs.epoch, fs.err, fs.patience, Khop3TileHelp{g, input, n, fanout});
         if (lane == 0)
           __hip_atomic_store(&fs.desc[b], scan_desc(fs.epoch, FLAG_P, prefix + s_off[128]), __ATOMIC_RELAXED,
                              __HIP_MEMORY_SCOPE_AGENT);
@@ -738,7 +761,7 @@ int sample_khop3_impl(GraphView g, const uint32_t *input, size_t n_max, Count n,
   else if (!shared_scan->cleared)
     GGMS_HIP(hipMemsetAsync(ctl, 0, (8 + 2 * (tiles + 1)) * sizeof(uint32_t), s));
   const FusedScan fs{tick, reinterpret_cast<unsigned long long *>(ctl + 8), next_scan_epoch(), num_out_dev,
-                     device_status_word()};
+                     device_status_word(), scan_patience()};
   const SrcMode sm{seed_local, src_local};
   // 64 slots up to fanout 31 (load < 0.5), else the reference's 128 (HASHTABLE_SIZE, khop3.cu:43)
   const uint32_t set_mask = fanout < 32 ? 63u : 127u;

@@ -80,6 +80,34 @@ __global__ __launch_bounds__(kBlock) void k_random_walk(GraphView g, const uint3
 // SPILL (more than kLdsVisits visits per seed -- far beyond PinSAGE's 12; the reference has no such bound, its
 // edge tables live in HBM): the lane's column is its own visit slice of tmp_dst / tmp_src, compacted in place (the
 // u-th distinct node lands at or before the visit it was read from), and every lane writes its own picks.
+// what tile t's descriptor holds -- sum over its T seeds of min(distinct visited nodes, K) -- computed by one wave from
+// the walk's visit lists (scan_lookback's Help).  Not for SPILL launches: those compact the lists in place.
+template <uint32_t T>
+struct WalkTileHelp {
+  static constexpr bool kCan = true;
+  const uint32_t *tmp_src, *tmp_dst;
+  uint64_t n, stride;
+  uint32_t per, K;
+  __device__ __forceinline__ uint32_t operator()(uint64_t t) const {
+    uint32_t acc = 0;
+    for (uint32_t j = 0; j < T / kWave; ++j) {
+      const uint64_t s = t * T + j * kWave + (threadIdx.x & 63u);
+      if (s >= n) continue;
+      uint32_t nu = 0;
+      for (uint32_t e = 0; e < per; ++e) {
+        if (tmp_src[(uint64_t)e * stride + s] == kEmptyKey) continue;
+        const uint32_t d = tmp_dst[(uint64_t)e * stride + s];
+        bool seen = false;
+        for (uint32_t f = 0; f < e; ++f)
+          seen |= tmp_src[(uint64_t)f * stride + s] != kEmptyKey && tmp_dst[(uint64_t)f * stride + s] == d;
+        nu += seen ? 0u : 1u;
+      }
+      acc += nu < K ? nu : K;
+    }
+    return wave_reduce_sum(acc);
+  }
+};
+
 template <uint32_t T, bool INSERT, bool SPILL>
 __global__ __launch_bounds__(T) void k_walk_topk_emit(uint32_t *tmp_src, uint32_t *tmp_dst, Count n_arg,
                                                       uint64_t stride, uint32_t per, uint32_t K, uint32_t Kc,
@@ -96,14 +124,15 @@ __global__ __launch_bounds__(T) void k_walk_topk_emit(uint32_t *tmp_src, uint32_
   const uint64_t num_tiles = (n + T - 1) / T;
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
   // A launch with a workgroup per tile (every layer but the largest ones) needs no ticket: tile = workgroup id, one
-  // memory round trip less on the tile's latency chain.  Workgroups are dispatched in id order, so a tile's predecessors
-  // run or are done when it looks back (the bounded wait covers anything else).
-  const bool one_tile_each = gridDim.x >= num_tiles; // uniform
+  // memory round trip less on the tile's latency chain.  Nothing is assumed about when a predecessor's workgroup runs:
+  // a look-back that has waited long enough computes the missing aggregates itself (WalkTileHelp).  SPILL launches
+  // rewrite their input, so they keep the strict ticket instead (a taken tile's predecessors are running).
+  const bool one_tile_each = !SPILL && gridDim.x >= num_tiles; // uniform
   for (uint32_t turn = 0;; ++turn) {
     if (one_tile_each) {
       if (turn != 0) break;
     } else {
-      if (tid == 0) s_tile = take_ticket(fs.tick);
+      if (tid == 0) s_tile = take_ticket(fs.tick, SPILL);
       __syncthreads();
     }
     const uint64_t b = one_tile_each ? (uint64_t)blockIdx.x : s_tile;
@@ -170,7 +199,8 @@ __global__ __launch_bounds__(T) void k_walk_topk_emit(uint32_t *tmp_src, uint32_
     if (tid < kWave) {
       uint32_t prefix = 0;
       if (b != 0) {
-        prefix = scan_lookback(fs.desc, b, fs.epoch, fs.err);
+        if (SPILL) prefix = scan_lookback(fs.desc, b, fs.epoch, fs.err);
+        else prefix = scan_lookback(fs.desc, b, fs.epoch, fs.err, fs.patience, WalkTileHelp<T>{tmp_src, tmp_dst, n, stride, per, K});
         if (lane == 0)
           __hip_atomic_store(&fs.desc[b], scan_desc(fs.epoch, FLAG_P, prefix + total), __ATOMIC_RELAXED,
                              __HIP_MEMORY_SCOPE_AGENT);
@@ -289,7 +319,7 @@ int sample_random_walk_impl(GraphView g, const uint32_t *input, size_t n_max, Co
   else if (!shared_scan->cleared)
     GGMS_HIP(hipMemsetAsync(ctl, 0, (8 + 2 * (tiles + 1)) * sizeof(uint32_t), s));
   const FusedScan fs{tick, reinterpret_cast<unsigned long long *>(ctl + 8), next_scan_epoch(), num_out_dev,
-                     device_status_word()};
+                     device_status_word(), scan_patience()};
   const SrcMode sm{seed_local, src_local};
   const bool spill = per > kLdsVisits;
   const size_t lds = spill ? 0 : 2 * (size_t)(per + Kc) * T * sizeof(uint32_t);

@@ -60,15 +60,18 @@ struct ScanArea {
 // counter, one failing ticket per workgroup at the end and a "last one out re-arms the counter" atomic on the
 // neighbouring word come to 10 K atomics on one line = 114 us of a 200-us kernel.  So the tickets of a launch come from
 // kTicketLanes counters 64 bytes apart: workgroup w draws from lane w % S, lane l hands out the tiles l, l + S,
-// l + 2 S, ...  A tile's predecessors are still either finished, or owned by a running workgroup, or the next ticket
-// of a lane whose workgroups only ever wait for LOWER tiles -- the smallest unfinished tile is never waited for by
-// the workgroups that could take it -- so the look-back keeps its forward progress.  Nothing is re-armed: every
-// ticketed launch of a batch has a ticket set of its own, all of them zeroed by the batch prologue.
+// l + 2 S, ...  A tile's predecessors are then no longer guaranteed to be running when it looks back (another lane's
+// next ticket may belong to a workgroup that has not started, and a second kernel's waiting workgroups may hold the
+// slot it needs): the look-backs of these kernels therefore compute a predecessor that does not show up for
+// themselves (scan_lookback's Help).  Nothing is re-armed: every ticketed launch of a batch has a ticket set of its
+// own, all of them zeroed by the batch prologue.
 constexpr uint32_t kTicketLanes = 32, kTicketStride = 16;
 constexpr uint32_t kTicketWords = kTicketLanes * kTicketStride; // one set
 constexpr uint32_t kTicketSets = 20;                             // per batch: one per ticketed sampler launch (<= 16 layers)
-__device__ __forceinline__ uint64_t take_ticket(uint32_t *set) { // one thread of the workgroup
-  const uint32_t lanes = gridDim.x < kTicketLanes ? gridDim.x : kTicketLanes;
+// strict: ONE counter -- a taken tile's predecessors are then always running or done (the forward-progress rule that
+// needs nothing else), at 11 ns per ticket: for kernels whose look-back cannot compute a predecessor for itself.
+__device__ __forceinline__ uint64_t take_ticket(uint32_t *set, bool strict = false) { // one thread of the workgroup
+  const uint32_t lanes = strict ? 1u : (gridDim.x < kTicketLanes ? gridDim.x : kTicketLanes);
   const uint32_t l = blockIdx.x % lanes;
   return (uint64_t)l + (uint64_t)lanes * atomicAdd(&set[kTicketStride * l], 1u);
 }
@@ -88,13 +91,37 @@ __device__ __forceinline__ unsigned long long scan_desc(uint32_t epoch, uint32_t
   return ((unsigned long long)((epoch << 2) | flag) << 32) | value;
 }
 
+// ---- a wait that does not depend on where or when another workgroup runs --------------------------------------------
+// HIP promises nothing about dispatch order or placement, and a workgroup that spins holds its slot: two kernels with
+// look-back chains on one device (two processes sharing a GPU, two batches in flight) can each fill the slots the
+// other's next workgroup needs, and then every resident workgroup waits for one that cannot start.  (Seen: two bench
+// ranks on one MI355X at papers100M size, GGMS_STATUS_SCAN_SPIN in half of the runs.)  So a look-back only waits
+// `patience` polls for a predecessor's descriptor; after that it COMPUTES the missing aggregates itself from the
+// scan's input (Help: tile -> what the tile's descriptor would hold; 64 lanes, result uniform) and publishes them.
+// Every resident workgroup therefore finishes whatever the others do.  The computed word is only used if the tile's
+// own word is still missing AFTER the inputs were read (its owner publishes before it overwrites anything: scans
+// that work in place stay exact).  NoHelp keeps the plain bounded wait (strictly ticketed kernels: a taken tile's
+// predecessors are always running).
+struct NoHelp {
+  static constexpr bool kCan = false;
+  __device__ __forceinline__ uint32_t operator()(uint64_t) const { return 0u; }
+};
+constexpr uint32_t kNoPatienceLimit = 0xffffffffu;
+inline std::atomic<uint32_t> &scan_patience_word() {
+  static std::atomic<uint32_t> v{2048u};
+  return v;
+}
+inline uint32_t scan_patience() { return scan_patience_word().load(std::memory_order_relaxed); }
+
 // Decoupled look-back, run by the 64 lanes of ONE wave: sum of the aggregates of the tiles before `tile`, back to
 // the nearest published inclusive prefix (which carries `base` in from tile 0).  64 predecessors per step.
 // Bounded: a protocol error must not hang the GPU -- after 2^22 polls the wave gives up, ORs kErrScanSpin into
 // the device status word (the host fails the batch on it) and returns what it has.
-__device__ __forceinline__ uint32_t scan_lookback(const unsigned long long *desc, uint64_t tile, uint32_t epoch,
-                                                  uint32_t *err) {
-  constexpr uint32_t FLAG_P = 2;
+template <typename Help = NoHelp>
+__device__ __forceinline__ uint32_t scan_lookback(unsigned long long *desc, uint64_t tile, uint32_t epoch,
+                                                  uint32_t *err, uint32_t patience = kNoPatienceLimit,
+                                                  const Help &help = Help()) {
+  constexpr uint32_t FLAG_A = 1, FLAG_P = 2;
   const uint32_t lane = threadIdx.x & 63u;
   uint32_t acc = 0;
   int64_t start = (int64_t)tile - 1; // nearest predecessor is read by lane 0
@@ -106,15 +133,35 @@ __device__ __forceinline__ uint32_t scan_lookback(const unsigned long long *desc
     const int64_t t = start - (int64_t)lane;
     unsigned long long d = scan_desc(epoch, FLAG_P, 0); // lanes past tile 0 read as "prefix 0"
     if (t >= 0) d = __hip_atomic_load(&desc[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const uint32_t tag = (uint32_t)(d >> 32);
-    const bool ready = (tag >> 2) == epoch && (tag & 3u) != 0;
-    const uint64_t pmask = __ballot(ready && (tag & 3u) == FLAG_P);
+    uint32_t tag = (uint32_t)(d >> 32);
+    bool ready = (tag >> 2) == epoch && (tag & 3u) != 0;
+    uint64_t pmask = __ballot(ready && (tag & 3u) == FLAG_P);
     const uint64_t rmask = __ballot(ready);
-    const uint32_t first_p = pmask ? (uint32_t)__builtin_ctzll(pmask) : 64u;
+    uint32_t first_p = pmask ? (uint32_t)__builtin_ctzll(pmask) : 64u;
     const uint64_t needed = first_p < 64u ? ((first_p == 63u) ? ~0ull : ((1ull << (first_p + 1)) - 1ull)) : ~0ull;
     if ((rmask & needed) != needed) { // a descriptor between us and the nearest prefix is not written yet
-      __builtin_amdgcn_s_sleep(1);
-      continue;
+      if (!Help::kCan || spins < patience) {
+        __builtin_amdgcn_s_sleep(1);
+        continue;
+      }
+      uint64_t missing = needed & ~rmask; // uniform; lanes past tile 0 are ready by construction
+      while (missing) {
+        const uint32_t bpos = (uint32_t)__builtin_ctzll(missing);
+        missing &= missing - 1ull;
+        const uint64_t tt = (uint64_t)(start - (int64_t)bpos);
+        const uint32_t h = help(tt);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the inputs were READ before the word is looked at again
+        const unsigned long long now = __hip_atomic_load(&desc[tt], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t ntag = (uint32_t)(now >> 32);
+        const bool there = (ntag >> 2) == epoch && (ntag & 3u) != 0;
+        const unsigned long long mine = scan_desc(epoch, tt == 0 ? FLAG_P : FLAG_A, h);
+        if (!there && lane == 0) __hip_atomic_store(&desc[tt], mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lane == bpos) d = there ? now : mine;
+      }
+      tag = (uint32_t)(d >> 32);
+      ready = (tag >> 2) == epoch && (tag & 3u) != 0;
+      pmask = __ballot(ready && (tag & 3u) == FLAG_P);
+      first_p = pmask ? (uint32_t)__builtin_ctzll(pmask) : 64u;
     }
     const uint32_t mine = (lane <= first_p || first_p == 64u) ? (uint32_t)d : 0u;
     acc += wave_reduce_sum(mine);
@@ -131,6 +178,24 @@ struct FusedScan {
   uint32_t epoch;
   uint64_t *num_out;         // total number of edges
   uint32_t *err;
+  uint32_t patience;         // polls before a look-back serves itself (scan_patience())
+};
+
+// what tile t's descriptor holds, computed by one wave from the scan's input (scan_lookback's Help)
+template <typename ValueF>
+struct TileSumHelp {
+  static constexpr bool kCan = true;
+  const ValueF &value;
+  uint64_t n;
+  uint32_t base;
+  __device__ __forceinline__ uint32_t operator()(uint64_t t) const {
+    uint32_t acc = 0;
+    for (uint32_t k = 0; k < kTile / kWave; ++k) {
+      const uint64_t i = t * kTile + k * kWave + (threadIdx.x & 63u);
+      if (i < n) acc += value(i);
+    }
+    return wave_reduce_sum(acc) + (t == 0 ? base : 0u);
+  }
 };
 
 template <typename ValueF, typename EmitF>
@@ -138,17 +203,20 @@ __global__ __launch_bounds__(kBlock) void k_tile_scan(ValueF value, EmitF emit, 
                                                       unsigned long long *desc, uint32_t epoch,
                                                       const uint32_t *base_in, uint32_t *total32_out,
                                                       uint64_t *total64_out, uint64_t *mirror_a, uint64_t *mirror_b,
-                                                      uint32_t *err) {
+                                                      uint32_t *err, uint32_t patience) {
   constexpr uint32_t ROUNDS = kTile / kBlock, FLAG_A = 1, FLAG_P = 2;
   __shared__ uint32_t smem[kBlock / kWave];
   __shared__ uint32_t s_tile, s_prefix;
   const uint64_t n = n_arg.get();
   const uint64_t num_tiles = (n + kTile - 1) / kTile;
-  const uint32_t base = base_in ? *base_in : 0u; // read before anybody can overwrite it (total32_out may alias)
+  // total32_out may alias base_in (a running count updated in place): the last tile overwrites it, but only after
+  // tile 0's descriptor is out -- so whoever finds that descriptor missing AFTER this read has read the old value
+  // (tile 0's owner and the look-backs that compute tile 0 for themselves check exactly that)
+  const uint32_t base_seen = base_in ? *base_in : 0u;
   // Up to kSinglePassTiles workgroups (the default use of this kernel) take tile = workgroup id: a ticket and an exit
   // count from one word are 2 x 256 same-address atomics, 11 ns each (tools/micro_ticket.hip) -- most of an 8-us launch.
-  // That many workgroups are resident together and are dispatched in id order, so a tile's predecessors are running;
-  // the bounded look-back turns anything else into the status word.  Larger grids (GGMS_SCAN=1) keep the ticket.
+  // A predecessor that has not started (nothing is promised about dispatch order) is computed by whoever waits for it
+  // (scan_lookback, TileSumHelp).  Larger grids (GGMS_SCAN=1) keep the ticket.
   const bool ticketed = gridDim.x > kSinglePassTiles;
   for (uint64_t round = 0;; ++round) {
     if (ticketed) {
@@ -169,14 +237,19 @@ __global__ __launch_bounds__(kBlock) void k_tile_scan(ValueF value, EmitF emit, 
     }
     if (threadIdx.x < kWave) { // wave 0 publishes and looks back, 64 predecessors per step
       const uint32_t lane = threadIdx.x;
-      uint32_t prefix = base;
+      uint32_t prefix = base_seen;
       if (tile == 0) {
+        if (base_in) { // somebody who could not wait may have computed this tile's word already (and the total may be out)
+          asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+          const unsigned long long d0 = __hip_atomic_load(&desc[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if ((uint32_t)(d0 >> 34) == epoch && ((uint32_t)(d0 >> 32) & 3u) == FLAG_P) prefix = (uint32_t)d0 - running;
+        }
         if (lane == 0)
-          __hip_atomic_store(&desc[0], scan_desc(epoch, FLAG_P, base + running), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(&desc[0], scan_desc(epoch, FLAG_P, prefix + running), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       } else {
         if (lane == 0)
           __hip_atomic_store(&desc[tile], scan_desc(epoch, FLAG_A, running), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const uint32_t acc = scan_lookback(desc, tile, epoch, err);
+        const uint32_t acc = scan_lookback(desc, tile, epoch, err, patience, TileSumHelp<ValueF>{value, n, base_seen});
         prefix = acc; // already includes `base` through tile 0's inclusive prefix
         if (lane == 0)
           __hip_atomic_store(&desc[tile], scan_desc(epoch, FLAG_P, prefix + running), __ATOMIC_RELAXED,
@@ -187,7 +260,7 @@ __global__ __launch_bounds__(kBlock) void k_tile_scan(ValueF value, EmitF emit, 
         if (tile + 1 == num_tiles) { // the last tile knows the grand total
           const uint32_t total = prefix + running;
           if (total32_out) *total32_out = total;
-          if (total64_out) *total64_out = (uint64_t)(total - base);
+          if (total64_out) *total64_out = (uint64_t)(total - base_seen); // nobody but this tile overwrites base_in
           if (mirror_a) *mirror_a = (uint64_t)total;
           if (mirror_b) *mirror_b = (uint64_t)total;
         }
@@ -204,10 +277,10 @@ __global__ __launch_bounds__(kBlock) void k_tile_scan(ValueF value, EmitF emit, 
   }
   if (threadIdx.x == 0) {
     if (num_tiles == 0 && blockIdx.x == 0) { // empty input: totals = base
-      if (total32_out) *total32_out = base;
+      if (total32_out) *total32_out = base_seen;
       if (total64_out) *total64_out = 0;
-      if (mirror_a) *mirror_a = (uint64_t)base;
-      if (mirror_b) *mirror_b = (uint64_t)base;
+      if (mirror_a) *mirror_a = (uint64_t)base_seen;
+      if (mirror_b) *mirror_b = (uint64_t)base_seen;
     }
     // the last block out re-arms the control words for the next launch on this scratch
     if (ticketed && atomicAdd(&ctl[1], 1u) == gridDim.x - 1) {
@@ -397,7 +470,8 @@ inline int tile_scan(ValueF value, EmitF emit, size_t n_max, Count n, ScanArea a
     return GGMS_OK;
   }
   hipLaunchKernelGGL((k_tile_scan<ValueF, EmitF>), dim3(grid), dim3(kBlock), 0, stream, value, emit, n, ctl, desc,
-                     next_scan_epoch(), base_in, total32_out, total64_out, mirror_a, mirror_b, device_status_word());
+                     next_scan_epoch(), base_in, total32_out, total64_out, mirror_a, mirror_b, device_status_word(),
+                     scan_patience());
   GGMS_LAUNCH_CHECK();
   return GGMS_OK;
 }
