@@ -723,6 +723,9 @@ def main():
         if world == 1:
             engine = engine_record(datagen, graph, fanouts, args, log)
         else:  # rank 0 runs the child (which forks one engine worker per GPU), the other ranks wait
+            extract_main = keep_main = None  # the engine's workers build their own shards on these GPUs
+            torch.cuda.empty_cache()
+            barrier()
             if rank == 0:
                 engine = engine_record(datagen, graph, fanouts, args, log, workers=world,
                                        force_device=os.environ.get("GGMS_BENCH_DEVICE"))
