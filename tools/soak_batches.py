@@ -3,6 +3,7 @@ running beside them, every batch compared with the oracle -- hunts for rare inte
 look-back / dedup protocols that the small parity cases cannot provoke.
 
     python tools/soak_batches.py [num_batches] [sample_type]
+    GGMS_TEST_SCAN_PATIENCE=0 python tools/soak_batches.py ...      the scans' look-backs never wait (self-serve path)
 """
 import os
 import sys
@@ -16,6 +17,9 @@ sys.path.insert(0, ROOT)
 import oracle  # noqa: E402
 from xgnn_amd import datagen, ops  # noqa: E402
 
+if os.environ.get("GGMS_TEST_SCAN_PATIENCE") is not None:  # 0: every look-back that finds a word missing serves itself
+    from xgnn_amd import lib  # noqa: E402
+    lib().ggms_debug_set_scan_patience(int(os.environ["GGMS_TEST_SCAN_PATIENCE"]))
 nb = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 stype = sys.argv[2] if len(sys.argv) > 2 else "khop3"
 code = {"khop3": ops.KHOP3, "khop0": ops.KHOP0, "khop1": ops.KHOP1, "khop2": ops.KHOP2,
