@@ -228,7 +228,7 @@ __global__ __launch_bounds__(kWave) void k_weighted_hash_dedup(const uint32_t *_
   __shared__ uint32_t picked[SPW][kDedupSlots];                          // the current seed's accepted picks, in order
   const uint64_t n = n_arg.get();
   const uint32_t lane = threadIdx.x, g = lane / G, lig = lane % G, grp_shift = lane & ~(G - 1u);
-  constexpr uint32_t GMASK = (1u << G) - 1u, WPB = kBlock / SPW; // waves per reference block of 256 streams
+  constexpr uint32_t GMASK = G >= 32 ? 0xffffffffu : (1u << (G & 31u)) - 1u, WPB = kBlock / SPW; // waves per reference block of 256 streams
   uint32_t *const tv = val[g], *const tr = round_of[g];
   const uint64_t num_tiles = (n + 1023) / 1024;
   for (uint64_t q = blockIdx.x; q < WPB * num_tiles; q += gridDim.x) { // WPB waves x SPW streams = one reference block
@@ -240,13 +240,30 @@ __global__ __launch_bounds__(kWave) void k_weighted_hash_dedup(const uint32_t *_
     Xorwow st;
     st.load(states + 6 * sid);
     bool drew = false;
+    // the stream's four seeds are known up front: their ids, list bounds and output offsets are fetched together (the
+    // seeds themselves must be served one after the other: the generator's state after a seed depends on its tries)
+    uint32_t rid_[4], off_[4], len_[4], o_[4], sv_[4];
+#pragma unroll
+    for (uint32_t r = 0; r < 4; ++r) {
+      const uint64_t index = b * 1024 + tb + (uint64_t)r * kBlock;
+      rid_[r] = index < n ? input[index] : 0u;
+    }
+#pragma unroll
+    for (uint32_t r = 0; r < 4; ++r) {
+      const uint64_t index = b * 1024 + tb + (uint64_t)r * kBlock;
+      off_[r] = len_[r] = o_[r] = sv_[r] = 0;
+      if (index < n) {
+        off_[r] = indptr[rid_[r]];
+        len_[r] = indptr[rid_[r] + 1] - off_[r];
+        o_[r] = offset[index];
+        sv_[r] = sm.value(rid_[r], index);
+      }
+    }
+#pragma unroll
     for (uint32_t r = 0; r < 4; ++r) {
       const uint64_t index = b * 1024 + tb + (uint64_t)r * kBlock;
       if (index >= n) break;
-      const uint32_t rid = input[index];
-      const uint32_t off = indptr[rid], len = indptr[rid + 1] - off;
-      const uint32_t o = offset[index];
-      const uint32_t sv = sm.value(rid, index);
+      const uint32_t rid = rid_[r], off = off_[r], len = len_[r], o = o_[r], sv = sv_[r];
       if (len <= fanout) {
         for (uint32_t j = lig; j < len; j += G) {
           const uint32_t nbr = indices[off + j];
@@ -397,24 +414,32 @@ int sample_weighted_hash_dedup_impl(const uint32_t *indptr, const uint32_t *indi
   const SrcMode sm{seed_local, src_local};
   const DedupInsert di = insert ? *insert : DedupInsert{};
   const size_t blocks = (n_max + 1023) / 1024; // reference blocks of 256 streams
-  // Tries per round = G R: about 1.5 x fanout, so that an ordinary seed is done in one round trip.  G = lanes that
-  // share a stream: 16.  Four lanes per stream with 16 tries each (a quarter of the generator instructions per
-  // stream) were built and measured SLOWER on the large products layer (kernel 350 -> 440 us): a wave then waits for
-  // the slowest of 16 streams instead of 4, and the try-order loop runs 16 rounds of 4-lane ballots.
-  // GGMS_HASH_DEDUP_G=4 selects that variant (measurement hook; same results).
+  // G = lanes that share a stream: 16; tries per round = G R with R = 1.  "About 1.5 x fanout tries per round, so that
+  // an ordinary seed is done in one round trip" (R = 4 at fanout 25) was the first choice and measured WORSE: 128
+  // generator steps per lane and round and 120 VGPRs (the large products layer's 5312 waves did not fit the chip at
+  // once) against 32 steps and 71 VGPRs -- step 0.62 -> 0.52 ms on products with two or three round trips per seed
+  // (profiles/r03_ab_hash_dedup_tries_per_round.txt; R = 2: 0.55, R = 3: 0.59).  Four lanes per stream with 16 tries
+  // each (a quarter of the generator instructions per stream) were built and measured slower too (a wave then waits
+  // for the slowest of 16 streams instead of 4), as were 8 and 32 lanes per stream.
+  // GGMS_HASH_DEDUP_G = 4 / 8 / 32 and GGMS_HASH_DEDUP_R = 1..4 select those variants (measurement hooks; same results).
   static const int pin_g = [] { const char *e = getenv("GGMS_HASH_DEDUP_G"); return e ? atoi(e) : 0; }();
   const bool narrow = pin_g == 4;
 #define GGMS_HD(GG, RR)                                                                                              \
   hipLaunchKernelGGL((k_weighted_hash_dedup<GG, RR>), dim3((unsigned)std::min<size_t>((256 / (64 / GG)) * blocks, 8192)), \
                      dim3(kWave), 0, s, indptr, indices, prob, alias, input, n, fanout, offset, out_src, out_dst, states, \
                      sm, di)
-  if (narrow) {
+  if (pin_g == 32) {
+    GGMS_HD(32, 1);
+  } else if (narrow) {
     if (fanout <= 8) GGMS_HD(4, 4);
     else if (fanout <= 20) GGMS_HD(4, 8);
     else GGMS_HD(4, 16);
   } else {
-    if (fanout <= 8) GGMS_HD(16, 1);
-    else if (fanout <= 20) GGMS_HD(16, 2);
+    static const int pin_r = [] { const char *e = getenv("GGMS_HASH_DEDUP_R"); return e ? atoi(e) : 0; }();
+    const int r = pin_r >= 1 && pin_r <= 4 ? pin_r : 1;
+    if (r == 1) GGMS_HD(16, 1);
+    else if (r == 2) GGMS_HD(16, 2);
+    else if (r == 3) GGMS_HD(16, 3);
     else GGMS_HD(16, 4);
   }
 #undef GGMS_HD
