@@ -154,6 +154,21 @@ nodes = np.random.RandomState(2).randint(0, N, 3000).astype(np.uint32)
 out = torch.zeros((3000, dim), dtype=torch.float32, device=dev)
 st.extract(torch.from_numpy(nodes.view(np.int32)).to(dev), 3000, out)
 assert out.cpu().numpy().tobytes() == oracle.extract(feat, nodes).tobytes()
+# the other collectives bench.py and connect_peers issue at N > 1, on the same backend: object broadcast / gather
+# (staged on the device by RCCL, the gather from the deadline helper thread), the timing barrier, float64 reductions
+where = ["/dev/shm/somewhere"]
+dist.broadcast_object_list(where, src=0)
+assert where == ["/dev/shm/somewhere"]
+got = [None]
+ggms_store.with_deadline(lambda: dist.all_gather_object(got, (b"h" * 64, 123)), "all_gather_object", seconds=60)
+assert got == [(b"h" * 64, 123)]
+dist.barrier()
+torch.cuda.synchronize()
+stats = torch.tensor([1.5, 2.0, 3.0], dtype=torch.float64, device=dev)
+mx, sm = stats.clone(), stats.clone()
+dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+dist.all_reduce(sm, op=dist.ReduceOp.SUM)
+assert mx.tolist() == [1.5, 2.0, 3.0] and sm.tolist() == [1.5, 2.0, 3.0]
 dist.destroy_process_group()
 print("nccl-ok")
 """
