@@ -610,6 +610,7 @@ __global__ __launch_bounds__(kBlock) void k_owner_scan_chunked(unsigned long lon
                   } else { // still missing: the total (which needs this word) had not replaced *num_items at v1's time
                     got0 = v1 + cnt_j;
                     __hip_atomic_store(desc0, scan_desc(epoch, FLAG_P, got0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // out before this chunk (if it is the last) writes the total
                   }
                   ready0 = true;
                 }

@@ -156,6 +156,9 @@ __device__ __forceinline__ uint32_t scan_lookback(unsigned long long *desc, uint
         const bool there = (ntag >> 2) == epoch && (ntag & 3u) != 0;
         const unsigned long long mine = scan_desc(epoch, tt == 0 ? FLAG_P : FLAG_A, h);
         if (!there && lane == 0) __hip_atomic_store(&desc[tt], mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // the word is OUT before this wave goes on: if it is the last tile, the total it writes (over a count that tile
+        // 0's word was computed from) must not become visible before that word
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (lane == bpos) d = there ? now : mine;
       }
       tag = (uint32_t)(d >> 32);
