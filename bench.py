@@ -72,10 +72,13 @@ def parse():
                          "inside the gather kernel over xGMI (hipIpc); 'a2a' = same shards, rows exchanged with RCCL "
                          "all-to-all; 'hybrid' = the --replicate-frac hottest rows (degree rank) on every GPU, the tail "
                          "sharded; 'replica' = every GPU holds all cached rows (DP over seeds only)")
-    ap.add_argument("--replicate-frac", default="0.25",
-                    help="hybrid store: fraction of the cached rows replicated on every GPU, or 'auto' = the largest "
-                         "prefix that fits --hbm-budget-gb per GPU (ggms_store.plan_replication)")
-    ap.add_argument("--hbm-budget-gb", type=float, default=24.0, help="hybrid store with --replicate-frac auto")
+    ap.add_argument("--replicate-frac", default="auto",
+                    help="hybrid store: 'auto' (default) = the largest hot prefix whose replica + this GPU's share of the "
+                         "sharded rest fits --hbm-budget-gb per GPU (ggms_store.plan_replication), or a fraction of the "
+                         "cached rows")
+    ap.add_argument("--hbm-budget-gb", type=float, default=48.0,
+                    help="hybrid store with --replicate-frac auto: HBM one GPU may spend on feature rows (default 48 of "
+                         "the 288 GB: papers100M's 57-GB table is then 0.82 replicated, the rest sharded)")
     ap.add_argument("--other-stores", default="replica,hybrid",
                     help="N > 1: stores measured after the main timed region (one block) and reported under 'stores'")
     ap.add_argument("--neighbour-skew", type=float, default=0.0,
@@ -406,6 +409,8 @@ def main():
         del tmp
         log("host tier filled")
 
+    hybrid_plan = {}
+
     def build_store(kind):
         """-> (extract(nodes, num_max, out, num_dev, counters), what it keeps alive) for one store kind."""
         log(f"building store {kind}")
@@ -434,6 +439,8 @@ def main():
             R = (ggms_store.plan_replication(num_cached, row_bytes, world, int(args.hbm_budget_gb * 1e9))
                  if args.replicate_frac == "auto" else int(num_cached * float(args.replicate_frac)))
             R = min(R, num_cached - world)  # keep a sharded tail
+            hybrid_plan.update(replicated_rows=int(R), replicated_fraction=R / max(1, num_cached),
+                               hbm_budget_gb=args.hbm_budget_gb if args.replicate_frac == "auto" else None)
         if full and R == 0:
             order, table = torch.arange(N, dtype=torch.int64, device=dev), None
         else:
@@ -705,7 +712,8 @@ def main():
                     "feature_extract_GBps": b["feat_rate_all"], "rows_per_step": b["rows_all"] / args.steps,
                     "remote_row_fraction": remote_rows / max(1.0, b["rows_all"]),
                     "xgmi_bytes_per_step": remote_rows * row_bytes / args.steps,
-                    "rows_by_tier": {"host": t[0], "remote_shard": t[1], "local_shard": t[2], "replica": t[3]}}
+                    "rows_by_tier": {"host": t[0], "remote_shard": t[1], "local_shard": t[2], "replica": t[3]},
+                    **(hybrid_plan if kind == "hybrid" else {})}
         stores = {main_store: store_record(blk, main_store)}
         for kind in [k for k in args.other_stores.split(",") if k and k != main_store]:
             extract_main = keep_main = None

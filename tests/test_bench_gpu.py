@@ -62,7 +62,9 @@ def test_two_ranks_default_is_the_sharded_store():
     assert set(st) == {"peer", "replica", "hybrid"}
     assert 0.3 < st["peer"]["remote_row_fraction"] < 0.7 and st["peer"]["xgmi_bytes_per_step"] > 0
     assert st["replica"]["remote_row_fraction"] == 0 and st["replica"]["xgmi_bytes_per_step"] == 0
-    assert 0 < st["hybrid"]["remote_row_fraction"] < st["peer"]["remote_row_fraction"]
+    # default plan: the largest hot prefix that fits the per-GPU budget is replicated (at this size: all but the tail)
+    assert 0 <= st["hybrid"]["remote_row_fraction"] < st["peer"]["remote_row_fraction"]
+    assert st["hybrid"]["replicated_fraction"] > 0.9 and st["hybrid"]["hbm_budget_gb"] == 48.0
 
 
 _BROKEN_IPC = """
@@ -121,7 +123,8 @@ def test_five_ranks_one_gpu_peer_and_hybrid():
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
     env.update(GGMS_BENCH_DEVICE="0", GGMS_BENCH_BACKEND="gloo")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "5", "--preset", "tiny", "--steps", "3",
-                        "--warmup", "1", "--batch", "128", "--repeats", "1", "--other-stores", "hybrid", "--no-engine"],
+                        "--warmup", "1", "--batch", "128", "--repeats", "1", "--other-stores", "hybrid", "--replicate-frac", "0.25",
+                        "--no-engine"],
                        capture_output=True, text=True, timeout=1200, cwd=ROOT, env=env)
     assert r.returncode == 0, r.stderr[-3000:]
     d = _last_json(r.stdout)
@@ -238,7 +241,7 @@ def test_configs4_friendster_pinsage_hybrid_store_full_size():
     walks, hybrid GGMS -- the hotter half of the rows in HBM (a quarter of those replicated on both ranks, the rest
     sharded), every row also in pinned host DRAM; one gather serves replica, local shard, peer shard and host rows."""
     d = _two_ranks_full_size(["--preset", "friendster", "--sample-type", "random_walk", "--fanout", "5,5,5",
-                              "--store", "hybrid", "--cache-ratio", "0.5"], timeout=1200)
+                              "--store", "hybrid", "--cache-ratio", "0.5", "--replicate-frac", "0.25"], timeout=1200)
     assert d["rows_verified"] and d["n_gpus"] == 2 and "N=65608366" in d["config"]["workload"]
     t = d["stores"]["hybrid"]["rows_by_tier"]
     assert min(t["host"], t["remote_shard"], t["local_shard"], t["replica"]) > 0
