@@ -59,8 +59,11 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline: keep sampling mini-batches this long")
     ap.add_argument("--host-steps", type=int, default=10, help="timed steps of the host-tier sub-record")
     ap.add_argument("--host-profile", action="store_true", help="print host enqueue time per section to stderr")
-    ap.add_argument("--pipelines", type=int, default=1,
-                    help="sampling batches in flight (each on its own stream with its own dedup table)")
+    ap.add_argument("--pipelines", type=int, default=None,
+                    help="sampling batches in flight (each on its own stream with its own dedup table).  Default 1; 2 for "
+                         "khop0, whose generator is re-seeded per launch -- its batches do not have to consume a shared "
+                         "generator pool in order, so a second one in flight fills the first one's latency chains "
+                         "(profiles/r03_ab_pipelines_products.txt)")
     ap.add_argument("--heavy-after-gather", action="store_true",
                     help="the last (largest) layer's sampler launch of batch k+1 waits for the gather of batch k: the two "
                          "fabric-heaviest kernels run one after the other, the smaller layers still overlap the gather")
@@ -482,6 +485,8 @@ def main():
         extra_kw = dict(random_walk_length=3, random_walk_restart_prob=0.5, num_random_walk=4)
     # batches in flight: K sampling pipelines (own stream, dedup table, workspace; RNG pool consumed in batch
     # order) + the extract stream; outputs live in batch slots, as in the engine
+    if args.pipelines is None:
+        args.pipelines = 2 if args.sample_type == "khop0" else 1
     K = 1 if args.no_overlap else max(1, args.pipelines)
     NSLOT = K + 1
     sampler = ops.BatchSampler(g, fanouts, args.batch, sample_type=code, seed=0x5EED + rank, device=dev,
