@@ -60,3 +60,35 @@ def test_split_and_hub_graph(ops, impatient):
 def test_full_size_batch(ops, impatient):
     P.test_full_size_batch_properties(ops)
     assert ops.device_status() == 0
+
+
+@pytest.mark.parametrize("n", [5000, 300_000])
+def test_owner_of_the_first_chunk_arrives_after_the_total_is_out(ops, n):
+    """The table already holds items (its count is updated IN PLACE by the scan).  Chunk 0's workgroup is held back for
+    about 2 ms; with a patience of 4 polls every other chunk counts chunk 0 itself, the last one replaces the count by
+    the total -- and only then does chunk 0's owner start: it must take the base from the word the others published,
+    not from the (already overwritten) count.  Local ids, the unique list and the count stay the oracle's."""
+    import numpy as np
+    import oracle
+    from xgnn_amd import lib
+    rng = np.random.RandomState(n)
+    universe = n // 2 + 7
+    ht = ops.OrderedHashTable(4 * n + 16, num_node=universe + 1)
+    orc = oracle.HashTable(universe + 1, 4 * n + 16)
+    ht.reset()
+    orc.reset()
+    first = rng.randint(0, universe, n // 3).astype(np.uint32)
+    P._check_fill(ops, ht, orc, first)  # base != 0 for the fill under test
+    assert ht.num_items > 0
+    lib().ggms_debug_set_scan_patience(4)
+    try:
+        for _ in range(3):
+            items = rng.randint(0, universe, n).astype(np.uint32)
+            lib().ggms_debug_delay_next_scan(500)  # one shot: about 2 ms
+            P._check_fill(ops, ht, orc, items)
+            ns, _ = ht.map_edges(P.dev(items), None)
+            os_, _ = orc.map_edges(items, items)
+            np.testing.assert_array_equal(P.host_u32(ns), os_)
+        assert ops.device_status() == 0
+    finally:
+        lib().ggms_debug_set_scan_patience(2048)

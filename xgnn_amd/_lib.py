@@ -48,6 +48,7 @@ SYMBOLS = {
     "ggms_device_status": (_i, [C.POINTER(_u32), _i]),
     "ggms_debug_poison_next_scan": (None, []),
     "ggms_debug_set_scan_patience": (None, [C.c_uint32]),
+    "ggms_debug_delay_next_scan": (None, [C.c_uint32]),
     "ggms_fabric_probe": (_i, [_i, _vp, _sz, _sz, _u32, _vp, _vp]),
     "ggms_dtype_bytes": (_sz, [_i]),
     "ggms_random_states_init": (_i, [_vp, _sz, _u64, _vp]),

@@ -474,7 +474,7 @@ __global__ __launch_bounds__(kBlock) void k_owner_scan_chunked(unsigned long lon
                                                                uint32_t *chunk_desc, uint32_t epoch, uint32_t epoch16,
                                                                uint32_t *num_items, uint64_t *mirror_a,
                                                                uint64_t *mirror_b, uint32_t *err, uint32_t skip_below,
-                                                               uint32_t patience) {
+                                                               uint32_t patience, uint32_t delay0) {
   constexpr uint32_t FLAG_P = 2;
   __shared__ uint32_t smem[kBlock / kWave];
   __shared__ uint32_t s_total;
@@ -493,6 +493,10 @@ __global__ __launch_bounds__(kBlock) void k_owner_scan_chunked(unsigned long lon
   // nothing is assumed about when their workgroups run -- a chunk that has waited `patience` polls counts the missing
   // ones itself (below), so every resident workgroup finishes whatever else holds the device's slots.
   const uint32_t c = blockIdx.x;
+  // ggms_debug_delay_next_scan (tests): chunk 0's workgroup "starts late" -- after the others have counted its chunk
+  // themselves and the last one has replaced *num_items by the total
+  if (c == 0 && delay0)
+    for (uint32_t i = 0; i < delay0; ++i) __builtin_amdgcn_s_sleep(127);
   uint32_t base_seen = 0;
   unsigned long long d0_seen = 0;
   if (c == 0) { // the table's item count, and THEN whether somebody has computed this chunk's word already (see below)
@@ -690,6 +694,7 @@ __global__ __launch_bounds__(kBlock) void k_owner_scan_chunked(unsigned long lon
 }
 
 static std::atomic<bool> g_poison_next_scan{false};
+static std::atomic<uint32_t> g_delay_next_scan{0};
 
 static size_t owner_scan_grid_cap() { // GGMS_OSCAN_GRID: measurement hook
   static const size_t v = [] { const char *e = getenv("GGMS_OSCAN_GRID"); const long x = e ? atol(e) : 0; return x > 0 ? (size_t)x : (size_t)512; }();
@@ -789,15 +794,16 @@ int ht_fill_impl(const ggms_hashtable_t *ht, const uint32_t *input, size_t n_max
     const uint32_t epoch16 = epoch % 65535u + 1u; // never 0: a cleared descriptor is "not written"
     const uint32_t skip_below = poisoned ? 1u : 0u;
     const uint32_t patience = poisoned ? kNoPatienceLimit : scan_patience(); // the poisoned launch tests the BOUND
+    const uint32_t delay0 = g_delay_next_scan.exchange(0);
     unsigned long long *desc0 = desc;             // chunk 0: 64-bit, carries the table's item count in
     if (di.batch)
       hipLaunchKernelGGL(k_owner_scan_chunked<true>, dim3(cgrid), dim3(kBlock), 0, s, di.w, di.version, ht->n2o, input,
                          di.cand, di.lost, di.tag, mapped, n, desc0, scratch.chunk, epoch, epoch16, ht->num_items_dev,
-                         mirror_a, mirror_b, err, skip_below, patience);
+                         mirror_a, mirror_b, err, skip_below, patience, delay0);
     else
       hipLaunchKernelGGL(k_owner_scan_chunked<false>, dim3(cgrid), dim3(kBlock), 0, s, di.w, di.version, ht->n2o, input,
                          di.cand, di.lost, di.tag, mapped, n, desc0, scratch.chunk, epoch, epoch16, ht->num_items_dev,
-                         mirror_a, mirror_b, err, skip_below, patience);
+                         mirror_a, mirror_b, err, skip_below, patience, delay0);
   } else {
     // Fewer workgroups than tiles on purpose: a workgroup takes tiles from the ticket one after the other, so by the
     // time tile t is taken the tiles before t - grid have finished and the look-back finds a published prefix in
@@ -833,6 +839,7 @@ extern "C" {
 // TableSize(num, scale = kDefaultScale = 2): cuda_hashtable.cu:146-149, cuda_hashtable.h:105
 void ggms_debug_poison_next_scan(void) { g_poison_next_scan.store(true); }
 void ggms_debug_set_scan_patience(uint32_t polls) { scan_patience_word().store(polls); }
+void ggms_debug_delay_next_scan(uint32_t sleeps) { g_delay_next_scan.store(sleeps); }
 
 size_t ggms_hashtable_num_buckets(size_t capacity) {
   size_t half = capacity >> 1;
