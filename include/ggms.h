@@ -86,10 +86,10 @@ void ggms_debug_poison_next_scan(void);
  * progress depends on when or where another one runs (two processes or two batches sharing a GPU).  0: never wait
  * (tests: every look-back that finds a word missing takes the self-serve path); 0xffffffff: never help. */
 void ggms_debug_set_scan_patience(uint32_t polls);
-/* Test aid: in the next chunked owner scan of a direct-layout table fill (this process) the workgroup of chunk 0 sleeps
- * `sleeps` x s_sleep(127) (about 4 us each) before it reads anything -- with a small patience the other chunks count
- * chunk 0 themselves and the last one replaces the table's item count by the total before chunk 0's owner starts:
- * the "owner arrives late" case of the self-serve look-back.  One shot. */
+/* Test aid: in the next single-pass ordered scan of this process (the owner scan of a table fill, either layout) the
+ * workgroup of tile / chunk 0 sleeps `sleeps` x s_sleep(127) (about 4 us each) before it reads anything -- with a small
+ * patience the others compute its word themselves and the last one replaces the table's item count by the total before
+ * that workgroup starts: the "owner arrives late" case of the self-serve look-back.  One shot. */
 void ggms_debug_delay_next_scan(uint32_t sleeps);
 size_t ggms_dtype_bytes(int dtype);
 

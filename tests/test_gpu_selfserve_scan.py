@@ -62,8 +62,8 @@ def test_full_size_batch(ops, impatient):
     assert ops.device_status() == 0
 
 
-@pytest.mark.parametrize("n", [5000, 300_000])
-def test_owner_of_the_first_chunk_arrives_after_the_total_is_out(ops, n):
+@pytest.mark.parametrize("n,direct", [(5000, True), (300_000, True), (60_000, False)])
+def test_owner_of_the_first_chunk_arrives_after_the_total_is_out(ops, n, direct):
     """The table already holds items (its count is updated IN PLACE by the scan).  Chunk 0's workgroup is held back for
     about 2 ms; with a patience of 4 polls every other chunk counts chunk 0 itself, the last one replaces the count by
     the total -- and only then does chunk 0's owner start: it must take the base from the word the others published,
@@ -73,7 +73,8 @@ def test_owner_of_the_first_chunk_arrives_after_the_total_is_out(ops, n):
     from xgnn_amd import lib
     rng = np.random.RandomState(n)
     universe = n // 2 + 7
-    ht = ops.OrderedHashTable(4 * n + 16, num_node=universe + 1)
+    # direct layout: the chunked owner scan; hashed layout: the generic single-pass scan over the same in-place count
+    ht = ops.OrderedHashTable(4 * n + 16, num_node=(universe + 1) if direct else None)
     orc = oracle.HashTable(universe + 1, 4 * n + 16)
     ht.reset()
     orc.reset()

@@ -694,7 +694,6 @@ __global__ __launch_bounds__(kBlock) void k_owner_scan_chunked(unsigned long lon
 }
 
 static std::atomic<bool> g_poison_next_scan{false};
-static std::atomic<uint32_t> g_delay_next_scan{0};
 
 static size_t owner_scan_grid_cap() { // GGMS_OSCAN_GRID: measurement hook
   static const size_t v = [] { const char *e = getenv("GGMS_OSCAN_GRID"); const long x = e ? atol(e) : 0; return x > 0 ? (size_t)x : (size_t)512; }();
@@ -794,7 +793,7 @@ int ht_fill_impl(const ggms_hashtable_t *ht, const uint32_t *input, size_t n_max
     const uint32_t epoch16 = epoch % 65535u + 1u; // never 0: a cleared descriptor is "not written"
     const uint32_t skip_below = poisoned ? 1u : 0u;
     const uint32_t patience = poisoned ? kNoPatienceLimit : scan_patience(); // the poisoned launch tests the BOUND
-    const uint32_t delay0 = g_delay_next_scan.exchange(0);
+    const uint32_t delay0 = scan_delay_word().exchange(0u);
     unsigned long long *desc0 = desc;             // chunk 0: 64-bit, carries the table's item count in
     if (di.batch)
       hipLaunchKernelGGL(k_owner_scan_chunked<true>, dim3(cgrid), dim3(kBlock), 0, s, di.w, di.version, ht->n2o, input,
@@ -839,7 +838,7 @@ extern "C" {
 // TableSize(num, scale = kDefaultScale = 2): cuda_hashtable.cu:146-149, cuda_hashtable.h:105
 void ggms_debug_poison_next_scan(void) { g_poison_next_scan.store(true); }
 void ggms_debug_set_scan_patience(uint32_t polls) { scan_patience_word().store(polls); }
-void ggms_debug_delay_next_scan(uint32_t sleeps) { g_delay_next_scan.store(sleeps); }
+void ggms_debug_delay_next_scan(uint32_t sleeps) { scan_delay_word().store(sleeps); }
 
 size_t ggms_hashtable_num_buckets(size_t capacity) {
   size_t half = capacity >> 1;

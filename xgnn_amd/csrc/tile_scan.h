@@ -112,6 +112,11 @@ inline std::atomic<uint32_t> &scan_patience_word() {
   return v;
 }
 inline uint32_t scan_patience() { return scan_patience_word().load(std::memory_order_relaxed); }
+// ggms_debug_delay_next_scan (tests): the workgroup of tile / chunk 0 of the next single-pass scan "starts late"
+inline std::atomic<uint32_t> &scan_delay_word() {
+  static std::atomic<uint32_t> v{0u};
+  return v;
+}
 
 // Decoupled look-back, run by the 64 lanes of ONE wave: sum of the aggregates of the tiles before `tile`, back to
 // the nearest published inclusive prefix (which carries `base` in from tile 0).  64 predecessors per step.
@@ -206,7 +211,7 @@ __global__ __launch_bounds__(kBlock) void k_tile_scan(ValueF value, EmitF emit, 
                                                       unsigned long long *desc, uint32_t epoch,
                                                       const uint32_t *base_in, uint32_t *total32_out,
                                                       uint64_t *total64_out, uint64_t *mirror_a, uint64_t *mirror_b,
-                                                      uint32_t *err, uint32_t patience) {
+                                                      uint32_t *err, uint32_t patience, uint32_t delay0) {
   constexpr uint32_t ROUNDS = kTile / kBlock, FLAG_A = 1, FLAG_P = 2;
   __shared__ uint32_t smem[kBlock / kWave];
   __shared__ uint32_t s_tile, s_prefix;
@@ -215,6 +220,8 @@ __global__ __launch_bounds__(kBlock) void k_tile_scan(ValueF value, EmitF emit, 
   // total32_out may alias base_in (a running count updated in place): the last tile overwrites it, but only after
   // tile 0's descriptor is out -- so whoever finds that descriptor missing AFTER this read has read the old value
   // (tile 0's owner and the look-backs that compute tile 0 for themselves check exactly that)
+  if (delay0 && blockIdx.x == 0) // test aid: tile 0's owner starts after the others computed its word and the total is out
+    for (uint32_t i = 0; i < delay0; ++i) __builtin_amdgcn_s_sleep(127);
   const uint32_t base_seen = base_in ? *base_in : 0u;
   // Up to kSinglePassTiles workgroups (the default use of this kernel) take tile = workgroup id: a ticket and an exit
   // count from one word are 2 x 256 same-address atomics, 11 ns each (tools/micro_ticket.hip) -- most of an 8-us launch.
@@ -474,7 +481,7 @@ inline int tile_scan(ValueF value, EmitF emit, size_t n_max, Count n, ScanArea a
   }
   hipLaunchKernelGGL((k_tile_scan<ValueF, EmitF>), dim3(grid), dim3(kBlock), 0, stream, value, emit, n, ctl, desc,
                      next_scan_epoch(), base_in, total32_out, total64_out, mirror_a, mirror_b, device_status_word(),
-                     scan_patience());
+                     scan_patience(), scan_delay_word().exchange(0u));
   GGMS_LAUNCH_CHECK();
   return GGMS_OK;
 }
