@@ -742,6 +742,17 @@ def main():
             if rank == 0:
                 engine = engine_record(datagen, graph, fanouts, args, log, workers=world,
                                        force_device=os.environ.get("GGMS_BENCH_DEVICE"))
+            # the other ranks wait on the HOST (the rendezvous store), not inside an RCCL collective: a collective's
+            # kernel would spin on their GPUs for the minute the engine's workers are measuring on them
+            try:
+                import datetime
+                store = dist.distributed_c10d._get_default_store()
+                if rank == 0:
+                    store.set("ggms_bench_engine_done", "1")
+                else:
+                    store.wait(["ggms_bench_engine_done"], datetime.timedelta(seconds=args.engine_timeout + 240))
+            except Exception as e:  # noqa: BLE001 -- no such store: the collective below is the meeting point
+                log(f"host-side wait unavailable ({type(e).__name__}: {e}); waiting in the barrier")
             barrier()
         log("engine sub-record done")
 

@@ -167,6 +167,11 @@ ggms_store.with_deadline(lambda: dist.all_gather_object(got, (b"h" * 64, 123)), 
 assert got == [(b"h" * 64, 123)]
 dist.barrier()
 torch.cuda.synchronize()
+# the host-side meeting point of the long wait (engine sub-record): the rendezvous store, no kernel on the GPU
+import datetime
+store = dist.distributed_c10d._get_default_store()
+store.set("ggms_bench_engine_done", "1")
+store.wait(["ggms_bench_engine_done"], datetime.timedelta(seconds=10))
 stats = torch.tensor([1.5, 2.0, 3.0], dtype=torch.float64, device=dev)
 mx, sm = stats.clone(), stats.clone()
 dist.all_reduce(mx, op=dist.ReduceOp.MAX)
