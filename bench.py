@@ -71,10 +71,13 @@ def parse():
                     help="one stream: extract of batch k and sampling of batch k+1 run back to back "
                          "(default: two streams, the HBM-bound gather overlaps the latency-bound sampler)")
     ap.add_argument("--store", default=None, choices=["replica", "peer", "a2a", "hybrid"],
-                    help="N > 1 (default peer): 'peer' = GGMS feature shards (slot %% N), rows read from the owner's HBM "
-                         "inside the gather kernel over xGMI (hipIpc); 'a2a' = same shards, rows exchanged with RCCL "
-                         "all-to-all; 'hybrid' = the --replicate-frac hottest rows (degree rank) on every GPU, the tail "
-                         "sharded; 'replica' = every GPU holds all cached rows (DP over seeds only)")
+                    help="N > 1 (default hybrid): 'hybrid' = GGMS placement under a per-GPU HBM budget -- the hottest rows "
+                         "(degree rank) on every GPU, as many as --hbm-budget-gb holds beside this GPU's share of the "
+                         "sharded rest (--replicate-frac auto; what the reference's PartitionSolver decides on NVLink), "
+                         "one gather kernel serves replica, local shard and peer shards (xGMI, hipIpc); 'peer' = the "
+                         "budget-minimum case: pure feature shards (slot %% N), 7/8 of the rows read over xGMI inside the "
+                         "gather; 'a2a' = same shards, rows exchanged with RCCL all-to-all; 'replica' = every GPU holds "
+                         "all cached rows (DP over seeds only)")
     ap.add_argument("--replicate-frac", default="auto",
                     help="hybrid store: 'auto' (default) = the largest hot prefix whose replica + this GPU's share of the "
                          "sharded rest fits --hbm-budget-gb per GPU (ggms_store.plan_replication), or a fraction of the "
@@ -82,7 +85,7 @@ def parse():
     ap.add_argument("--hbm-budget-gb", type=float, default=48.0,
                     help="hybrid store with --replicate-frac auto: HBM one GPU may spend on feature rows (default 48 of "
                          "the 288 GB: papers100M's 57-GB table is then 0.82 replicated, the rest sharded)")
-    ap.add_argument("--other-stores", default="replica,hybrid",
+    ap.add_argument("--other-stores", default="peer,replica",
                     help="N > 1: stores measured after the main timed region (one block) and reported under 'stores'")
     ap.add_argument("--neighbour-skew", type=float, default=0.0,
                     help="0 (default, SURVEY 8d): neighbour ids uniform; s > 0: a neighbour is drawn with probability "
@@ -371,7 +374,7 @@ def main():
     if args.fanout is None:
         args.fanout = "25,10" if args.preset in ("products", "tiny") else "5,10,15"
     fanouts = [int(x) for x in args.fanout.split(",")]
-    main_store = (args.store or "peer") if world > 1 else "local"
+    main_store = (args.store or "hybrid") if world > 1 else "local"
     graph = shared_graph(datagen, args, world, local_rank, dist)
     log("graph generated")
     meta = graph["meta"]
@@ -801,7 +804,7 @@ def main():
         achieved = algo_bytes_per_launch / avg_launch_s / 1e9
         tr = measured_traffic(args.preset)
         traffic = None
-        if tr is not None and not tr["stale"]:  # PMC bytes per row (profiled run of this command) x rows of this run / this run's launch time
+        if tr is not None and not tr["stale"] and world == 1 and full:  # (the profiled kernel: one GPU, every row in HBM) PMC bytes per row (profiled run of this command) x rows of this run / this run's launch time
             traffic = tr["hbm_bytes_per_launch"] / tr["rows_per_launch"] * (rows / args.steps) / avg_launch_s / 1e9
         elapsed_all = [b["elapsed"] for b in blocks]
         res = {
@@ -826,8 +829,11 @@ def main():
                             f"{'neighbours uniform' if not args.neighbour_skew else f'neighbour skew {args.neighbour_skew} (prob. of a degree-proportional pick)'}, "
                             f"fanout {fanouts} {args.sample_type}, batch {args.batch}, "
                             f"graph in HBM, feature cache_ratio {args.cache_ratio}"
-                            f"{' (all rows in HBM, node order)' if full else ' (rest in pinned host DRAM)'}, "
-                            f"seeds DP over {world} GPU(s), feature store: {main_store}",
+                            f"{(' (all rows in HBM, slots in degree-rank order)' if main_store == 'hybrid' else ' (all rows in HBM, node order)') if full else ' (rest in pinned host DRAM)'}, "
+                            f"seeds DP over {world} GPU(s), feature store: {main_store}"
+                            + (f" ({hybrid_plan.get('replicated_fraction', 0):.2f} of the cached rows on every GPU"
+                               + (f" under a {args.hbm_budget_gb:g}-GB per-GPU budget" if args.replicate_frac == "auto" else "")
+                               + f", the rest sharded over the {world} GPUs)" if main_store == "hybrid" and world > 1 else ""),
                 "global_batch": args.batch * world,
                 "parallelism": f"dp{world}",
                 "streams": "1 (serial)" if args.no_overlap else

@@ -48,8 +48,10 @@ def test_single_gpu_line():
     assert en["ms_per_step"] > 0 and en["edges_per_s"] > 0 and en["feature_GBps"] > 0 and en["steps"] == 8
 
 
-def test_two_ranks_default_is_the_sharded_store():
-    """--gpus 2 with no --store: the main region runs on GGMS shards (peer), replica + hybrid are measured beside it."""
+def test_two_ranks_default_is_the_planned_placement():
+    """--gpus 2 with no --store: the main region runs on the GGMS placement planned from the per-GPU HBM budget (hybrid:
+    hot prefix on every GPU, the rest sharded, one gather kernel over replica / local shard / peer shard); the pure
+    shards (peer) and the replicas are measured beside it."""
     env = dict(os.environ, GGMS_BENCH_DEVICE="0", GGMS_BENCH_BACKEND="gloo")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                         "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"),
@@ -57,7 +59,8 @@ def test_two_ranks_default_is_the_sharded_store():
                        capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
     assert r.returncode == 0, r.stderr[-3000:]
     d = _last_json(r.stdout)
-    assert KEYS <= set(d) and d["n_gpus"] == 2 and "feature store: peer" in d["config"]["workload"]
+    assert KEYS <= set(d) and d["n_gpus"] == 2 and "feature store: hybrid" in d["config"]["workload"]
+    assert "48-GB per-GPU budget" in d["config"]["workload"]
     st = d["stores"]
     assert set(st) == {"peer", "replica", "hybrid"}
     assert 0.3 < st["peer"]["remote_row_fraction"] < 0.7 and st["peer"]["xgmi_bytes_per_step"] > 0
@@ -65,6 +68,7 @@ def test_two_ranks_default_is_the_sharded_store():
     # default plan: the largest hot prefix that fits the per-GPU budget is replicated (at this size: all but the tail)
     assert 0 <= st["hybrid"]["remote_row_fraction"] < st["peer"]["remote_row_fraction"]
     assert st["hybrid"]["replicated_fraction"] > 0.9 and st["hybrid"]["hbm_budget_gb"] == 48.0
+    assert st["hybrid"]["edges_per_s"] == d["value"]
 
 
 _BROKEN_IPC = """
@@ -93,9 +97,9 @@ def test_two_ranks_whose_shards_cannot_be_mapped_report_replicas_and_say_so(tmp_
     assert r.returncode == 0, r.stderr[-3000:]
     d = _last_json(r.stdout)
     assert d["n_gpus"] == 2 and "feature store: replica" in d["config"]["workload"]
-    assert d["config"]["store_requested"] == "peer" and "invalid argument (test)" in d["config"]["store_error"]
+    assert d["config"]["store_requested"] == "hybrid" and "invalid argument (test)" in d["config"]["store_error"]
     assert "rank 0 of 2" in d["config"]["store_error"] and "rank 1 of 2" in d["config"]["store_error"]
-    assert "error" in d["stores"]["hybrid"] and d["stores"]["replica"]["edges_per_s"] > 0
+    assert "error" in d["stores"]["peer"] and d["stores"]["replica"]["edges_per_s"] > 0
     assert "cannot be built" in r.stderr
 
 
@@ -123,8 +127,8 @@ def test_five_ranks_one_gpu_peer_and_hybrid():
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
     env.update(GGMS_BENCH_DEVICE="0", GGMS_BENCH_BACKEND="gloo")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "5", "--preset", "tiny", "--steps", "3",
-                        "--warmup", "1", "--batch", "128", "--repeats", "1", "--other-stores", "hybrid", "--replicate-frac", "0.25",
-                        "--no-engine"],
+                        "--warmup", "1", "--batch", "128", "--repeats", "1", "--store", "peer", "--other-stores", "hybrid",
+                        "--replicate-frac", "0.25", "--no-engine"],
                        capture_output=True, text=True, timeout=1200, cwd=ROOT, env=env)
     assert r.returncode == 0, r.stderr[-3000:]
     d = _last_json(r.stdout)
