@@ -252,7 +252,7 @@ def scratch_dir(need_bytes, prefix):
     return tempfile.mkdtemp(prefix=prefix)
 
 
-def engine_record(datagen, graph, fanouts, args, log, workers=0, force_device=None):
+def engine_record(datagen, graph, fanouts, args, log, workers=0, force_device=None, replicate=0.0):
     """The same workload through the operator surface north_star names (samgraph.torch: config / init / sample_once /
     get_next_batch) in a CHILD process: the graph is written in the reference's on-disk format without feat.bin /
     label.bin (the loader then maps zero-filled tables, engine.cc:199-235 -- topology and sizes are the real ones), one
@@ -276,7 +276,7 @@ def engine_record(datagen, graph, fanouts, args, log, workers=0, force_device=No
         r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "engine_epoch.py"), d, "--fanout"]
                            + [str(f) for f in fanouts]
                            + ["--batch-size", str(args.batch), "--sample-type", args.sample_type, "--cache-percentage", "1.0"]
-                           + (["--arch6", str(workers)] if workers else []),
+                           + (["--arch6", str(workers), "--replicate-percentage", f"{replicate:.6f}"] if workers else []),
                            capture_output=True, text=True, timeout=args.engine_timeout, env=env)
         lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
         if r.returncode != 0 or not lines:
@@ -288,7 +288,10 @@ def engine_record(datagen, graph, fanouts, args, log, workers=0, force_device=No
                         "kLogEpochFeatureBytes / kLogEpochCopyTime" if not workers else
                         f"samgraph.torch arch6: data_init in the parent, {workers} forked workers (sample_init / train_init / "
                         "sample_once / get_next_batch), feature table sharded over the workers' GPUs (part_cache, gpu_extract, "
-                        "hipIpc peers), whole CSR on every GPU; second epoch, the slowest worker's wall time; rates summed "
+                        "hipIpc peers"
+                        + (f"; the {replicate:.2f} hottest of the rows on every GPU (replicate_percentage), the rest sharded"
+                           if replicate else "")
+                        + "), whole CSR on every GPU; second epoch, the slowest worker's wall time; rates summed "
                         "over the workers from the reference's log items")
         return e
     except subprocess.TimeoutExpired:
@@ -631,6 +634,7 @@ def main():
         main_store = "replica"
         torch.cuda.empty_cache()
         extract_main, keep_main = build_store(main_store)
+    main_plan = dict(hybrid_plan) if main_store == "hybrid" else {}
     blocks, next_step = measure(extract_main, args.steps, args.warmup, repeats)
     log("main region done")
     blk = median_block(blocks)
@@ -743,8 +747,11 @@ def main():
             torch.cuda.empty_cache()
             barrier()
             if rank == 0:
+                # the same placement as the main region's: the planned hot prefix on every GPU (0 = pure shards)
                 engine = engine_record(datagen, graph, fanouts, args, log, workers=world,
-                                       force_device=os.environ.get("GGMS_BENCH_DEVICE"))
+                                       force_device=os.environ.get("GGMS_BENCH_DEVICE"),
+                                       replicate=(main_plan.get("replicated_fraction", 0.0)
+                                                  if main_store == "hybrid" else 0.0))
             # the other ranks wait on the HOST (the rendezvous store), not inside an RCCL collective: a collective's
             # kernel would spin on their GPUs for the minute the engine's workers are measuring on them
             try:
@@ -831,7 +838,7 @@ def main():
                             f"graph in HBM, feature cache_ratio {args.cache_ratio}"
                             f"{(' (all rows in HBM, slots in degree-rank order)' if main_store == 'hybrid' else ' (all rows in HBM, node order)') if full else ' (rest in pinned host DRAM)'}, "
                             f"seeds DP over {world} GPU(s), feature store: {main_store}"
-                            + (f" ({hybrid_plan.get('replicated_fraction', 0):.2f} of the cached rows on every GPU"
+                            + (f" ({main_plan.get('replicated_fraction', 0):.2f} of the cached rows on every GPU"
                                + (f" under a {args.hbm_budget_gb:g}-GB per-GPU budget" if args.replicate_frac == "auto" else "")
                                + f", the rest sharded over the {world} GPUs)" if main_store == "hybrid" and world > 1 else ""),
                 "global_batch": args.batch * world,

@@ -118,6 +118,7 @@ def test_gpus_flag_alone_starts_the_ranks():
     en = d["engine"]
     assert "error" not in en, en
     assert en["arch"] == "arch6" and en["workers"] == 2 and en["edges_per_s"] > 0 and en["feature_GBps"] > 0
+    assert en["replicate_percentage"] > 0.9  # the main region's placement (at this size the plan replicates all but the tail)
 
 
 def test_five_ranks_one_gpu_peer_and_hybrid():

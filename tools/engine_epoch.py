@@ -26,6 +26,9 @@ def main():
     ap.add_argument("--cache-percentage", type=float, default=1.0)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--pipelined", action="store_true", help="extract_start(0): the background thread samples ahead")
+    ap.add_argument("--replicate-percentage", type=float, default=0.0,
+                    help="arch6: this fraction of the cached rows (hottest first) on every GPU, the rest sharded "
+                         "(config key replicate_percentage; 0 = pure shards)")
     ap.add_argument("--arch6", type=int, default=0, metavar="WORKERS",
                     help="the multi-GPU deployment instead of arch1: config + data_init here, one forked worker per GPU "
                          "(sample_init / train_init on cuda:<worker>), feature shards across the workers' GPUs "
@@ -77,6 +80,8 @@ def main_arch6(a):
            "cache_percentage": a.cache_percentage, "max_sampling_jobs": 10, "max_copying_jobs": 1, "omp_thread_num": 40,
            "num_layer": len(a.fanout), "num_hidden": 256, "lr": 0.003, "dropout": 0.5, "num_fanout": len(a.fanout),
            "fanout": a.fanout, "num_worker": W, "part_cache": "True", "gpu_extract": "True", "seed": a.seed}
+    if a.replicate_percentage > 0:
+        cfg["replicate_percentage"] = a.replicate_percentage
     sam.config(cfg)
     sam.data_init()  # host only: the GPUs are first touched in the workers
     out_dir = tempfile.mkdtemp(prefix="ggms_engine_")
@@ -117,7 +122,7 @@ def main_arch6(a):
     recs = [json.load(open(os.path.join(out_dir, f"w{w}.json"))) for w in range(W)]
     wall = max(r["wall_s"] for r in recs)
     edges = sum(r["edges"] for r in recs)
-    out = {"arch": "arch6", "workers": W, "steps": recs[0]["steps"], "wall_s": wall, "ms_per_step": wall / recs[0]["steps"] * 1e3,
+    out = {"arch": "arch6", "workers": W, "replicate_percentage": a.replicate_percentage, "steps": recs[0]["steps"], "wall_s": wall, "ms_per_step": wall / recs[0]["steps"] * 1e3,
            "edges": edges, "edges_per_s": edges / wall,
            "sample_edges_per_s": sum(r["edges"] / r["sample_s"] for r in recs if r["sample_s"]),
            "feature_GBps": sum(r["feature_bytes"] / r["copy_s"] / 1e9 for r in recs if r["copy_s"]),
