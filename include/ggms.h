@@ -54,16 +54,19 @@ enum ggms_dtype {
 int ggms_abi_version(void);
 const char *ggms_last_error(void);
 
-/* Device status word (one per device, sticky).  The reference CHECK-aborts when a device-side bound is hit
- * (logging.cc:69-73); kernels here cannot abort, so they OR a bit into this word and return:
+/* Status words.  The reference CHECK-aborts when a device-side bound is hit (logging.cc:69-73); kernels here
+ * cannot abort, so they OR a bit into a status word and return:
  *   GGMS_STATUS_SCAN_SPIN   an ordered scan's look-back gave up waiting for a predecessor tile (protocol error);
  *   GGMS_STATUS_TABLE_FULL  the hashed dedup table had no free bucket for a key (sized too small).
- * Results of a call that set a bit are invalid.  The word is per DEVICE, shared by every table, sampler and stream:
- *   - ggms_sample_batch TAKES it at the end of the batch (atomic exchange with 0 into counts_dev[3 L + 1]): the
- *     failure is reported once, to the batch that ends next on that device (with several batches in flight that
- *     may be a neighbour of the one that failed -- the engine aborts on any of them), and later batches start clean;
- *   - leaf operators leave it set until ggms_device_status(clear != 0), which drains the device first
- *     (hipDeviceSynchronize: kernels on non-blocking streams included) and then zeroes it. */
+ * Results of a call that set a bit are invalid.  Two kinds of word:
+ *   - every BATCH has its own: the second word behind its table's item counter (ggms_hashtable_t.num_items_dev[1],
+ *     zeroed by ggms_hashtable_init).  Every kernel of a ggms_sample_batch call ORs into that word only, the
+ *     batch's last kernel moves it into counts_dev[3 L + 1] (exchange with 0: the next batch on that table starts
+ *     clean) -- so with several batches in flight a failure is reported by the batch it happened in, and only by
+ *     it.  A non-zero word is also ORed into the device word below;
+ *   - one per DEVICE, sticky, for the leaf operators (and as the record of failed batches): it stays set until
+ *     ggms_device_status(clear != 0), which drains the device first (hipDeviceSynchronize: kernels on
+ *     non-blocking streams included) and then zeroes it. */
 #define GGMS_STATUS_SCAN_SPIN 1u
 #define GGMS_STATUS_TABLE_FULL 2u
 int ggms_device_status(uint32_t *status_host, int clear);
@@ -91,6 +94,19 @@ void ggms_debug_set_scan_patience(uint32_t polls);
  * patience the others compute its word themselves and the last one replaces the table's item count by the total before
  * that workgroup starts: the "owner arrives late" case of the self-serve look-back.  One shot. */
 void ggms_debug_delay_next_scan(uint32_t sleeps);
+/* Test aids (this process): force a slower, result-identical form of a kernel that default sizes rarely or never
+ * reach.  value < 0 restores the default.  The library reads NO environment variable for any of this (the one it
+ * reads is GGMS_EXTRACT_BLOCKS, the gather's grid cap).
+ *   GGMS_DEBUG_KHOP0_DRAW_CAP     draws parked per khop0 launch (small: seeds whose draws do not fit are resolved in
+ *                                 place by the generating lanes)
+ *   GGMS_DEBUG_OWNER_SCAN_CHUNKS  workgroups of the chunked owner scan (small: chunks too long for registers are read
+ *                                 twice)
+ *   GGMS_DEBUG_OWNER_SCAN_TILES   != 0: the tile-chained owner scan (by default only beyond 65 M items per fill) */
+#define GGMS_DEBUG_KHOP0_DRAW_CAP 0
+#define GGMS_DEBUG_OWNER_SCAN_CHUNKS 1
+#define GGMS_DEBUG_OWNER_SCAN_TILES 2
+#define GGMS_DEBUG_NUM_KNOBS 3
+void ggms_debug_set_knob(int knob, long long value);
 size_t ggms_dtype_bytes(int dtype);
 
 /* ---------------------------------------------------------------------------
@@ -98,8 +114,13 @@ size_t ggms_dtype_bytes(int dtype);
  * indptr/indices are one CSR.  num_part > 0: DeviceDistGraph (:114-158): node
  * v < num_cache_node lives in shard v % num_part at row v / num_part; every
  * other node in slot num_part (the whole CSR, normally pinned host memory).
- * part_indptr / part_indices are DEVICE arrays of num_part + 1 pointers.
+ * part_indptr / part_indices are HOST arrays of num_part + 1 device pointers
+ * (num_part <= GGMS_MAX_PARTS): the nine pointers of an 8-GPU node travel in the
+ * kernels' arguments (SGPRs), where the reference's DeviceDistGraph keeps them in
+ * a device array that every seed's lookup reads first (dist_graph.h:150-157);
+ * `v % num_part`, `v / num_part` are a multiply-high by a launch constant.
  * ------------------------------------------------------------------------- */
+#define GGMS_MAX_PARTS 8
 typedef struct {
   const ggms_id_t *indptr;
   const ggms_id_t *indices;
@@ -249,7 +270,8 @@ int ggms_sample_random_walk(const ggms_graph_t *graph, const ggms_id_t *input,
 typedef struct {
   void *o2n;               /* hashed: o2n_size buckets of 16 B; direct: o2n_size words of 8 B */
   ggms_id_t *n2o;          /* n2o_size ids                                   */
-  uint32_t *num_items_dev; /* device counter                                 */
+  uint32_t *num_items_dev; /* TWO device words: [0] item counter, [1] status
+                              word of the batch that runs on this table       */
   uint64_t o2n_size;       /* hashed: power of two; direct: >= number of node ids */
   uint64_t n2o_size;
   uint32_t version;        /* bumped by ggms_hashtable_reset                 */
@@ -290,7 +312,7 @@ int ggms_map_edges(const ggms_hashtable_t *ht, const ggms_id_t *global_src,
  *   counts_dev[3*i + 1] = num_src(i)    (= unique nodes after layer i)
  *   counts_dev[3*i + 2] = num_dst(i)    (= size of layer i's frontier)
  *   counts_dev[3*L]     = number of input nodes; the list is ht->n2o
- *   counts_dev[3*L + 1] = device status word after the batch (0 = ok, see ggms_device_status)
+ *   counts_dev[3*L + 1] = status word of THIS batch (0 = ok; "Status words" above)
  * row[i] = local id of the sampled neighbour, col[i] = local id of the seed
  * (TrainGraph, dist_loops.cc:303-322).  row/col are HOST arrays of L device
  * pointers with the capacities ggms_sample_batch_capacity reports; fanouts is
@@ -395,9 +417,10 @@ int ggms_gather_scatter(void *out, const void *src, const ggms_id_t *src_index,
                         ggms_stream_t stream);
 /* combine_cache_data_for_partition :277-299 with DeviceDistFeature
  * (cuda/dist_graph.h:182-212): slot s lives in parts[s % num_part] at row
- * s / num_part.  parts_dev: DEVICE array of num_part base pointers (local
- * HBM, peer HBM mapped with hipIpcOpenMemHandle, or mapped host memory). */
-int ggms_gather_scatter_partition(void *out, const void *const *parts_dev,
+ * s / num_part.  parts: HOST array of num_part (<= GGMS_MAX_PARTS) base
+ * pointers (local HBM, peer HBM mapped with hipIpcOpenMemHandle, or mapped host
+ * memory); they are passed to the kernel by value. */
+int ggms_gather_scatter_partition(void *out, const void *const *parts,
                                   uint32_t num_part,
                                   const ggms_id_t *src_index,
                                   const ggms_id_t *dst_index, size_t num,
@@ -406,14 +429,14 @@ int ggms_gather_scatter_partition(void *out, const void *const *parts_dev,
 /* One-pass replacement of GetMissCacheIndex + GPUExtractMissData +
  * CombineCacheData (dist_loops.cc:1209-1285): out[i,:] = table[nodes[i]] ==
  * kEmptyKey ? host_feat[nodes[i],:] : parts[slot % P][slot / P,:].
- * num_part == 0 -> single cache array parts_dev[0].  Also counts misses.
+ * num_part == 0 -> single cache array parts[0].  Also counts misses.  parts: HOST array, as above.
  * table == NULL: the whole feature table is cached and kept in NODE order (slot = node id):
  * out[i,:] = parts[node % P][node / P,:] with no table read and no miss tier -- the layout of a full cache
  * is not observable through the reference's interface, and the gather loses one dependent random read per row.
  * The same convention holds for ggms_owner_histogram. */
 int ggms_extract_cached(void *out, const ggms_id_t *nodes, size_t num_nodes,
                         const uint64_t *num_nodes_dev, const ggms_id_t *table,
-                        const void *const *parts_dev, uint32_t num_part,
+                        const void *const *parts, uint32_t num_part,
                         const void *host_feat, size_t dim, int dtype,
                         uint64_t *num_miss_dev, ggms_stream_t stream);
 
@@ -430,7 +453,7 @@ typedef struct {
   const ggms_id_t *table;
   const void *replica;
   uint64_t num_replica;
-  const void *const *parts_dev; /* DEVICE array of num_part base pointers */
+  const void *const *parts; /* HOST array of num_part (<= GGMS_MAX_PARTS) base pointers */
   uint32_t num_part;
   uint32_t my_part;
   const void *host_feat;

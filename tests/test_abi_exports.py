@@ -57,7 +57,7 @@ def test_reference_python_surface_present():
 
 def test_host_only_entry_points():
     l = xgnn_amd.lib()
-    assert l.ggms_abi_version() == 2
+    assert l.ggms_abi_version() == 3
     # shards a peer can open (ROCm 7.2: sizes with bit 31 set never open): rounded up to the next multiple of 4 GiB
     assert l.ggms_ipc_safe_bytes(1 << 20) == 1 << 20 and l.ggms_ipc_safe_bytes(3000 << 20) == 4 << 30
     assert l.ggms_ipc_safe_bytes(28_431_348_736) == 7 << 32 and l.ggms_ipc_safe_bytes(6000 << 20) == 6000 << 20

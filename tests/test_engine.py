@@ -447,39 +447,6 @@ def test_example_training_loop(tmp_path):
 
 
 @pytest.mark.gpu
-def test_single_pass_scan_variant():
-    """GGMS_SCAN=1 selects the decoupled look-back form of every ordered scan: same results."""
-    env = dict(os.environ, GGMS_SCAN="1")
-    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_parity.py"), "-m", "gpu",
-                        "-q", "-x", "-k", "hashtable or sample_batch_vs_oracle or get_miss_cache or weighted or khop3"],
-                       capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
-    assert r.returncode == 0, r.stdout[-2000:]
-
-
-@pytest.mark.gpu
-@pytest.mark.parametrize("env", [dict(GGMS_OSCAN_CHUNK_GRID="24"), dict(GGMS_OSCAN="tiles")])
-def test_owner_scan_variants(env):
-    """The ordered owner scan has three forms with the same results: chunks held in registers (default), chunks too
-    long for that (forced here by allowing only 24 chunks: every chunk is re-read for the write-out), and the
-    tile-chained decoupled look-back kernel."""
-    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_parity.py"), "-m", "gpu",
-                        "-q", "-x", "-k", "hashtable or sample_batch_vs_oracle or fused_khop3 or hub_graph"],
-                       capture_output=True, text=True, timeout=900, env=dict(os.environ, **env), cwd=ROOT)
-    assert r.returncode == 0, r.stdout[-2000:]
-
-
-@pytest.mark.gpu
-@pytest.mark.parametrize("cap", ["0", "3000"])
-def test_khop0_draw_buffer_overflow_path(cap):
-    """khop0 parks raw draws in a buffer and resolves them in a second kernel; seeds that do not fit are resolved
-    in place.  A tiny buffer (GGMS_KHOP0_CAP) must give the same results."""
-    env = dict(os.environ, GGMS_KHOP0_CAP=cap)
-    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_parity.py"), "-m", "gpu",
-                        "-q", "-x", "-k", "khop0"], capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
-    assert r.returncode == 0, r.stdout[-2000:]
-
-
-@pytest.mark.gpu
 def test_arch6_presample_cache_policy(tmp_path):
     """cache_policy = pre_sample (dist/pre_sampler.cc:39-139): worker 0 samples `presample_epoch` epochs of the
     whole train set, ranks nodes by (visit count << 32 | id) descending, and that ranking fills the cache."""

@@ -19,12 +19,18 @@ def ops():
     return o
 
 
+def session_patience():
+    """What the session runs with (conftest.scan_patience_of_this_run): GGMS_TEST_SCAN_PATIENCE, else the default."""
+    import os
+    return int(os.environ.get("GGMS_TEST_SCAN_PATIENCE", "2048"))
+
+
 @pytest.fixture()
 def impatient(ops):
     from xgnn_amd import lib
     lib().ggms_debug_set_scan_patience(0)
     yield
-    lib().ggms_debug_set_scan_patience(2048)
+    lib().ggms_debug_set_scan_patience(session_patience())
 
 
 def test_fused_khop3_and_every_sampler_random_shapes(ops, impatient):
@@ -92,4 +98,4 @@ def test_owner_of_the_first_chunk_arrives_after_the_total_is_out(ops, n, direct)
             np.testing.assert_array_equal(P.host_u32(ns), os_)
         assert ops.device_status() == 0
     finally:
-        lib().ggms_debug_set_scan_patience(2048)
+        lib().ggms_debug_set_scan_patience(session_patience())

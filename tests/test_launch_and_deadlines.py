@@ -129,7 +129,10 @@ class HostShard:
     def import_peer(self, h):
         if sys.argv[3] == "import" and rank == 1:
             raise RuntimeError("hipIpcOpenMemHandle: invalid device pointer")
+        self.opened = getattr(self, "opened", 0) + 1
         return 1234
+    def release_peers(self):  # the mappings that did open are closed before the verdict is raised
+        print("RELEASED", getattr(self, "opened", 0))
 
 os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=sys.argv[2])
 dist.init_process_group("gloo", rank=rank, world_size=2)
@@ -159,4 +162,5 @@ def test_a_refused_ipc_call_on_one_rank_is_raised_on_every_rank(tmp_path, where)
     for p, (out, err) in zip(ps, outs):
         assert p.returncode == 0, err[-1000:]
         assert "REFUSED" in out and "rank 1 of 2" in out and "in step" in out and "MAPPED" not in out
+        assert "RELEASED" in out  # nobody is left owning a peer mapping
         assert ("hipIpcOpenMemHandle: invalid device pointer" if where == "import" else "hipIpcGetMemHandle") in out

@@ -29,7 +29,7 @@ class SampleExtra(C.Structure):
 class FeatureTiers(C.Structure):
     """ggms_feature_tiers_t"""
     _fields_ = [("table", C.c_void_p), ("replica", C.c_void_p), ("num_replica", C.c_uint64),
-                ("parts_dev", C.c_void_p), ("num_part", C.c_uint32), ("my_part", C.c_uint32),
+                ("parts", C.c_void_p), ("num_part", C.c_uint32), ("my_part", C.c_uint32),
                 ("host_feat", C.c_void_p), ("host_row_mask", C.c_uint32), ("_pad", C.c_uint32)]
 
 
@@ -49,6 +49,7 @@ SYMBOLS = {
     "ggms_debug_poison_next_scan": (None, []),
     "ggms_debug_set_scan_patience": (None, [C.c_uint32]),
     "ggms_debug_delay_next_scan": (None, [C.c_uint32]),
+    "ggms_debug_set_knob": (None, [_i, C.c_longlong]),
     "ggms_fabric_probe": (_i, [_i, _vp, _sz, _sz, _u32, _vp, _vp]),
     "ggms_dtype_bytes": (_sz, [_i]),
     "ggms_random_states_init": (_i, [_vp, _sz, _u64, _vp]),

@@ -59,6 +59,12 @@ int raise_dynamic_lds(const void *func, size_t bytes, const char *who) {
   return GGMS_OK;
 }
 
+std::atomic<long long> &debug_knob_word(int knob) {
+  static std::atomic<long long> v[GGMS_DEBUG_NUM_KNOBS] = {{-1}, {-1}, {-1}};
+  return v[knob];
+}
+long long debug_knob(int knob) { return debug_knob_word(knob).load(std::memory_order_relaxed); }
+
 unsigned long long next_dedup_tag() {
   static std::atomic<unsigned long long> g{[] {
     std::random_device rd;
@@ -82,7 +88,11 @@ using namespace ggms;
 
 extern "C" {
 
-int ggms_abi_version(void) { return 2; }
+int ggms_abi_version(void) { return 3; }
+
+void ggms_debug_set_knob(int knob, long long value) {
+  if (knob >= 0 && knob < GGMS_DEBUG_NUM_KNOBS) debug_knob_word(knob).store(value < 0 ? -1 : value);
+}
 
 int ggms_device_status(uint32_t *status_host, int clear) {
   GGMS_CHECK_ARG(status_host);

@@ -499,11 +499,10 @@ void Engine::UploadGraph() {
   // slot P: the whole CSR in (device-mapped) host memory, :367-381
   part_indptr_[P] = (void *)map_host(ds.indptr.ptr, ds.indptr.bytes);
   part_indices_[P] = (void *)map_host(ds.indices.ptr, ds.indices.bytes);
-  d_part_indptr_tab_ = dev_upload(part_indptr_.data(), (P + 1) * sizeof(void *), stream_);
-  d_part_indices_tab_ = dev_upload(part_indices_.data(), (P + 1) * sizeof(void *), stream_);
-  SAM_HIP(hipStreamSynchronize(stream_));
-  graph_.part_indptr = (const ggms_id_t *const *)d_part_indptr_tab_;
-  graph_.part_indices = (const ggms_id_t *const *)d_part_indices_tab_;
+  // the P + 1 pointers stay on the host: ggms_sample_batch hands them to its kernels by value (include/ggms.h)
+  SAM_CHECK(P <= GGMS_MAX_PARTS, "use_dist_graph: at most GGMS_MAX_PARTS topology shards");
+  graph_.part_indptr = (const ggms_id_t *const *)part_indptr_.data();
+  graph_.part_indices = (const ggms_id_t *const *)part_indices_.data();
   graph_.num_part = P;
   graph_.num_cache_node = num_cache_node;
 }
@@ -708,7 +707,7 @@ void Engine::BuildCache() {
       if (q != p) cache_parts_[q] = OpenPeer(shared_->feat_part[q], q, shared_->feat_rows[q] * row_bytes, "feature shard");
     Barrier("feature shards opened");
   }
-  d_cache_parts_tab_ = dev_upload(cache_parts_.data(), P * sizeof(void *), stream_);
+  SAM_CHECK(P <= GGMS_MAX_PARTS, "part_cache: at most GGMS_MAX_PARTS feature shards");
   num_cache_part_ = cfg.part_cache ? P : 0;
   // miss tier: pinned host memory read by the gather kernel itself (GPUExtractMissData, :573-625)
   feat_src_ = map_host(ds.feat.ptr, ds.feat.bytes);
@@ -878,7 +877,7 @@ bool Engine::EnqueueOne(bool background) {
     tiers.table = cache_table_;
     tiers.replica = d_replica_;
     tiers.num_replica = num_replica_;
-    tiers.parts_dev = (const void *const *)d_cache_parts_tab_;
+    tiers.parts = (const void *const *)cache_parts_.data();
     tiers.num_part = std::max<uint32_t>(1, num_cache_part_);
     tiers.my_part = cfg.part_cache ? (uint32_t)worker_id_ : 0;
     tiers.host_feat = feat_src_;
@@ -887,7 +886,7 @@ bool Engine::EnqueueOne(bool background) {
   } else if (cfg.UseGPUCache()) {
     // DoArch6GetCacheMissIndex + DoArch6GPUCacheFeatureCopy (dist_loops.cc:1015-1285) in one pass
     SAM_GGMS(ggms_extract_cached(b->feat, b->input_nodes, max_unique_, n_in, cache_table_,
-                                 (const void *const *)d_cache_parts_tab_, num_cache_part_, feat_src_, ds.feat_dim,
+                                 (const void *const *)cache_parts_.data(), num_cache_part_, feat_src_, ds.feat_dim,
                                  ds.feat_dtype, n_miss, xs));
   } else if (mock) { // GPUMockExtract, cuda_loops.cc:692-700 / dist_loops.cc:608-616
     SAM_GGMS(ggms_gather_scatter_masked(b->feat, feat_src_, b->input_nodes, nullptr, max_unique_, n_in, ds.feat_dim,
@@ -955,7 +954,7 @@ void Engine::StagedExtract(Batch *b, hipStream_t xs) {
       SAM_GGMS(ggms_gather_scatter(b->feat, cache_parts_[0], b->hit_src, b->hit_dst, num_hit, nullptr, ds.feat_dim,
                                    ds.feat_dtype, xs));
     else
-      SAM_GGMS(ggms_gather_scatter_partition(b->feat, (const void *const *)d_cache_parts_tab_, num_cache_part_, b->hit_src,
+      SAM_GGMS(ggms_gather_scatter_partition(b->feat, (const void *const *)cache_parts_.data(), num_cache_part_, b->hit_src,
                                              b->hit_dst, num_hit, nullptr, ds.feat_dim, ds.feat_dtype, xs));
   }
 }

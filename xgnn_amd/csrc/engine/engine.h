@@ -222,7 +222,6 @@ class Engine {
   // device graph
   uint32_t *d_indptr_ = nullptr, *d_indices_ = nullptr;
   std::vector<void *> part_indptr_, part_indices_; // P+1 entries (slot P = host CSR)
-  void *d_part_indptr_tab_ = nullptr, *d_part_indices_tab_ = nullptr;
   ggms_graph_t graph_{};
   // sampler state
   ggms_hashtable_t ht_{};
@@ -254,7 +253,6 @@ class Engine {
   // features
   uint32_t *cache_table_ = nullptr;            // id -> slot (GPUCacheManager::_sampler_gpu_hashtable)
   std::vector<void *> cache_parts_;            // shard base pointers (local or IPC-mapped)
-  void *d_cache_parts_tab_ = nullptr;
   uint32_t num_cache_part_ = 0;
   size_t num_cached_nodes_ = 0;
   size_t num_replica_ = 0;                     // hybrid store: slots [0, num_replica_) live in d_replica_ on every GPU

@@ -52,37 +52,41 @@ struct PlainRows {
 };
 
 // DeviceDistFeature::Get (cuda/dist_graph.h:191-205): slot -> shard slot % P, row slot / P
+// The shard pointers travel by value (PtrSet: a select chain on registers, not a load from a device pointer table) and
+// the split is a multiply-high by the launch-constant shard count (Divisor) -- both sit on every row's
+// index -> slot -> pointer chain, ahead of the row's first byte.
+typedef PtrSet<const char, kMaxParts> PartPtrs;
 struct PartitionRows {
-  const char *const *parts;
+  PartPtrs parts;
   const uint32_t *index;
   uint64_t row_bytes;
-  uint32_t num_part;
+  Divisor num_part;
   static constexpr bool kTiers = false;
   __device__ __forceinline__ const char *row(uint64_t i, uint32_t &tier) const {
     tier = 0;
-    const uint32_t slot = index[i];
-    const uint32_t part = slot % num_part, real = slot / num_part;
-    return parts[part] + (uint64_t)real * row_bytes;
+    uint32_t part, real;
+    num_part.divmod(index[i], real, part);
+    return parts.pick(part) + (uint64_t)real * row_bytes;
   }
 };
 
 // fused hit/miss: table[node] == kEmptyKey -> host tier row `node`, else cache slot
 struct CachedRows {
-  const char *const *parts;
+  PartPtrs parts;
   const uint32_t *nodes;
   const uint32_t *table;
   const char *host;
   uint64_t row_bytes;
-  uint32_t num_part; // 0: one cache array parts[0]
+  Divisor num_part; // d = 1: one cache array parts[0]
   static constexpr bool kTiers = false;
   __device__ __forceinline__ const char *row(uint64_t i, uint32_t &tier) const {
     const uint32_t node = nodes[i];
     const uint32_t slot = table[node];
     tier = (slot == kEmptyKey) ? kTierHost : 0u;
     if (slot == kEmptyKey) return host + (uint64_t)node * row_bytes;
-    if (num_part == 0) return parts[0] + (uint64_t)slot * row_bytes;
-    const uint32_t part = slot % num_part, real = slot / num_part;
-    return parts[part] + (uint64_t)real * row_bytes;
+    uint32_t part, real;
+    num_part.divmod(slot, real, part);
+    return parts.pick(part) + (uint64_t)real * row_bytes;
   }
 };
 
@@ -93,14 +97,14 @@ struct CachedRows {
 //                                                                      (combine_cache_data_for_partition)
 // and says which tier served the row, for the per-tier counters (count_local_cache, :171-207).
 struct TieredRows {
-  const char *const *parts;
+  PartPtrs parts;
   const uint32_t *nodes;
   const uint32_t *table;
   const char *host;
   const char *replica;
   uint64_t row_bytes;
   uint32_t num_replica;
-  uint32_t num_part; // >= 1
+  Divisor num_part; // d >= 1
   uint32_t my_part;
   uint32_t host_mask; // host tier row = node & host_mask (mock table of SAMGRAPH_EMPTY_FEAT; else all ones)
   static constexpr bool kTiers = true;
@@ -115,10 +119,10 @@ struct TieredRows {
       tier = kTierReplica;
       return replica + (uint64_t)slot * row_bytes;
     }
-    const uint32_t s = slot - num_replica;
-    const uint32_t part = s % num_part, real = s / num_part;
+    uint32_t part, real;
+    num_part.divmod(slot - num_replica, real, part);
     tier = part == my_part ? kTierLocal : kTierRemote;
-    return parts[part] + (uint64_t)real * row_bytes;
+    return parts.pick(part) + (uint64_t)real * row_bytes;
   }
 };
 
@@ -126,19 +130,32 @@ struct TieredRows {
 // not observable through the reference's interface (the batch's rows come out in input-node order either way), and
 // it removes one dependent random 4-byte read (a 64-byte sector of HBM traffic) per gathered row.
 struct IdentRows {
-  const char *const *parts;
+  PartPtrs parts;
   const uint32_t *nodes;
   uint64_t row_bytes;
-  uint32_t num_part; // 0: one array parts[0]
+  Divisor num_part; // d = 1: one array parts[0]
   static constexpr bool kTiers = false;
   __device__ __forceinline__ const char *row(uint64_t i, uint32_t &tier) const {
     tier = 0;
     const uint32_t node = nodes[i];
-    if (num_part == 0) return parts[0] + (uint64_t)node * row_bytes;
-    const uint32_t part = node % num_part, real = node / num_part;
-    return parts[part] + (uint64_t)real * row_bytes;
+    if (num_part.d == 1) return parts.p[0] + (uint64_t)node * row_bytes; // uniform
+    uint32_t part, real;
+    num_part.divmod(node, real, part);
+    return parts.pick(part) + (uint64_t)real * row_bytes;
   }
 };
+
+// host side: the caller's HOST array of shard base pointers -> kernel argument
+static inline bool part_ptrs(const void *const *parts, uint32_t num_part, PartPtrs &out) {
+  out = PartPtrs{};
+  const uint32_t n = num_part ? num_part : 1;
+  if (!parts || n > kMaxParts) {
+    set_error("extract: num_part %u (at most %u shards; `parts` is a HOST array of num_part device pointers)", num_part, kMaxParts);
+    return false;
+  }
+  for (uint32_t p = 0; p < n; ++p) out.p[p] = (const char *)parts[p];
+  return true;
+}
 
 __device__ __forceinline__ uint64_t shfl_u64(uint64_t v, int src) {
   const uint32_t lo = __shfl((uint32_t)v, src, 64);
@@ -164,7 +181,9 @@ __device__ __forceinline__ void store_chunk(uint64_t addr, V v) {
 }
 
 // U = independent chunk loads in flight per lane (16, or 8 for rows of fewer than 8 chunks)
-template <int CB, typename Rows, bool IDENT_DST, bool NT, bool NTS, int U = 8>
+// Loads and stores are non-temporal: a batch's rows are read once and the gathered batch is a > 100-MB stream that
+// nothing re-reads from cache (measured + 3..5 % on MI355X each, profiles/r01-r02).
+template <int CB, typename Rows, bool IDENT_DST, int U>
 __global__ __launch_bounds__(kBlock) void k_gather_rows(char *__restrict__ out, Rows rows,
                                                         const uint32_t *__restrict__ dst_index, Count n_arg,
                                                         uint32_t rc, uint32_t magic, uint64_t *miss_count) {
@@ -224,7 +243,7 @@ __global__ __launch_bounds__(kBlock) void k_gather_rows(char *__restrict__ out, 
         const uint32_t r = __umulhi(cc[u], magic) + (rc == 1 ? cc[u] : 0u);
         const uint32_t col = cc[u] - r * rc;
         const uint64_t p = shfl_u64(sp, (int)r);
-        tmp[u] = load_chunk<V, NT>(p + (uint64_t)col * CB);
+        tmp[u] = load_chunk<V, true>(p + (uint64_t)col * CB);
       }
 #pragma unroll
       for (int u = 0; u < U; ++u) {
@@ -236,7 +255,7 @@ __global__ __launch_bounds__(kBlock) void k_gather_rows(char *__restrict__ out, 
           const uint32_t r = __umulhi(cc[u], magic) + (rc == 1 ? cc[u] : 0u);
           q = shfl_u64(dp, (int)r) + (uint64_t)(cc[u] - r * rc) * CB;
         }
-        if (c < total) store_chunk<V, NTS>(q, tmp[u]);
+        if (c < total) store_chunk<V, true>(q, tmp[u]);
       }
     }
     sp = sp_n; dp = dp_n; miss = miss_n;
@@ -308,43 +327,31 @@ static int launch_gather(char *out, Rows rows, const uint32_t *dst_index, size_t
     GGMS_LAUNCH_CHECK();
     return GGMS_OK;
   }
-  // rows of a batch are read once: non-temporal loads by default (GGMS_EXTRACT_NT=0 turns them off)
-  static const bool env_nt = [] { const char *e = getenv("GGMS_EXTRACT_NT"); return !(e && e[0] == '0'); }();
-  // the gathered batch is a >100 MB stream that nothing re-reads from cache: non-temporal stores
-  // measured +3..5 % on MI355X (GGMS_EXTRACT_NT_STORE=0 turns them off)
-  static const bool env_nts = [] { const char *e = getenv("GGMS_EXTRACT_NT_STORE"); return !(e && e[0] == '0'); }();
-  const bool nt = env_nt;
   const uint32_t magic = rc == 1 ? 0u : (uint32_t)(((1ull << 32) + rc - 1) / rc);
   // one wave per 64 rows, grid-stride.  The grid is capped at ONE 4-wave block per CU (GGMS_EXTRACT_BLOCKS,
-  // default 256): with 8 x 16-B loads per lane in flight that already streams at the rate of a full-occupancy
-  // launch (measured 236 us vs 244 us at 2048 blocks, products batch), and the free wave slots let the next
-  // batch's latency-bound sampling kernels run beside the gather on another stream (step 0.68 -> 0.55 ms).
+  // default 256 -- the one environment variable the library reads: it moves the memory side's share between the
+  // gather and the sampler beside it, profiles/r03_ab_gather_grid.txt): with 16 x 16-B loads per lane in flight that
+  // already streams at the rate of a full-occupancy launch, and the free wave slots let the next batch's
+  // latency-bound sampling kernels run beside the gather on another stream.
   static const int max_blocks = [] { const char *e = getenv("GGMS_EXTRACT_BLOCKS"); int v = e ? atoi(e) : 256; return v > 0 ? v : 256; }();
   int grid = grid_for(n_max, kBlock);
   if (grid > max_blocks) grid = max_blocks;
-  // 16 independent chunk loads per lane instead of 8 once a row has >= 8 chunks.  Measured on MI355X: the gather
-  // alone 222 -> 215 us at 400-B rows (0.58 -> 0.60 of peak), 0.65 -> 0.70 at 512-B rows, and it holds its rate
-  // when the sampler runs beside it (in-pipeline 289 -> 226 us).  GGMS_EXTRACT_DEEP=0 restores 8 (measurement hook).
-  static const bool env_deep = [] { const char *e = getenv("GGMS_EXTRACT_DEEP"); return !(e && e[0] == '0'); }();
-  const bool deep = env_deep && rc >= 8;
-#define GGMS_LAUNCH_U(CB, ID, NT, NTS, UU)                                                                    \
-  hipLaunchKernelGGL((k_gather_rows<CB, Rows, ID, NT, NTS, UU>), dim3(grid), dim3(kBlock), 0, stream, out, rows, \
-                     dst_index, n, (uint32_t)rc, magic, miss_count)
-#define GGMS_LAUNCH(CB, ID, NT)                                                          \
-  do {                                                                                    \
-    if (deep) {                                                                           \
-      if (env_nts) GGMS_LAUNCH_U(CB, ID, NT, true, 16); else GGMS_LAUNCH_U(CB, ID, NT, false, 16); \
-    } else {                                                                              \
-      if (env_nts) GGMS_LAUNCH_U(CB, ID, NT, true, 8); else GGMS_LAUNCH_U(CB, ID, NT, false, 8);   \
-    }                                                                                     \
+  // 16 independent chunk loads per lane once a row has >= 8 chunks, else 8 (measured: 0.58 -> 0.60 of peak at 400-B
+  // rows, 0.65 -> 0.70 at 512-B rows, and the gather holds its rate when the sampler runs beside it)
+  const bool deep = rc >= 8;
+#define GGMS_LAUNCH(CB, ID)                                                                                          \
+  do {                                                                                                               \
+    if (deep)                                                                                                        \
+      hipLaunchKernelGGL((k_gather_rows<CB, Rows, ID, 16>), dim3(grid), dim3(kBlock), 0, stream, out, rows, dst_index, n, \
+                         (uint32_t)rc, magic, miss_count);                                                           \
+    else                                                                                                             \
+      hipLaunchKernelGGL((k_gather_rows<CB, Rows, ID, 8>), dim3(grid), dim3(kBlock), 0, stream, out, rows, dst_index, n, \
+                         (uint32_t)rc, magic, miss_count);                                                           \
   } while (0)
-#define GGMS_CASE(CB)                                                \
-  case CB:                                                           \
-    if (dst_index == nullptr) {                                      \
-      if (nt) GGMS_LAUNCH(CB, true, true); else GGMS_LAUNCH(CB, true, false);   \
-    } else {                                                         \
-      if (nt) GGMS_LAUNCH(CB, false, true); else GGMS_LAUNCH(CB, false, false); \
-    }                                                                \
+#define GGMS_CASE(CB)                                        \
+  case CB:                                                   \
+    if (dst_index == nullptr) GGMS_LAUNCH(CB, true);         \
+    else GGMS_LAUNCH(CB, false);                             \
     break;
   switch (cb) {
     GGMS_CASE(16)
@@ -355,7 +362,6 @@ static int launch_gather(char *out, Rows rows, const uint32_t *dst_index, size_t
   }
 #undef GGMS_CASE
 #undef GGMS_LAUNCH
-#undef GGMS_LAUNCH_U
   GGMS_LAUNCH_CHECK();
   return GGMS_OK;
 }
@@ -422,38 +428,43 @@ int ggms_mock_extract(void *dst, const void *src, const ggms_id_t *index, size_t
   return ggms_gather_scatter_masked(dst, src, index, nullptr, num_index, nullptr, dim, dtype, mask, stream);
 }
 
-int ggms_gather_scatter_partition(void *out, const void *const *parts_dev, uint32_t num_part,
+int ggms_gather_scatter_partition(void *out, const void *const *parts, uint32_t num_part,
                                   const ggms_id_t *src_index, const ggms_id_t *dst_index, size_t num,
                                   const uint64_t *num_dev, size_t dim, int dtype, ggms_stream_t stream) {
   const size_t es = ggms_dtype_bytes(dtype);
   GGMS_CHECK_ARG(es != 0 && dim != 0 && num_part != 0);
   if (num == 0) return GGMS_OK;
-  GGMS_CHECK_ARG(out && parts_dev && src_index);
+  GGMS_CHECK_ARG(out && parts && src_index);
   const size_t row_bytes = dim * es;
   // shard bases come from hipMalloc / hipIpcOpenMemHandle / hipHostMalloc: >= 256-B aligned
   const int cb = pick_chunk(row_bytes, (uintptr_t)out);
-  PartitionRows rows{(const char *const *)parts_dev, src_index, row_bytes, num_part};
+  PartPtrs pp;
+  if (!part_ptrs(parts, num_part, pp)) return GGMS_ERR_INVALID;
+  PartitionRows rows{pp, src_index, row_bytes, divisor_of(num_part)};
   return launch_gather((char *)out, rows, dst_index, num, count_of(num, num_dev), row_bytes, cb, nullptr,
                        to_stream(stream));
 }
 
 int ggms_extract_cached(void *out, const ggms_id_t *nodes, size_t num_nodes, const uint64_t *num_nodes_dev,
-                        const ggms_id_t *table, const void *const *parts_dev, uint32_t num_part,
+                        const ggms_id_t *table, const void *const *parts, uint32_t num_part,
                         const void *host_feat, size_t dim, int dtype, uint64_t *num_miss_dev,
                         ggms_stream_t stream) {
   const size_t es = ggms_dtype_bytes(dtype);
   GGMS_CHECK_ARG(es != 0 && dim != 0);
   if (num_nodes == 0) return GGMS_OK;
-  GGMS_CHECK_ARG(out && nodes && parts_dev);
+  GGMS_CHECK_ARG(out && nodes && parts);
   const size_t row_bytes = dim * es;
+  PartPtrs pp;
+  if (!part_ptrs(parts, num_part, pp)) return GGMS_ERR_INVALID;
+  const Divisor div = divisor_of(num_part ? num_part : 1);
   if (!table) { // full cache in node order: slot = node id
-    IdentRows rows{(const char *const *)parts_dev, nodes, row_bytes, num_part};
+    IdentRows rows{pp, nodes, row_bytes, div};
     if (num_miss_dev) GGMS_HIP(hipMemsetAsync(num_miss_dev, 0, sizeof(uint64_t), to_stream(stream)));
     return launch_gather((char *)out, rows, nullptr, num_nodes, count_of(num_nodes, num_nodes_dev), row_bytes,
                          pick_chunk(row_bytes, (uintptr_t)out), nullptr, to_stream(stream));
   }
   const int cb = pick_chunk(row_bytes, (uintptr_t)out | (uintptr_t)host_feat);
-  CachedRows rows{(const char *const *)parts_dev, nodes, table, (const char *)host_feat, row_bytes, num_part};
+  CachedRows rows{pp, nodes, table, (const char *)host_feat, row_bytes, div};
   return launch_gather((char *)out, rows, nullptr, num_nodes, count_of(num_nodes, num_nodes_dev), row_bytes,
                        cb, num_miss_dev, to_stream(stream));
 }
@@ -464,13 +475,15 @@ int ggms_extract_tiered(void *out, const ggms_id_t *nodes, size_t num_nodes, con
   const size_t es = ggms_dtype_bytes(dtype);
   GGMS_CHECK_ARG(es != 0 && dim != 0 && tiers);
   if (num_nodes == 0) return GGMS_OK;
-  GGMS_CHECK_ARG(out && nodes && tiers->parts_dev && tiers->num_part >= 1 && tiers->my_part < tiers->num_part);
+  GGMS_CHECK_ARG(out && nodes && tiers->parts && tiers->num_part >= 1 && tiers->my_part < tiers->num_part);
   GGMS_CHECK_ARG(tiers->num_replica == 0 || tiers->replica);
   GGMS_CHECK_ARG(tiers->num_replica < (1ull << 32));
   const size_t row_bytes = dim * es;
   const int cb = pick_chunk(row_bytes, (uintptr_t)out | (uintptr_t)tiers->host_feat | (uintptr_t)tiers->replica);
-  TieredRows rows{(const char *const *)tiers->parts_dev, nodes, tiers->table, (const char *)tiers->host_feat,
-                  (const char *)tiers->replica, row_bytes, (uint32_t)tiers->num_replica, tiers->num_part,
+  PartPtrs pp;
+  if (!part_ptrs(tiers->parts, tiers->num_part, pp)) return GGMS_ERR_INVALID;
+  TieredRows rows{pp, nodes, tiers->table, (const char *)tiers->host_feat,
+                  (const char *)tiers->replica, row_bytes, (uint32_t)tiers->num_replica, divisor_of(tiers->num_part),
                   tiers->my_part, tiers->host_row_mask ? tiers->host_row_mask : 0xffffffffu};
   return launch_gather((char *)out, rows, nullptr, num_nodes, count_of(num_nodes, num_nodes_dev), row_bytes, cb,
                        tier_rows_dev, to_stream(stream));

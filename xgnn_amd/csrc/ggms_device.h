@@ -35,18 +35,9 @@ void set_error(const char *fmt, ...);
 
 inline hipStream_t to_stream(ggms_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 
-// Grid for a grid-stride kernel over n items.  The cap decides how a kernel shares the chip with the other
-// stream: 2048 blocks x 256 threads is every wave slot of the device (256 CUs x 32 waves) held for the whole
-// kernel, so a kernel arriving on the other stream waits it out; a grid of many short-lived blocks frees
-// slots all the time and the dispatcher interleaves the two queues.  GGMS_GRID_CAP overrides (measurement hook).
-inline size_t grid_cap() {
-  static const size_t cap = [] {
-    const char *e = getenv("GGMS_GRID_CAP");
-    const long v = e ? atol(e) : 0;
-    return v > 0 ? (size_t)v : (size_t)kMaxGridBlocks;
-  }();
-  return cap;
-}
+// Grid for a grid-stride kernel over n items, capped at every wave slot of the device (256 CUs x 32 waves =
+// 2048 blocks x 256 threads).
+inline size_t grid_cap() { return (size_t)kMaxGridBlocks; }
 inline int grid_for(size_t n, size_t per_block) {
   size_t g = (n + per_block - 1) / per_block;
   if (g < 1) g = 1;
@@ -54,14 +45,16 @@ inline int grid_for(size_t n, size_t per_block) {
   return (int)g;
 }
 
-// ---- device status word ---------------------------------------------------------
-// One sticky 32-bit word per device (allocated on first use): a kernel that hits a bound it must not hit
-// ORs a bit in instead of hanging or carrying on silently; ggms_sample_batch copies it into
-// counts_dev[3 L + 1], ggms_device_status() reads it.  The reference CHECK-aborts in these places
-// (logging.cc:69-73); the engine does the same once it has seen the word.
+// ---- status words ---------------------------------------------------------------
+// A kernel that hits a bound it must not hit ORs a bit into a status word instead of hanging or carrying on
+// silently.  Leaf operators use the sticky word of the device (allocated on first use, read by
+// ggms_device_status()); the kernels of a ggms_sample_batch call use the BATCH's own word -- the one behind its
+// table's item counter -- which the batch's last kernel moves into counts_dev[3 L + 1] (include/ggms.h).  The
+// reference CHECK-aborts in these places (logging.cc:69-73); the engine does the same once it has seen the word.
 constexpr uint32_t kErrScanSpin = 1u;    // decoupled look-back gave up waiting for a predecessor tile
 constexpr uint32_t kErrTableFull = 2u;   // hashed dedup table: probing found no free bucket
 uint32_t *device_status_word();          // common.hip; NULL if it cannot be allocated
+long long debug_knob(int knob);          // common.hip: ggms_debug_set_knob's value, -1 = default
 
 // ---- a count that lives either in an argument or in device memory ---------
 // Lets a whole mini-batch be enqueued without a host round trip: the size of
@@ -77,12 +70,47 @@ struct Count {
 inline Count count_of(size_t n, const uint64_t *dev = nullptr) { return Count{dev, nullptr, (uint64_t)n}; }
 inline Count count_of32(size_t n, const uint32_t *dev) { return Count{nullptr, dev, (uint64_t)n}; }
 
+// ---- v / d and v % d by a launch constant ------------------------------------------------------------------
+// q' = mulhi(v, floor(2^32 / d)) is q or q - 1 (v * (2^32 - m d) / (d 2^32) < v / 2^32 < 1): one fix-up.  d = 1 takes
+// m = 2^32 - 1 (q' = v - 1 for v >= 1, fixed up to v).  A 32-bit division by a runtime value is ~25 instructions on
+// this ISA (v_rcp_f32 + Newton step + fix-ups); shard counts are launch constants.
+struct Divisor {
+  uint32_t d, magic;
+  __device__ __forceinline__ void divmod(uint32_t v, uint32_t &q, uint32_t &r) const {
+    q = __umulhi(v, magic);
+    r = v - q * d;
+    const bool up = r >= d;
+    q += up ? 1u : 0u;
+    r -= up ? d : 0u;
+  }
+};
+inline Divisor divisor_of(uint32_t d) {
+  return Divisor{d, d <= 1 ? 0xffffffffu : (uint32_t)(0x100000000ull / d)};
+}
+
+// ---- shard base pointers, by value ------------------------------------------------------------------------
+// The pointers of up to GGMS_MAX_PARTS shards (+ one host slot) travel in the kernel arguments: a lane picks its
+// shard's pointer with a chain of selects on registers instead of a dependent load from a device-side pointer table
+// (the reference's DeviceDistGraph / DeviceDistFeature read `part_indptr[part]` from global memory before the first
+// useful request of every lookup can be issued, dist_graph.h:150-157,196-204).
+constexpr uint32_t kMaxParts = GGMS_MAX_PARTS;
+template <typename T, uint32_t N>
+struct PtrSet {
+  T *p[N];
+  __device__ __forceinline__ T *pick(uint32_t k) const {
+    T *r = p[0];
+#pragma unroll
+    for (uint32_t i = 1; i < N; ++i) r = (k == i) ? p[i] : r;
+    return r;
+  }
+};
+
 // ---- graph views (DeviceNormalGraph / DeviceDistGraph) ---------------------
 struct GraphView {
   const uint32_t *indptr;
   const uint32_t *indices;
-  const uint32_t *const *part_indptr;
-  const uint32_t *const *part_indices;
+  PtrSet<const uint32_t, kMaxParts + 1> pip, pix; // shard p at [p]; the whole CSR (host tier) ALWAYS at [kMaxParts]
+  Divisor part;                                   // d = num_part
   uint32_t num_part;
   uint32_t num_cache_node;
 
@@ -102,24 +130,41 @@ struct GraphView {
       len = e - b;
       return indices + b;
     }
-    uint32_t part, real;
-    if (v < num_cache_node) {
-      part = v % num_part;
-      real = v / num_part;
-    } else {
-      part = num_part; // whole CSR (host tier) in the last slot
-      real = v;
-    }
+    // DeviceDistGraph::operator[] / NumEdge (dist_graph.h:132-158): v < num_cache_node -> shard v % P, row v / P;
+    // every other node in the whole CSR of the last slot
+    uint32_t slot, real;
+    part.divmod(v, real, slot);
+    const bool cached = v < num_cache_node;
+    slot = cached ? slot : kMaxParts;
+    real = cached ? real : v;
     uint32_t b, e;
-    bounds(part_indptr[part], real, b, e);
+    bounds(pip.pick(slot), real, b, e);
     len = e - b;
-    return part_indices[part] + b;
+    return pix.pick(slot) + b;
   }
 };
 
-inline GraphView view_of(const ggms_graph_t *g) {
-  return GraphView{g->indptr, g->indices, g->part_indptr, g->part_indices, g->num_part,
-                   g->num_cache_node};
+// host side: NULL + an error message if the graph has more shards than the kernels carry
+inline bool view_of(const ggms_graph_t *g, GraphView &v) {
+  v = GraphView{};
+  v.indptr = g->indptr;
+  v.indices = g->indices;
+  v.num_part = g->num_part;
+  v.num_cache_node = g->num_cache_node;
+  v.part = divisor_of(g->num_part ? g->num_part : 1);
+  if (g->num_part == 0) return true;
+  if (g->num_part > kMaxParts || !g->part_indptr || !g->part_indices) {
+    set_error("graph view: num_part %u (at most %u shards; part_indptr / part_indices are HOST arrays of num_part + 1 device pointers)",
+              g->num_part, kMaxParts);
+    return false;
+  }
+  for (uint32_t p = 0; p < g->num_part; ++p) {
+    v.pip.p[p] = g->part_indptr[p];
+    v.pix.p[p] = g->part_indices[p];
+  }
+  v.pip.p[kMaxParts] = g->part_indptr[g->num_part];
+  v.pix.p[kMaxParts] = g->part_indices[g->num_part];
+  return true;
 }
 
 // ---- XORWOW, bit-compatible with cuRAND's curand_init(seed,0,0)/curand() ---

@@ -28,7 +28,7 @@ int sample_khop0_impl(GraphView g, const uint32_t *input, size_t n_max, Count n,
 int sample_khop2_impl(const uint32_t *indptr, uint32_t *indices, size_t num_node, const uint32_t *input, size_t n_max,
                       Count n, uint32_t fanout, uint32_t *out_src, uint32_t *out_dst, uint64_t *num_out_dev,
                       uint32_t *states, uint32_t *workspace, const uint32_t *seed_local, int src_local, hipStream_t s,
-                      ScanArea *shared_scan = nullptr, const DedupInsert *insert = nullptr);
+                      ScanArea *shared_scan = nullptr);
 
 // sample_weighted.hip
 size_t weighted_ws_words(size_t num_input, size_t fanout);

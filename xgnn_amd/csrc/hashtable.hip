@@ -201,14 +201,22 @@ __global__ __launch_bounds__(kBlock) void k_map_rest(Table t, const uint32_t *__
     }
 }
 
+// the last kernel of a batch moves the BATCH's status word (the word behind its table's item counter; every kernel
+// of the batch reports into that word only) into the batch's counts: exchange with 0, so the next batch on this
+// table starts clean; a failure is also recorded in the device's sticky word (ggms_device_status)
+__device__ __forceinline__ void take_batch_status(uint32_t *status, uint32_t *device_word, uint64_t *status_out) {
+  const uint32_t v = status ? atomicExch(status, 0u) : 0u;
+  *status_out = v;
+  if (v && device_word) atomicOr(device_word, v);
+}
+
 // Batch mode, every layer in ONE launch (blockIdx.y = job): the instances that lost to another instance of their
 // own fill.  A key's word is final once its fill is over, so the look-ups of all layers can wait until the last
-// fill is done.  Also hands the device status word to the batch's counts (counts_dev[3 L + 1]).
+// fill is done.  Also hands the batch's status word to the batch's counts (counts_dev[3 L + 1]).
 __global__ __launch_bounds__(kBlock) void k_map_rest_all(const unsigned long long *__restrict__ w, MapRestJobs jobs,
-                                                         IdxMap map, uint32_t *status, uint64_t *status_out) {
-  // the batch TAKES the device word (exchange with 0): a failure is reported to the batch that ends next, once,
-  // and does not mark every later batch of the device as failed
-  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && status_out) *status_out = status ? atomicExch(status, 0u) : 0u;
+                                                         IdxMap map, uint32_t *status, uint32_t *device_word,
+                                                         uint64_t *status_out) {
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && status_out) take_batch_status(status, device_word, status_out);
   const uint32_t l = blockIdx.y;
   uint32_t *__restrict__ row = jobs.row[l];
   const uint32_t *__restrict__ key = jobs.key[l];
@@ -695,10 +703,7 @@ __global__ __launch_bounds__(kBlock) void k_owner_scan_chunked(unsigned long lon
 
 static std::atomic<bool> g_poison_next_scan{false};
 
-static size_t owner_scan_grid_cap() { // GGMS_OSCAN_GRID: measurement hook
-  static const size_t v = [] { const char *e = getenv("GGMS_OSCAN_GRID"); const long x = e ? atol(e) : 0; return x > 0 ? (size_t)x : (size_t)512; }();
-  return v;
-}
+constexpr size_t kOwnerScanTileGrid = 512; // workgroups of the tile-chained form
 
 // descriptors the owner scan needs for n_max items (64-bit words behind the 8 control words)
 size_t owner_scan_tiles(size_t n_max) { return (n_max + kOwnTile - 1) / kOwnTile; }
@@ -707,21 +712,24 @@ size_t owner_scan_tiles(size_t n_max) { return (n_max + kOwnTile - 1) / kOwnTile
 size_t ht_ws_words(size_t num_input) { return 3 * num_input + tile_scan_words(num_input) + 24 + chunk_desc_words(); }
 size_t chunk_desc_words() { return kChunkGrid + 8; }
 
-__global__ void k_status_copy(uint32_t *status, uint64_t *status_out) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) *status_out = status ? atomicExch(status, 0u) : 0u;
+__global__ void k_status_copy(uint32_t *status, uint32_t *device_word, uint64_t *status_out) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) take_batch_status(status, device_word, status_out);
 }
 
+// status_out != NULL: this is the batch's last launch -- it takes the batch's status word (ht->num_items_dev + 1)
 int launch_map_rest_all(const ggms_hashtable_t *ht, const MapRestJobs &jobs, uint32_t num_jobs, size_t max_items,
                         const IdxMap &map, uint64_t *status_out, hipStream_t s) {
+  uint32_t *batch_status = status_out ? ht->num_items_dev + 1 : nullptr;
+  uint32_t *device_word = status_out ? device_status_word() : nullptr;
   if (num_jobs == 0) { // nothing deferred (hashed layout, or no layer could sample): only the status word
     if (!status_out) return GGMS_OK;
-    hipLaunchKernelGGL(k_status_copy, dim3(1), dim3(64), 0, s, device_status_word(), status_out);
+    hipLaunchKernelGGL(k_status_copy, dim3(1), dim3(64), 0, s, batch_status, device_word, status_out);
     GGMS_LAUNCH_CHECK();
     return GGMS_OK;
   }
   const int gx = grid_for(max_items ? max_items : 1, kBlock);
   hipLaunchKernelGGL(k_map_rest_all, dim3(gx, num_jobs), dim3(kBlock), 0, s, (const unsigned long long *)ht->o2n, jobs, map,
-                     status_out ? device_status_word() : (uint32_t *)nullptr, status_out);
+                     batch_status, device_word, status_out);
   GGMS_LAUNCH_CHECK();
   return GGMS_OK;
 }
@@ -745,7 +753,7 @@ int ht_fill_impl(const ggms_hashtable_t *ht, const uint32_t *input, size_t n_max
     return GGMS_OK;
   }
   Table t = table_of(ht);
-  uint32_t *err = device_status_word();
+  uint32_t *err = scratch.status_word(); // the batch's own word, or the device's sticky one (leaf operators)
   const int grid = grid_for(n_max, kBlock);
   uint32_t *item_pos = di.cand; // hashed layout: bucket positions
   if (!ht->direct) {
@@ -774,15 +782,12 @@ int ht_fill_impl(const ggms_hashtable_t *ht, const uint32_t *input, size_t n_max
   // bound -- the failure the status word exists for
   const bool poisoned = !scratch.cleared && g_poison_next_scan.exchange(false);
   if (poisoned) GGMS_HIP(hipMemsetD32Async((hipDeviceptr_t)ctl, 1, 1, s));
-  // chunked form (one ticket, one look-back per workgroup) wherever the caller's scan area has room for its
-  // descriptors; GGMS_OSCAN=tiles keeps the tile-chained kernel (measurement hook)
-  static const bool force_tiles = [] { const char *e = getenv("GGMS_OSCAN"); return e && e[0] == 't'; }();
-  // GGMS_OSCAN_CHUNK_GRID: fewer chunks than kChunkGrid (tests: chunks too long for registers take the two-pass form)
-  static const size_t chunk_grid = [] {
-    const char *e = getenv("GGMS_OSCAN_CHUNK_GRID");
-    const long v = e ? atol(e) : 0;
-    return v > 0 && v < (long)kChunkGrid ? (size_t)v : (size_t)kChunkGrid;
-  }();
+  // chunked form (no ticket, one look-back per workgroup) wherever the caller's scan area has room for its
+  // descriptors.  Test aids (ggms_debug_set_knob): the tile-chained kernel, which otherwise only runs beyond 65 M
+  // items, and fewer chunks than kChunkGrid (chunks too long for registers take the two-pass form)
+  const bool force_tiles = debug_knob(GGMS_DEBUG_OWNER_SCAN_TILES) > 0;
+  const long long knob_chunks = debug_knob(GGMS_DEBUG_OWNER_SCAN_CHUNKS);
+  const size_t chunk_grid = knob_chunks > 0 && knob_chunks < (long long)kChunkGrid ? (size_t)knob_chunks : (size_t)kChunkGrid;
   const int cgrid = (int)std::min<size_t>(std::max<size_t>(owner_scan_tiles(n_max), 1), chunk_grid);
   // a chunk's owner count travels in 16 bits: at most kChunkMaxTiles tiles per chunk (65 M items at the full grid);
   // beyond that the tile-chained kernel runs
@@ -807,7 +812,7 @@ int ht_fill_impl(const ggms_hashtable_t *ht, const uint32_t *input, size_t n_max
     // Fewer workgroups than tiles on purpose: a workgroup takes tiles from the ticket one after the other, so by the
     // time tile t is taken the tiles before t - grid have finished and the look-back finds a published prefix in
     // its first window; with one workgroup per tile every tile starts at once and tile t walks t / 64 windows.
-    const int oscan_grid = (int)std::min<size_t>(grid_for(owner_scan_tiles(n_max), 1), owner_scan_grid_cap());
+    const int oscan_grid = (int)std::min<size_t>(grid_for(owner_scan_tiles(n_max), 1), kOwnerScanTileGrid);
     if (di.batch)
       hipLaunchKernelGGL(k_owner_scan<true>, dim3(oscan_grid), dim3(kBlock), 0, s, di.w, di.version, ht->n2o, input, di.cand,
                          di.lost, di.tag, mapped, n, ctl, desc, next_scan_epoch(), ht->num_items_dev, mirror_a, mirror_b, err);
@@ -854,7 +859,7 @@ int ggms_hashtable_init(ggms_hashtable_t *ht, ggms_stream_t stream) {
   GGMS_CHECK_ARG(ht->direct || (ht->o2n_size & (ht->o2n_size - 1)) == 0);
   GGMS_HIP(hipMemsetAsync(ht->o2n, 0xff, ht->o2n_size * (ht->direct ? 8 : 16), to_stream(stream)));
   GGMS_HIP(hipMemsetAsync(ht->n2o, 0xff, ht->n2o_size * sizeof(uint32_t), to_stream(stream)));
-  GGMS_HIP(hipMemsetAsync(ht->num_items_dev, 0, sizeof(uint32_t), to_stream(stream)));
+  GGMS_HIP(hipMemsetAsync(ht->num_items_dev, 0, 2 * sizeof(uint32_t), to_stream(stream))); // item count + batch status
   ht->version = 0;
   return GGMS_OK;
 }

@@ -198,8 +198,13 @@ int ggms_sample_batch(int sample_type, const ggms_graph_t *graph, const ggms_id_
   ScanArea scan{w + lay.scan, true};
   scan.chunk = w + lay.chunk;
   scan.tickets = scan.chunk + chunk_desc_words(); // chunk_desc_words() is a multiple of 4: the sets stay 16-byte aligned
+  // every kernel of this batch reports a bound it hits into the BATCH's status word (behind the table's item counter;
+  // zero since ggms_hashtable_init or the previous batch's last kernel), never into a word shared with the batches
+  // in flight beside it (include/ggms.h, "Status words")
+  scan.status = ht->num_items_dev + 1;
 
-  const GraphView g = view_of(graph);
+  GraphView g;
+  if (!view_of(graph, g)) return GGMS_ERR_INVALID;
   // hash_table->Reset (dist_loops.cc:105): a new version stamp; the item count is zeroed by the prologue below
   if (ht->version >= 0x7ffffff0u) {
     int rc0 = ggms_hashtable_init(ht, stream);
@@ -209,8 +214,7 @@ int ggms_sample_batch(int sample_type, const ggms_graph_t *graph, const ggms_id_
   // FillWithDupRevised(seeds), dist_loops.cc:110-111, + the local ids of the raw seeds (they may repeat): the
   // first layer's `col`.  Its insert kernel is the first kernel of the batch and carries the prologue:
   // scan-area clear, item count reset, num_dst of the first layer = |seeds| (dist_loops.cc:305).
-  const size_t clear_words = scan_mode() == 1 ? 8 + 2 * (num_tiles_for(std::max(c.max_e_all, c.max_in_all)) + 1) : 0;
-  const BatchPrologue pro{scan_align(scan.words), (uint32_t)std::max<size_t>(8 + 2 * lay.scan_tiles, clear_words),
+  const BatchPrologue pro{scan_align(scan.words), (uint32_t)(8 + 2 * lay.scan_tiles),
                           scan.chunk, (uint32_t)(chunk_desc_words() + (size_t)kTicketSets * kTicketWords), ht->num_items_dev,
                           counts_dev + 3 * (num_layer - 1) + 2};
   // direct table = batch mode of the dedup protocol (ggms_device.h): one index space for the whole batch, seeds first
@@ -261,15 +265,12 @@ int ggms_sample_batch(int sample_type, const ggms_graph_t *graph, const ggms_id_
       rc = sample_khop0_impl(g, input, n_max, n, (uint32_t)fanouts[i], col[i], tmp_dst, num_edge, samp_ws,
                              first ? seed_local : nullptr, 1, s, &scan, inserted ? &di : nullptr);
     } else if (sample_type == GGMS_KHOP2) {
-      // no fused insert by default: even with the four seeds of a lane in lock-step and their atomics issued
-      // together, the returning atomics sit in the draw loop's dependency chain (measured on products: 0.45 -> 0.62 ms
-      // per step).  GGMS_KHOP2_FUSED=1 turns it on (measurement hook).
-      static const bool fuse2 = [] { const char *e = getenv("GGMS_KHOP2_FUSED"); return e && e[0] == '1'; }();
-      inserted = fuse2 && ht->direct != 0 && e_max != 0;
-      if (inserted) di.tag = next_dedup_tag();
+      // no fused insert: even with the four seeds of a lane in lock-step and their atomics issued together, the
+      // returning atomics sit in the draw loop's dependency chain (measured on products: 0.45 -> 0.62 ms per step;
+      // the separate insert launch of ht_fill_impl follows)
       rc = sample_khop2_impl(graph->indptr, const_cast<uint32_t *>(graph->indices), graph->num_node, input, n_max, n,
                              (uint32_t)fanouts[i], col[i], tmp_dst, num_edge, (uint32_t *)states, samp_ws,
-                             first ? seed_local : nullptr, 1, s, &scan, inserted ? &di : nullptr);
+                             first ? seed_local : nullptr, 1, s, &scan);
     } else if (sample_type == GGMS_KHOP1) {
       inserted = ht->direct != 0 && e_max != 0; // the weighted family enters its output in the compaction's emit
       if (inserted) di.tag = next_dedup_tag();

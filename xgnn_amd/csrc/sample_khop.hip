@@ -592,6 +592,8 @@ __global__ __launch_bounds__(1024) void k_khop0_resolve_heavy(GraphView g, const
 // per lane instead of 4 x fanout, with identical draws and an identical final state.
 // The compact COO is written directly at the seed's scanned offset.  Seeds of one call
 // must be distinct (two copies of a seed would race on the same list, as in the reference).
+// The batch enters the output into its dedup table with a separate launch: a returning atomic
+// in the draw loop sits on the lane's dependency chain (measured 0.45 -> 0.62 ms per products step).
 // One wave per workgroup (a quarter of a reference block): every memory instruction of this kernel touches 64
 // different lines, so the CU's address path, shared by the waves of a workgroup, is what a 256-thread block waits
 // for (measured: 8000 seeds = 8 blocks took 50 us by themselves); spread over four times as many CUs it does not.
@@ -600,7 +602,7 @@ __global__ __launch_bounds__(kWave) void k_sample_khop2(const uint32_t *__restri
                                                          uint32_t fanout, const uint32_t *__restrict__ offset,
                                                          uint32_t *__restrict__ out_src,
                                                          uint32_t *__restrict__ out_dst,
-                                                         uint32_t *__restrict__ states, SrcMode sm, DedupInsert di) {
+                                                         uint32_t *__restrict__ states, SrcMode sm) {
   const uint64_t n = n_arg.get();
   const uint64_t num_tiles = (n + 1023) / 1024;
   for (uint64_t q = blockIdx.x; q < 4 * num_tiles; q += gridDim.x) {
@@ -653,19 +655,6 @@ __global__ __launch_bounds__(kWave) void k_sample_khop2(const uint32_t *__restri
               out_src[o[r] + j0 + u] = sv[r];
               out_dst[o[r] + j0 + u] = v[r][u];
             }
-        if (di.w) {
-          unsigned long long old[4][4];
-#pragma unroll
-          for (uint32_t r = 0; r < 4; ++r)
-#pragma unroll
-            for (uint32_t u = 0; u < 4; ++u)
-              if (!draws[r] && j0 + u < len[r]) old[r][u] = di.issue(v[r][u], o[r] + j0 + u);
-#pragma unroll
-          for (uint32_t r = 0; r < 4; ++r)
-#pragma unroll
-            for (uint32_t u = 0; u < 4; ++u)
-              if (!draws[r] && j0 + u < len[r]) di.finish(old[r][u], o[r] + j0 + u);
-        }
       }
     }
     if (!(draws[0] || draws[1] || draws[2] || draws[3])) continue; // stream untouched
@@ -687,20 +676,13 @@ __global__ __launch_bounds__(kWave) void k_sample_khop2(const uint32_t *__restri
         picked[r] = indices[off[r] + sel[r]];
         moved[r] = indices[off[r] + tail[r]];
       }
-      unsigned long long old[4];
 #pragma unroll
       for (uint32_t r = 0; r < 4; ++r) {
         if (!draws[r]) continue;
         out_src[o[r] + j] = sv[r];
         out_dst[o[r] + j] = picked[r];
-        if (di.w) old[r] = di.issue(picked[r], o[r] + j);
         indices[off[r] + sel[r]] = moved[r];
         indices[off[r] + tail[r]] = picked[r];
-      }
-      if (di.w) {
-#pragma unroll
-        for (uint32_t r = 0; r < 4; ++r)
-          if (draws[r]) di.finish(old[r], o[r] + j);
       }
     }
     st[3].store(states + 6 * sid); // past its own draws, or -- a short last list -- still where seed 2 ended
@@ -711,16 +693,8 @@ __global__ __launch_bounds__(kWave) void k_sample_khop2(const uint32_t *__restri
 // is 8 groups): one group per wave (512 threads per tile) for the first layers of a batch, two (256 threads) beyond.
 // Four groups per wave (128 threads per tile: the densest draws phase) measured 5 % slower on products [25,10], 14 % on
 // papers100M [25,10] and 1 % on the papers100M GCN layers: the sweep of a tile is a latency chain, twice the lanes
-// halve its rounds (profiles/r03_ab_khop3_groups_per_wave.txt).  GGMS_KHOP3_GPW=1|2|4 pins it (measurement hook).
-static int khop3_groups_per_wave(size_t blocks) {
-  static const int pinned = [] {
-    const char *e = getenv("GGMS_KHOP3_GPW");
-    return e ? atoi(e) : 0;
-  }();
-  if (pinned == 1 || pinned == 2 || pinned == 4) return pinned;
-  if (blocks * 8 <= 2048) return 1;
-  return 2;
-}
+// halve its rounds (profiles/r03_ab_khop3_groups_per_wave.txt) -- not built any more.
+static int khop3_groups_per_wave(size_t blocks) { return blocks * 8 <= 2048 ? 1 : 2; }
 
 size_t sample_ws_words(size_t num_input) {
   return num_input + tile_scan_words(num_input) + 16 + 2 * (num_input / 128 + 2) + kTicketWords + 16;
@@ -761,26 +735,23 @@ int sample_khop3_impl(GraphView g, const uint32_t *input, size_t n_max, Count n,
   else if (!shared_scan->cleared)
     GGMS_HIP(hipMemsetAsync(ctl, 0, (8 + 2 * (tiles + 1)) * sizeof(uint32_t), s));
   const FusedScan fs{tick, reinterpret_cast<unsigned long long *>(ctl + 8), next_scan_epoch(), num_out_dev,
-                     device_status_word(), scan_patience()};
+                     shared_scan ? shared_scan->status_word() : device_status_word(), scan_patience()};
   const SrcMode sm{seed_local, src_local};
   // 64 slots up to fanout 31 (load < 0.5), else the reference's 128 (HASHTABLE_SIZE, khop3.cu:43)
   const uint32_t set_mask = fanout < 32 ? 63u : 127u;
   const int gpw = khop3_groups_per_wave(tiles);
   const int grid = grid_for(tiles, 1);
-  // every workgroup has at most one tile: the sweep keeps four slots per lane in flight (GGMS_KHOP3_MULTI=0/1 pins it)
-  static const int pin_multi = [] { const char *e = getenv("GGMS_KHOP3_MULTI"); return e ? atoi(e) : -1; }();
-  const uint32_t multi = pin_multi >= 0 ? (uint32_t)(pin_multi != 0) : (tiles <= grid_cap() ? 1u : 0u);
+  // every workgroup has at most one tile: the sweep keeps four slots per lane in flight
+  const uint32_t multi = tiles <= grid_cap() ? 1u : 0u;
   const size_t lds = 128 * (size_t)fanout * sizeof(uint32_t);
   const DedupInsert none{};
   int rc_l = GGMS_OK;
   if (insert) {
     if (gpw == 1) rc_l = launch_khop3_fused<1, true>(grid, lds, s, g, input, n, fanout, out_src, out_dst, sm, states, set_mask, multi, fs, *insert);
-    else if (gpw == 2) rc_l = launch_khop3_fused<2, true>(grid, lds, s, g, input, n, fanout, out_src, out_dst, sm, states, set_mask, multi, fs, *insert);
-    else rc_l = launch_khop3_fused<4, true>(grid, lds, s, g, input, n, fanout, out_src, out_dst, sm, states, set_mask, multi, fs, *insert);
+    else rc_l = launch_khop3_fused<2, true>(grid, lds, s, g, input, n, fanout, out_src, out_dst, sm, states, set_mask, multi, fs, *insert);
   } else {
     if (gpw == 1) rc_l = launch_khop3_fused<1, false>(grid, lds, s, g, input, n, fanout, out_src, out_dst, sm, states, set_mask, multi, fs, none);
-    else if (gpw == 2) rc_l = launch_khop3_fused<2, false>(grid, lds, s, g, input, n, fanout, out_src, out_dst, sm, states, set_mask, multi, fs, none);
-    else rc_l = launch_khop3_fused<4, false>(grid, lds, s, g, input, n, fanout, out_src, out_dst, sm, states, set_mask, multi, fs, none);
+    else rc_l = launch_khop3_fused<2, false>(grid, lds, s, g, input, n, fanout, out_src, out_dst, sm, states, set_mask, multi, fs, none);
   }
   if (rc_l != GGMS_OK) return rc_l;
   GGMS_LAUNCH_CHECK();
@@ -789,11 +760,6 @@ int sample_khop3_impl(GraphView g, const uint32_t *input, size_t n_max, Count n,
 
 // draws parked per launch: 8 per output slot (a frontier whose mean degree stays under 9 x fanout fits entirely)
 size_t khop0_draw_cap(size_t num_input, size_t fanout) {
-  static const long long forced = [] { // test hook: GGMS_KHOP0_CAP=<draws> (small values exercise the in-place path)
-    const char *e = getenv("GGMS_KHOP0_CAP");
-    return e ? atoll(e) : -1ll;
-  }();
-  if (forced >= 0) return (size_t)forced;
   const unsigned long long want = 8ull * num_input * fanout;
   return (size_t)(want < 0x7fffffffull ? want : 0x7fffffffull);
 }
@@ -811,7 +777,11 @@ int sample_khop0_impl(GraphView g, const uint32_t *input, size_t n_max, Count n,
   uint32_t *heavy_count = heavy_list + n_max;
   uint32_t *scan_scr = heavy_count + 16;
   uint32_t *raw = scan_scr + tile_scan_words(n_max) + 16;
-  const uint32_t cap = (uint32_t)khop0_draw_cap(n_max, fanout);
+  // ggms_debug_set_knob(GGMS_DEBUG_KHOP0_DRAW_CAP) (tests): a SMALLER buffer than the workspace holds -- seeds whose
+  // draws do not fit are resolved in place by the generating lanes
+  const long long forced_cap = debug_knob(GGMS_DEBUG_KHOP0_DRAW_CAP);
+  const size_t full_cap = khop0_draw_cap(n_max, fanout);
+  const uint32_t cap = (uint32_t)(forced_cap >= 0 && (size_t)forced_cap < full_cap ? (size_t)forced_cap : full_cap);
   const ScanArea sa = shared_scan ? *shared_scan : ScanArea{scan_scr, false};
   int rc = tile_scan(SeedCount{g, input, fanout}, StoreOffset{offset}, n_max, n, sa, nullptr, nullptr,
                      num_out_dev, s);
@@ -854,17 +824,18 @@ int sample_khop0_impl(GraphView g, const uint32_t *input, size_t n_max, Count n,
 int sample_khop2_impl(const uint32_t *indptr, uint32_t *indices, size_t num_node, const uint32_t *input, size_t n_max,
                       Count n, uint32_t fanout, uint32_t *out_src, uint32_t *out_dst, uint64_t *num_out_dev,
                       uint32_t *states, uint32_t *workspace, const uint32_t *seed_local, int src_local, hipStream_t s,
-                      ScanArea *shared_scan, const DedupInsert *insert) {
+                      ScanArea *shared_scan) {
   (void)num_node;
   uint32_t *offset = workspace;
-  const GraphView g{indptr, indices, nullptr, nullptr, 0, 0};
+  GraphView g{};
+  g.indptr = indptr;
+  g.indices = indices;
   const ScanArea sa = shared_scan ? *shared_scan : ScanArea{offset + n_max, false};
   int rc = tile_scan(SeedCount{g, input, fanout}, StoreOffset{offset}, n_max, n, sa, nullptr, nullptr,
                      num_out_dev, s);
   if (rc != GGMS_OK) return rc;
   hipLaunchKernelGGL(k_sample_khop2, dim3(grid_for(4 * ((n_max + 1023) / 1024), 1)), dim3(kWave), 0, s, indptr, indices,
-                     input, n, fanout, offset, out_src, out_dst, states, SrcMode{seed_local, src_local},
-                     insert ? *insert : DedupInsert{});
+                     input, n, fanout, offset, out_src, out_dst, states, SrcMode{seed_local, src_local});
   GGMS_LAUNCH_CHECK();
   return GGMS_OK;
 }
@@ -894,7 +865,9 @@ int ggms_sample_khop3(const ggms_graph_t *graph, const ggms_id_t *input, size_t 
   GGMS_CHECK_ARG(workspace_bytes >= ggms_sample_workspace_bytes(GGMS_KHOP3, num_input, fanout));
   GGMS_CHECK_ARG((uint64_t)num_input * fanout < (1ull << 32));
   GGMS_CHECK_ARG((num_input + 127) / 128 * 8 <= num_states); // assert(i < num_random_states), khop3.cu:89
-  return sample_khop3_impl(view_of(graph), input, num_input, count_of(num_input), (uint32_t)fanout, out_src, out_dst,
+  GraphView gv;
+  if (!view_of(graph, gv)) return GGMS_ERR_INVALID;
+  return sample_khop3_impl(gv, input, num_input, count_of(num_input), (uint32_t)fanout, out_src, out_dst,
                            num_out_dev, (uint32_t *)states, (uint32_t *)workspace, nullptr, 0, s);
 }
 
@@ -911,7 +884,9 @@ int ggms_sample_khop0(const ggms_graph_t *graph, const ggms_id_t *input, size_t 
   GGMS_CHECK_ARG(input && out_src && out_dst && workspace);
   GGMS_CHECK_ARG(workspace_bytes >= ggms_sample_workspace_bytes(GGMS_KHOP0, num_input, fanout));
   GGMS_CHECK_ARG((uint64_t)num_input * fanout < (1ull << 32));
-  return sample_khop0_impl(view_of(graph), input, num_input, count_of(num_input), (uint32_t)fanout, out_src, out_dst,
+  GraphView gv;
+  if (!view_of(graph, gv)) return GGMS_ERR_INVALID;
+  return sample_khop0_impl(gv, input, num_input, count_of(num_input), (uint32_t)fanout, out_src, out_dst,
                            num_out_dev, (uint32_t *)workspace, nullptr, 0, s);
 }
 

@@ -319,7 +319,7 @@ int sample_random_walk_impl(GraphView g, const uint32_t *input, size_t n_max, Co
   else if (!shared_scan->cleared)
     GGMS_HIP(hipMemsetAsync(ctl, 0, (8 + 2 * (tiles + 1)) * sizeof(uint32_t), s));
   const FusedScan fs{tick, reinterpret_cast<unsigned long long *>(ctl + 8), next_scan_epoch(), num_out_dev,
-                     device_status_word(), scan_patience()};
+                     shared_scan ? shared_scan->status_word() : device_status_word(), scan_patience()};
   const SrcMode sm{seed_local, src_local};
   const bool spill = per > kLdsVisits;
   const size_t lds = spill ? 0 : 2 * (size_t)(per + Kc) * T * sizeof(uint32_t);
@@ -377,7 +377,9 @@ int ggms_sample_random_walk(const ggms_graph_t *graph, const ggms_id_t *input, s
   GGMS_CHECK_ARG(input && out_src && out_dst && out_data && states && workspace);
   GGMS_CHECK_ARG(workspace_bytes >= ggms_sample_random_walk_workspace_bytes(num_input, walk_length, num_walk, K));
   GGMS_CHECK_ARG(ggms_random_walk_num_states(num_input, num_walk) <= num_states); // assert(thread_id < num_random_states)
-  return sample_random_walk_impl(view_of(graph), input, num_input, count_of(num_input), (uint32_t)walk_length,
+  GraphView gv;
+  if (!view_of(graph, gv)) return GGMS_ERR_INVALID;
+  return sample_random_walk_impl(gv, input, num_input, count_of(num_input), (uint32_t)walk_length,
                                  restart_prob, (uint32_t)num_walk, (uint32_t)K, out_src, out_dst, out_data, num_out_dev,
                                  (uint32_t *)states, (uint32_t *)workspace, nullptr, 0, s, nullptr, nullptr);
 }

@@ -420,29 +420,11 @@ int sample_weighted_hash_dedup_impl(const uint32_t *indptr, const uint32_t *indi
   // once) against 32 steps and 71 VGPRs -- step 0.62 -> 0.52 ms on products with two or three round trips per seed
   // (profiles/r03_ab_hash_dedup_tries_per_round.txt; R = 2: 0.55, R = 3: 0.59).  Four lanes per stream with 16 tries
   // each (a quarter of the generator instructions per stream) were built and measured slower too (a wave then waits
-  // for the slowest of 16 streams instead of 4), as were 8 and 32 lanes per stream.
-  // GGMS_HASH_DEDUP_G = 4 / 8 / 32 and GGMS_HASH_DEDUP_R = 1..4 select those variants (measurement hooks; same results).
-  static const int pin_g = [] { const char *e = getenv("GGMS_HASH_DEDUP_G"); return e ? atoi(e) : 0; }();
-  const bool narrow = pin_g == 4;
-#define GGMS_HD(GG, RR)                                                                                              \
-  hipLaunchKernelGGL((k_weighted_hash_dedup<GG, RR>), dim3((unsigned)std::min<size_t>((256 / (64 / GG)) * blocks, 8192)), \
-                     dim3(kWave), 0, s, indptr, indices, prob, alias, input, n, fanout, offset, out_src, out_dst, states, \
-                     sm, di)
-  if (pin_g == 32) {
-    GGMS_HD(32, 1);
-  } else if (narrow) {
-    if (fanout <= 8) GGMS_HD(4, 4);
-    else if (fanout <= 20) GGMS_HD(4, 8);
-    else GGMS_HD(4, 16);
-  } else {
-    static const int pin_r = [] { const char *e = getenv("GGMS_HASH_DEDUP_R"); return e ? atoi(e) : 0; }();
-    const int r = pin_r >= 1 && pin_r <= 4 ? pin_r : 1;
-    if (r == 1) GGMS_HD(16, 1);
-    else if (r == 2) GGMS_HD(16, 2);
-    else if (r == 3) GGMS_HD(16, 3);
-    else GGMS_HD(16, 4);
-  }
-#undef GGMS_HD
+  // for the slowest of 16 streams instead of 4), as were 8 and 32 lanes per stream
+  // (profiles/r03_ab_hash_dedup_lanes_per_stream.txt).  Only <16, 1> is built.
+  hipLaunchKernelGGL((k_weighted_hash_dedup<16, 1>), dim3((unsigned)std::min<size_t>((256 / (64 / 16)) * blocks, 8192)),
+                     dim3(kWave), 0, s, indptr, indices, prob, alias, input, n, fanout, offset, out_src, out_dst, states,
+                     sm, di);
   GGMS_LAUNCH_CHECK();
   return GGMS_OK;
 }

@@ -10,15 +10,14 @@
 // Single pass, decoupled look-back:
 //   * tiles of 1024 items (4 rounds of 256 threads, item = tile*1024 + round*256 + thread -- the
 //     reference's kCudaTileSize/kCudaBlockSize mapping, so output order = input order);
-//   * a block takes the next tile from an atomic ticket, so a tile's predecessors are always owned by
-//     blocks that are already running (forward progress without co-residency assumptions);
+//   * tile = workgroup id; nothing is assumed about when a predecessor's workgroup runs -- a look-back that has
+//     waited long enough computes the missing aggregate itself (scan_lookback's Help);
 //   * per tile one 64-bit descriptor {epoch : 30 | flag : 2 | value : 32}: flag A = tile aggregate,
 //     P = inclusive prefix.  Data and tag travel in ONE 8-byte relaxed agent-scope atomic store / load
 //     (no separate flag, hence no release/acquire pair to get wrong across XCDs); a word whose epoch is
 //     not the launch's epoch is "not yet written", so descriptors are never cleared between launches;
 //   * the element count may live in device memory (ggms::Count): no host round trip.
-// Control words {ticket, done} must be zero when a launch starts; the last block to leave re-zeroes
-// them.  Callers clear the control + descriptor region once (hipMemsetAsync) per API call / per batch.
+// Callers clear the control + descriptor region once (hipMemsetAsync) per API call / per batch.
 #pragma once
 
 #include <atomic>
@@ -52,6 +51,9 @@ struct ScanArea {
                              // with the area (`cleared`), never shared with the 64-bit descriptors of the other scans
   uint32_t *tickets = nullptr; // optional kTicketSets ticket sets (below), zeroed with the area; a ticketed sampler
   uint32_t next_ticket_set = 0; // launch of the batch takes the next one (take_ticket_set)
+  uint32_t *status = nullptr;   // where the scans of this area report a bound they hit: the batch's own status word;
+                                // NULL = the device's sticky word (leaf operators)
+  uint32_t *status_word() const { return status ? status : device_status_word(); }
 };
 
 // ---- tickets without a hot word ----------------------------------------------------------------------------------
@@ -207,14 +209,14 @@ struct TileSumHelp {
 };
 
 template <typename ValueF, typename EmitF>
-__global__ __launch_bounds__(kBlock) void k_tile_scan(ValueF value, EmitF emit, Count n_arg, uint32_t *ctl,
+__global__ __launch_bounds__(kBlock) void k_tile_scan(ValueF value, EmitF emit, Count n_arg,
                                                       unsigned long long *desc, uint32_t epoch,
                                                       const uint32_t *base_in, uint32_t *total32_out,
                                                       uint64_t *total64_out, uint64_t *mirror_a, uint64_t *mirror_b,
                                                       uint32_t *err, uint32_t patience, uint32_t delay0) {
   constexpr uint32_t ROUNDS = kTile / kBlock, FLAG_A = 1, FLAG_P = 2;
   __shared__ uint32_t smem[kBlock / kWave];
-  __shared__ uint32_t s_tile, s_prefix;
+  __shared__ uint32_t s_prefix;
   const uint64_t n = n_arg.get();
   const uint64_t num_tiles = (n + kTile - 1) / kTile;
   // total32_out may alias base_in (a running count updated in place): the last tile overwrites it, but only after
@@ -223,17 +225,12 @@ __global__ __launch_bounds__(kBlock) void k_tile_scan(ValueF value, EmitF emit, 
   if (delay0 && blockIdx.x == 0) // test aid: tile 0's owner starts after the others computed its word and the total is out
     for (uint32_t i = 0; i < delay0; ++i) __builtin_amdgcn_s_sleep(127);
   const uint32_t base_seen = base_in ? *base_in : 0u;
-  // Up to kSinglePassTiles workgroups (the default use of this kernel) take tile = workgroup id: a ticket and an exit
+  // tile = workgroup id (the launch has one workgroup per tile, at most kSinglePassTiles): a ticket and an exit
   // count from one word are 2 x 256 same-address atomics, 11 ns each (tools/micro_ticket.hip) -- most of an 8-us launch.
   // A predecessor that has not started (nothing is promised about dispatch order) is computed by whoever waits for it
-  // (scan_lookback, TileSumHelp).  Larger grids (GGMS_SCAN=1) keep the ticket.
-  const bool ticketed = gridDim.x > kSinglePassTiles;
+  // (scan_lookback, TileSumHelp).
   for (uint64_t round = 0;; ++round) {
-    if (ticketed) {
-      if (threadIdx.x == 0) s_tile = atomicAdd(&ctl[0], 1u);
-      __syncthreads();
-    }
-    const uint64_t tile = ticketed ? (uint64_t)s_tile : (uint64_t)blockIdx.x + round * gridDim.x;
+    const uint64_t tile = (uint64_t)blockIdx.x + round * gridDim.x;
     if (tile >= num_tiles) break;
     uint32_t v[ROUNDS], excl[ROUNDS];
     uint32_t running = 0;
@@ -283,20 +280,13 @@ __global__ __launch_bounds__(kBlock) void k_tile_scan(ValueF value, EmitF emit, 
       const uint64_t i = tile * kTile + r * kBlock + threadIdx.x;
       if (i < n) emit(i, v[r], prefix + excl[r]);
     }
-    __syncthreads(); // s_tile / s_prefix are rewritten next iteration
+    __syncthreads(); // s_prefix is rewritten next iteration
   }
-  if (threadIdx.x == 0) {
-    if (num_tiles == 0 && blockIdx.x == 0) { // empty input: totals = base
-      if (total32_out) *total32_out = base_seen;
-      if (total64_out) *total64_out = 0;
-      if (mirror_a) *mirror_a = (uint64_t)base_seen;
-      if (mirror_b) *mirror_b = (uint64_t)base_seen;
-    }
-    // the last block out re-arms the control words for the next launch on this scratch
-    if (ticketed && atomicAdd(&ctl[1], 1u) == gridDim.x - 1) {
-      ctl[0] = 0;
-      ctl[1] = 0;
-    }
+  if (threadIdx.x == 0 && num_tiles == 0 && blockIdx.x == 0) { // empty input: totals = base
+    if (total32_out) *total32_out = base_seen;
+    if (total64_out) *total64_out = 0;
+    if (mirror_a) *mirror_a = (uint64_t)base_seen;
+    if (mirror_b) *mirror_b = (uint64_t)base_seen;
   }
 }
 
@@ -427,25 +417,14 @@ __global__ __launch_bounds__(kBlock) void k_tile_prefix_t(const uint32_t *tile_s
 // with the single-pass kernel everywhere -- at ~900 tiles its 1-tile-per-block latency chain costs what the two
 // extra launches cost -- and the three-launch form has no inter-workgroup wait at all.  Small inputs are the
 // opposite case: every launch sits on the ~5 us floor, so one launch beats three.
-// GGMS_SCAN=1 forces the single-pass kernel everywhere, GGMS_SCAN=3 the three launches everywhere.
-inline int scan_mode() {
-  static const int v = [] { const char *e = getenv("GGMS_SCAN"); return e ? atoi(e) : 0; }();
-  return v;
-}
-inline bool scan_three_pass() { return scan_mode() != 1; }
-inline bool scan_single_pass(size_t n_max) {
-  if (scan_mode() == 1) return true;
-  if (scan_mode() == 3) return false;
-  return num_tiles_for(n_max) <= kSinglePassTiles;
-}
+inline bool scan_single_pass(size_t n_max) { return num_tiles_for(n_max) <= kSinglePassTiles; }
 
 // Host helper.  scratch: tile_scan_words(n_max) uint32, 8-byte aligned; its control words must be zero
 // (clear_scratch = true issues the memset here; batch callers clear once and pass false).
 inline uint32_t *scan_align(uint32_t *p) { return (uint32_t *)(((uintptr_t)p + 7) & ~(uintptr_t)7); }
 
 inline int clear_scan_area(uint32_t *words, size_t n_max, hipStream_t stream) {
-  const size_t w = scan_mode() == 1 ? 8 + 2 * (num_tiles_for(n_max) + 1) : scan_clear_words(n_max);
-  GGMS_HIP(hipMemsetAsync(scan_align(words), 0, w * sizeof(uint32_t), stream));
+  GGMS_HIP(hipMemsetAsync(scan_align(words), 0, scan_clear_words(n_max) * sizeof(uint32_t), stream));
   return GGMS_OK;
 }
 
@@ -479,8 +458,8 @@ inline int tile_scan(ValueF value, EmitF emit, size_t n_max, Count n, ScanArea a
     GGMS_LAUNCH_CHECK();
     return GGMS_OK;
   }
-  hipLaunchKernelGGL((k_tile_scan<ValueF, EmitF>), dim3(grid), dim3(kBlock), 0, stream, value, emit, n, ctl, desc,
-                     next_scan_epoch(), base_in, total32_out, total64_out, mirror_a, mirror_b, device_status_word(),
+  hipLaunchKernelGGL((k_tile_scan<ValueF, EmitF>), dim3(grid), dim3(kBlock), 0, stream, value, emit, n, desc,
+                     next_scan_epoch(), base_in, total32_out, total64_out, mirror_a, mirror_b, area.status_word(),
                      scan_patience(), scan_delay_word().exchange(0u));
   GGMS_LAUNCH_CHECK();
   return GGMS_OK;

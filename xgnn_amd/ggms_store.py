@@ -104,6 +104,9 @@ class HipLeaf:
         if n:
             self.ops.gather_scatter(out, src, src_index, dst_index, num=n)
 
+    def pointer_table(self, ptrs):
+        return self.ops.PartTable(ptrs)
+
     def gather_peer(self, out, nodes, num, table, parts_table, num_part, host_feat, num_dev=None, num_miss=None):
         self.ops.extract_cached(out, nodes, table, parts_table, num_part, host_feat, num=num, num_dev=num_dev,
                                 num_miss=num_miss)
@@ -149,7 +152,8 @@ class FeatureShards:
 
     # ---- mode "peer": publish / map the shards ------------------------------------------------------
     def connect_peers(self, shared_shard):
-        """Exchange hipIpc handles (all_gather of 64-byte blobs) and build the device pointer table."""
+        """Exchange hipIpc handles (all_gather of 64-byte blobs) and build the pointer table (a host array: the gather
+        takes the shard pointers by value)."""
         assert self.mode == "peer"
         self._shared = shared_shard
         # the shard must be COMPLETE before a peer may read it: drain this device's queue before publishing (the
@@ -192,8 +196,10 @@ class FeatureShards:
                           f"{me} waiting for the peers after mapping their shards: a rank is stuck opening one")
             failed = "; ".join(v for v in verdicts if v) or None
         if failed:
+            # nothing will own the mappings that did open: close them here (every rank gets here, see above)
+            shared_shard.release_peers()
             raise PeerConnectError(failed)
-        self.parts_table = torch.tensor(ptrs, dtype=torch.int64, device=self.shard.device)
+        self.parts_table = self.leaf.pointer_table(ptrs)
         return self
 
     # ---- one batch ----------------------------------------------------------------------------------

@@ -57,13 +57,13 @@ class DeviceGraph:
         self.c.num_part = 0
         self.c.num_cache_node = 0
         if part_indptr is not None:
-            # part_* : lists of P+1 tensors (slot P = whole CSR); pointer tables live on the device
-            dev = part_indptr[0].device
-            self._pip = torch.tensor([t.data_ptr() for t in part_indptr], dtype=torch.int64, device=dev)
-            self._pix = torch.tensor([t.data_ptr() for t in part_indices], dtype=torch.int64, device=dev)
+            # part_* : lists of P+1 tensors (slot P = whole CSR, device memory or pinned / registered host memory);
+            # the pointer tables are HOST arrays -- the kernels take the pointers by value (include/ggms.h)
+            self._pip = PartTable([t.data_ptr() for t in part_indptr])
+            self._pix = PartTable([t.data_ptr() for t in part_indices])
             self._keep += list(part_indptr) + list(part_indices)
-            self.c.part_indptr = self._pip.data_ptr()
-            self.c.part_indices = self._pix.data_ptr()
+            self.c.part_indptr = self._pip.ptr().value
+            self.c.part_indices = self._pix.ptr().value
             self.c.num_part = len(part_indptr) - 1
             self.c.num_cache_node = num_cache_node
             self.c.num_node = part_indptr[-1].numel() - 1
@@ -226,7 +226,7 @@ class OrderedHashTable:
         self.o2n = torch.empty((nb, 2 if direct else 4), dtype=torch.int32, device=device)
         _require_gpu(self.o2n)
         self.n2o = torch.empty(max(1, capacity), dtype=torch.int32, device=device)
-        self.num_items_dev = torch.zeros(1, dtype=torch.int32, device=device)
+        self.num_items_dev = torch.zeros(2, dtype=torch.int32, device=device)  # [item count, batch status word]
         self.c = _CHashTable()
         self.c.o2n = self.o2n.data_ptr()
         self.c.n2o = self.n2o.data_ptr()
@@ -249,7 +249,7 @@ class OrderedHashTable:
 
     @property
     def num_items(self):
-        return int(self.num_items_dev.item())
+        return int(self.num_items_dev[0].item())
 
     def unique(self):
         return self.n2o[: self.num_items]
@@ -318,9 +318,22 @@ def gather_scatter(out, src, src_index, dst_index, num=None, num_dev=None):
     return out
 
 
-def part_pointer_table(parts, device):
-    """Device array of shard base pointers (DeviceDistFeature, dist_graph.h:182-212)."""
-    return torch.tensor([p.data_ptr() for p in parts], dtype=torch.int64, device=device)
+class PartTable:
+    """HOST array of shard base pointers (DeviceDistFeature / DeviceDistGraph, dist_graph.h:114-212): the operators
+    hand the pointers to their kernels by value, at most GGMS_MAX_PARTS = 8 shards."""
+
+    def __init__(self, ptrs, keep=None):
+        self.n = len(ptrs)
+        self.arr = (C.c_void_p * max(1, self.n))(*[int(p) for p in ptrs])
+        self._keep = keep
+
+    def ptr(self):
+        return C.cast(self.arr, C.c_void_p)
+
+
+def part_pointer_table(parts, device=None):
+    """Pointer table of a list of shard tensors (kept alive by the table)."""
+    return PartTable([p.data_ptr() for p in parts], keep=list(parts))
 
 
 def gather_scatter_partition(out, parts_table, num_part, src_index, dst_index, num=None, num_dev=None):
@@ -328,7 +341,7 @@ def gather_scatter_partition(out, parts_table, num_part, src_index, dst_index, n
     _require_gpu(out)
     if num is None:
         num = src_index.numel()
-    check(lib().ggms_gather_scatter_partition(_ptr(out), _ptr(parts_table), num_part, _ptr(src_index),
+    check(lib().ggms_gather_scatter_partition(_ptr(out), parts_table.ptr(), num_part, _ptr(src_index),
                                               _ptr(dst_index), num, _ptr(num_dev), _dim_of(out),
                                               DTYPE_CODE[out.dtype], _stream()), "ggms_gather_scatter_partition")
     return out
@@ -340,7 +353,7 @@ def extract_cached(out, nodes, table, parts_table, num_part, host_feat, num=None
     _require_gpu(out)
     if num is None:
         num = nodes.numel()
-    check(lib().ggms_extract_cached(_ptr(out), _ptr(nodes), num, _ptr(num_dev), _ptr(table), _ptr(parts_table),
+    check(lib().ggms_extract_cached(_ptr(out), _ptr(nodes), num, _ptr(num_dev), _ptr(table), parts_table.ptr(),
                                     num_part, _ptr(host_feat), _dim_of(out), DTYPE_CODE[out.dtype], _ptr(num_miss),
                                     _stream()), "ggms_extract_cached")
     return out
@@ -358,7 +371,7 @@ def extract_tiered(out, nodes, table, replica, parts_table, num_part, my_part, h
     t.table = table.data_ptr() if table is not None else None
     t.replica = replica.data_ptr() if replica is not None else None
     t.num_replica = replica.shape[0] if replica is not None else 0
-    t.parts_dev = parts_table.data_ptr()
+    t.parts = parts_table.ptr().value
     t.num_part, t.my_part = num_part, my_part
     t.host_feat = host_feat.data_ptr() if host_feat is not None else None
     check(lib().ggms_extract_tiered(_ptr(out), _ptr(nodes), num, _ptr(num_dev), C.byref(t), _dim_of(out),
@@ -419,10 +432,14 @@ class SharedShard:
         self._imported.append(p.value)
         return p.value
 
-    def close(self):
+    def release_peers(self):
+        """Unmap every peer shard opened through this holder (hipIpcCloseMemHandle)."""
         for p in self._imported:
             lib().ggms_ipc_release(C.c_void_p(p))
         self._imported = []
+
+    def close(self):
+        self.release_peers()
         if self.ptr:
             self.tensor = None
             lib().ggms_device_free(C.c_void_p(self.ptr))
