@@ -32,6 +32,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+T0 = time.perf_counter()  # the wall-clock budget of the optional sub-records counts from here (--budget-s)
 
 
 def parse():
@@ -53,7 +54,20 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-tier", action="store_true", help="skip the cache_ratio 0 sub-record (configs[2])")
     ap.add_argument("--no-engine", action="store_true", help="skip the `engine` sub-record (samgraph.torch surface, child process)")
-    ap.add_argument("--engine-timeout", type=float, default=300.0)
+    ap.add_argument("--engine-timeout", type=float, default=300.0,
+                    help="upper bound of the engine child's run time; the wall-clock budget may leave it less")
+    ap.add_argument("--budget-s", type=float, default=400.0,
+                    help="wall-clock budget of the whole run, counted from process start.  The headline line is printed as "
+                         "soon as the main region is measured; every optional sub-record (sampler roofline, other stores, "
+                         "engine, host tier, CPU baseline) runs only if its estimated time still fits, else it is recorded "
+                         "as {\"skipped\": \"budget\"}; the engine child's timeout is what the budget leaves")
+    ap.add_argument("--dist-graph", type=float, default=None, metavar="FRACTION",
+                    help="XGNN mode's topology (use_dist_graph, /root/reference README.md:184): the leading nodes holding this "
+                         "fraction of the edges in topology shards (node v in shard v %% P at row v / P), the rest read from "
+                         "the whole CSR in registered host memory.  N = 1: the timed sampler runs through --topology-shards "
+                         "LOGICAL shards in this process; N > 1: feeds the `engine` record (arch6 + use_dist_graph, one "
+                         "shard per worker GPU, peers over hipIpc / xGMI), the main region keeps the whole CSR per GPU")
+    ap.add_argument("--topology-shards", type=int, default=2, help="N = 1 with --dist-graph: logical shards (<= 8)")
     ap.add_argument("--no-sampler-roofline", action="store_true",
                     help="skip the sampler-alone timing and the memory-side rate probe (roofline_sampler)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline: keep sampling mini-batches this long")
@@ -67,6 +81,9 @@ def parse():
     ap.add_argument("--heavy-after-gather", action="store_true",
                     help="the last (largest) layer's sampler launch of batch k+1 waits for the gather of batch k: the two "
                          "fabric-heaviest kernels run one after the other, the smaller layers still overlap the gather")
+    ap.add_argument("--no-distinct-seeds", action="store_true",
+                    help="do not tell the sampler that a batch's seeds are distinct (they are: slices of a shuffled train set): "
+                         "the seeds then take the general insert / ordered scan / look-up launches (A/B hook)")
     ap.add_argument("--no-overlap", action="store_true",
                     help="one stream: extract of batch k and sampling of batch k+1 run back to back "
                          "(default: two streams, the HBM-bound gather overlaps the latency-bound sampler)")
@@ -252,7 +269,8 @@ def scratch_dir(need_bytes, prefix):
     return tempfile.mkdtemp(prefix=prefix)
 
 
-def engine_record(datagen, graph, fanouts, args, log, workers=0, force_device=None, replicate=0.0):
+def engine_record(datagen, graph, fanouts, args, log, workers=0, force_device=None, replicate=0.0, timeout=None,
+                  dist_graph=0.0):
     """The same workload through the operator surface north_star names (samgraph.torch: config / init / sample_once /
     get_next_batch) in a CHILD process: the graph is written in the reference's on-disk format without feat.bin /
     label.bin (the loader then maps zero-filled tables, engine.cc:199-235 -- topology and sizes are the real ones), one
@@ -273,11 +291,14 @@ def engine_record(datagen, graph, fanouts, args, log, workers=0, force_device=No
             env.pop(k, None)
         if force_device is not None:  # one-GPU rehearsal: every engine worker on that device
             env["SAMGRAPH_FORCE_DEVICE"] = str(force_device)
-        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "engine_epoch.py"), d, "--fanout"]
-                           + [str(f) for f in fanouts]
-                           + ["--batch-size", str(args.batch), "--sample-type", args.sample_type, "--cache-percentage", "1.0"]
-                           + (["--arch6", str(workers), "--replicate-percentage", f"{replicate:.6f}"] if workers else []),
-                           capture_output=True, text=True, timeout=args.engine_timeout, env=env)
+        timeout = args.engine_timeout if timeout is None else timeout
+        cmd = ([sys.executable, os.path.join(ROOT, "tools", "engine_epoch.py"), d, "--fanout"] + [str(f) for f in fanouts]
+               + ["--batch-size", str(args.batch), "--sample-type", args.sample_type, "--cache-percentage", "1.0"]
+               + (["--arch6", str(workers), "--replicate-percentage", f"{replicate:.6f}"] if workers else [])
+               + (["--use-dist-graph", f"{dist_graph:.6f}"] if workers and dist_graph else []))
+        if os.environ.get("GGMS_BENCH_TEST_ENGINE_SLEEP"):  # test hook: a child that outlives whatever it is given
+            cmd = [sys.executable, "-c", f"import time; time.sleep({float(os.environ['GGMS_BENCH_TEST_ENGINE_SLEEP'])})"]
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env)
         lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
         if r.returncode != 0 or not lines:
             return {"error": f"engine child rc {r.returncode}: {r.stderr[-300:]}"}
@@ -291,11 +312,15 @@ def engine_record(datagen, graph, fanouts, args, log, workers=0, force_device=No
                         "hipIpc peers"
                         + (f"; the {replicate:.2f} hottest of the rows on every GPU (replicate_percentage), the rest sharded"
                            if replicate else "")
-                        + "), whole CSR on every GPU; second epoch, the slowest worker's wall time; rates summed "
+                        + "), "
+                        + (f"topology sharded over the workers' GPUs (use_dist_graph {dist_graph:g}: the leading nodes holding "
+                           "that fraction of the edges, peers over hipIpc; the rest from the whole CSR in registered host "
+                           "memory)" if dist_graph else "whole CSR on every GPU")
+                        + "; second epoch, the slowest worker's wall time; rates summed "
                         "over the workers from the reference's log items")
         return e
     except subprocess.TimeoutExpired:
-        return {"error": f"engine child exceeded {args.engine_timeout} s"}
+        return {"error": f"engine child exceeded the {timeout:.0f} s the wall-clock budget left it (--budget-s, --engine-timeout)"}
     finally:
         shutil.rmtree(d, ignore_errors=True)
 
@@ -389,6 +414,28 @@ def main():
 
     indptr, indices = to_dev(graph["indptr"]), to_dev(graph["indices"])
     g = ops.DeviceGraph(indptr, indices)
+    topo_text, topo_record, topo_keep = "graph in HBM", None, None
+    if args.dist_graph is not None and world == 1:
+        # XGNN mode's graph view (DeviceDistGraph, cuda/dist_graph.h:114-158) in ONE process: P logical shards in HBM +
+        # the whole CSR in registered host memory for the nodes beyond num_cache_node
+        P = max(1, min(8, args.topology_shards))
+        ncn = ggms_store.num_cache_node_for(graph["indptr"], args.dist_graph)
+        pip, pix = ggms_store.topology_shards(indptr, indices, P, ncn)
+        if ncn < N:
+            del g, indptr, indices  # the device copy of the whole CSR goes: the host slot serves the uncached nodes
+            torch.cuda.empty_cache()
+            topo_keep = (ops.RegisteredHost(graph["indptr"], dev), ops.RegisteredHost(graph["indices"], dev))
+            slot = (topo_keep[0].tensor, topo_keep[1].tensor)
+        else:
+            slot = (indptr, indices)  # never read: every node is cached
+        g = ops.DeviceGraph(None, None, part_indptr=pip + [slot[0]], part_indices=pix + [slot[1]], num_cache_node=ncn)
+        topo_record = {"use_dist_graph": args.dist_graph, "logical_shards": P, "num_cache_node": ncn,
+                       "cached_node_fraction": ncn / N,
+                       "host_slot": "whole CSR in hipHostRegister'ed host memory, read zero-copy over PCIe" if ncn < N else None}
+        topo_text = (f"graph in {P} logical topology shards in HBM (use_dist_graph {args.dist_graph:g}: the {ncn} leading nodes"
+                     + (", every other node read from the whole CSR in registered host memory)" if ncn < N else ")"))
+    elif args.dist_graph is not None:
+        topo_text = "graph in HBM (whole CSR per GPU in the main region; --dist-graph feeds the engine record)"
     labels = (torch.arange(N, dtype=torch.int64, device=dev) % meta["num_class"]).contiguous()
 
     def feat_rows(node_ids, out):
@@ -518,6 +565,12 @@ def main():
         lo = ls * args.batch
         return epoch_cache[ep][lo:min(per_rank, lo + args.batch)]
 
+    def seeds_distinct(seeds):
+        """What the caller of ggms_sample_batch knows about its seeds (ggms_sample_extra_t.seeds_distinct): a slice of a
+        shuffled train set is distinct unless both copies of a padding node of the aligned epoch fall into it -- checked
+        here, outside every timed region, as the engine checks its own batches."""
+        return (not args.no_distinct_seeds) and int(torch.unique(seeds).numel()) == int(seeds.numel())
+
     def barrier():
         if world > 1:
             dist.barrier()
@@ -529,7 +582,7 @@ def main():
     def make_step(extract_fn, counters, acc, seeds_of):
         """One step of the hot path: sample on the batch's pipeline stream, gather + labels on the extract stream."""
         def run_step(step, ev4=None):
-            seeds = seeds_of(step)
+            seeds, distinct = seeds_of(step)
             slot = step % NSLOT
             s_sample = s_samples[step % K]
             h0 = time.perf_counter()
@@ -539,7 +592,7 @@ def main():
                 if ev4 is not None:
                     ev4[0].record(s_sample)
                 h1 = time.perf_counter()
-                sampler.sample(seeds, slot=slot, copy_input_nodes=True,
+                sampler.sample(seeds, slot=slot, copy_input_nodes=True, distinct=distinct,
                                heavy_wait=last_gather[0] if args.heavy_after_gather else None)
                 h2 = time.perf_counter()
                 sampled = torch.cuda.Event()
@@ -575,6 +628,7 @@ def main():
         Returns per-block dicts (elapsed = max over ranks) and the step index after the last one."""
         total = warmup + steps * repeats
         seeds_all = [batch_seeds(first_step + s) for s in range(total)]  # the per-epoch reshuffle + H2D stay outside
+        seeds_all = [(s, seeds_distinct(s)) for s in seeds_all]
         # rows by tier: [host misses, remote-shard rows, local-shard rows, replica rows]
         counters = torch.zeros(4, dtype=torch.int64, device=dev)
         acc = torch.zeros(3 * L + 2, dtype=torch.int64, device=dev)
@@ -583,6 +637,8 @@ def main():
         for s in range(warmup):
             run_step(s)
         barrier()
+        if warmup and int(acc[3 * L + 1].item()):  # the warm-up batches' status words (acc is zeroed before each timed block)
+            raise SystemExit(f"device status {int(acc[3 * L + 1].item())} during warm-up")
         log("warm-up done")
         blocks = []
         for r in range(repeats):
@@ -629,10 +685,15 @@ def main():
         # turn): the line is then measured on whole-table replicas -- the reference's deployment without part_cache --
         # and SAYS so: config.store_requested / store_error, `feature store: replica` in the workload text
         store_error = str(e)[:600]
+    if store_error is not None:
+        # outside the except block: the exception's traceback holds the failed build's frame -- shard, replica and table,
+        # up to the whole HBM budget -- and only once it is gone can the allocator give that memory back
+        import gc
+        gc.collect()
+        torch.cuda.empty_cache()
         print(f"[bench] store {main_store!r} cannot be built: {store_error}\n[bench] measuring on 'replica' instead",
               file=sys.stderr, flush=True)
         main_store = "replica"
-        torch.cuda.empty_cache()
         extract_main, keep_main = build_store(main_store)
     main_plan = dict(hybrid_plan) if main_store == "hybrid" else {}
     blocks, next_step = measure(extract_main, args.steps, args.warmup, repeats)
@@ -672,50 +733,7 @@ def main():
         serial_us = e0.elapsed_time(e1) / reps * 1e3
         serial_rows = n_last
 
-    # ---- the sampler chain with nothing beside it, and the memory-side ceilings it runs against ----------------
-    # (rank 0's GPU; N > 1: every rank does the same work, only rank 0 reports)
-    sampler_alone_ms = probe = None
-    if not args.no_sampler_roofline:
-        n_alone = max(4, min(args.steps, 20))
-        seeds_alone = [batch_seeds(next_step + k) for k in range(n_alone + 1)]
-        next_step += n_alone + 1
-        s0 = s_samples[0]
-        barrier()
-        a0, a1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        with torch.cuda.stream(s0):
-            sampler.sample(seeds_alone[0], slot=0, copy_input_nodes=True)  # warm
-            a0.record(s0)
-            for k in range(n_alone):
-                sampler.sample(seeds_alone[1 + k], slot=k % NSLOT, copy_input_nodes=True)
-            a1.record(s0)
-        torch.cuda.synchronize()
-        sampler_alone_ms = a0.elapsed_time(a1) / n_alone
-        # ceilings: random requests on a table the size of the dedup table (one 64-bit word per node id), one launch =
-        # one step's worth of edges.  Returning atomicMin / 4-byte load / both per request (ggms_fabric_probe).
-        import ctypes as C
-        from xgnn_amd import lib as _lib
-        words = N
-        ptab = torch.full((words,), -1, dtype=torch.int64, device=dev)
-        sink = torch.zeros(1, dtype=torch.int32, device=dev)
-        reqs = max(1, int(edges / args.steps))
-        probe = {"table_bytes": words * 8, "requests_per_launch": reqs}
-        salt = 0x7fffff00
-        for kind, name in ((0, "atomic"), (1, "load"), (2, "load_atomic_pair")):
-            p0, p1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            for rep in range(5):
-                if rep == 1:
-                    p0.record()
-                rc = _lib().ggms_fabric_probe(kind, C.c_void_p(ptab.data_ptr()), words, reqs, salt, C.c_void_p(sink.data_ptr()),
-                                              C.c_void_p(torch.cuda.current_stream().cuda_stream))
-                assert rc == 0
-                salt -= 1
-            p1.record()
-            torch.cuda.synchronize()
-            probe[name + "s_per_s"] = reqs / (p0.elapsed_time(p1) / 4 / 1e3)
-        del ptab
-
-    # ---- N > 1: the other stores, one block each ------------------------------------------------------------------
-    stores = None
+    stores_main = None
     if world > 1:
         def store_record(b, kind):
             t = b["tiers_all"]
@@ -726,84 +744,23 @@ def main():
                     "xgmi_bytes_per_step": remote_rows * row_bytes / args.steps,
                     "rows_by_tier": {"host": t[0], "remote_shard": t[1], "local_shard": t[2], "replica": t[3]},
                     **(hybrid_plan if kind == "hybrid" else {})}
-        stores = {main_store: store_record(blk, main_store)}
-        for kind in [k for k in args.other_stores.split(",") if k and k != main_store]:
-            extract_main = keep_main = None
-            torch.cuda.empty_cache()
-            try:  # a store that cannot be built here (memory) must not cost the line its main result
-                ex, keep_main = build_store(kind)
-                b2, next_step = measure(ex, args.steps, 2, 1, first_step=next_step)
-                stores[kind] = store_record(b2[0], kind)
-            except (RuntimeError, MemoryError) as e:  # PeerConnectError is one: raised on every rank alike
-                stores[kind] = {"error": f"{type(e).__name__}: {str(e)[:200]}"}
+        stores_main = {main_store: store_record(blk, main_store)}
 
-    # ---- the same workload through the samgraph.torch surface (child process): arch1 at N = 1, arch6 with N workers ----
-    engine = None
-    if full and not args.no_engine and args.sample_type.startswith("khop"):
-        if world == 1:
-            engine = engine_record(datagen, graph, fanouts, args, log)
-        else:  # rank 0 runs the child (which forks one engine worker per GPU), the other ranks wait
-            extract_main = keep_main = None  # the engine's workers build their own shards on these GPUs
-            torch.cuda.empty_cache()
-            barrier()
-            if rank == 0:
-                # the same placement as the main region's: the planned hot prefix on every GPU (0 = pure shards)
-                engine = engine_record(datagen, graph, fanouts, args, log, workers=world,
-                                       force_device=os.environ.get("GGMS_BENCH_DEVICE"),
-                                       replicate=(main_plan.get("replicated_fraction", 0.0)
-                                                  if main_store == "hybrid" else 0.0))
-            # the other ranks wait on the HOST (the rendezvous store), not inside an RCCL collective: a collective's
-            # kernel would spin on their GPUs for the minute the engine's workers are measuring on them
-            try:
-                import datetime
-                store = dist.distributed_c10d._get_default_store()
-                if rank == 0:
-                    store.set("ggms_bench_engine_done", "1")
-                else:
-                    store.wait(["ggms_bench_engine_done"], datetime.timedelta(seconds=args.engine_timeout + 240))
-            except Exception as e:  # noqa: BLE001 -- no such store: the collective below is the meeting point
-                log(f"host-side wait unavailable ({type(e).__name__}: {e}); waiting in the barrier")
-            barrier()
-        log("engine sub-record done")
-
-    # ---- N = 1: BASELINE configs[2], every row in pinned host DRAM (cache_ratio 0) -----------------------------
-    host_tier = None
-    cpu_feat = None
-    if world == 1 and full and not args.no_host_tier:
-        cache = keep_main["cache"]
-        t0 = time.perf_counter()
-        hf = torch.empty((N, dim), dtype=torch.float32, pin_memory=True)  # hipHostMalloc, device-mapped
-        t_pin = time.perf_counter() - t0
-        hf.copy_(cache)  # the same rows the HBM tier holds (node order)
-        torch.cuda.synchronize()
-        # the box's pinned-copy rate, the ceiling of this tier: H2D of a 4-GiB slice of the table, 3 times
-        probe_rows = min(N, (4 << 30) // row_bytes)
-        dst = torch.empty((probe_rows, dim), dtype=torch.float32, device=dev)
-        c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        dst.copy_(hf[:probe_rows], non_blocking=True)
-        c0.record()
-        for _ in range(3):
-            dst.copy_(hf[:probe_rows], non_blocking=True)
-        c1.record()
-        torch.cuda.synchronize()
-        pinned_GBps = 3 * probe_rows * row_bytes / (c0.elapsed_time(c1) / 1e3) / 1e9
-        del dst
-
-        def extract_host(nodes, num_max, o, num_dev, counters):  # DoGPUFeatureExtract, dist_loops.cc:585-634
-            ops.gather_scatter(o, hf, nodes, None, num=num_max, num_dev=num_dev)
-        hb, next_step = measure(extract_host, args.host_steps, 1, 1, first_step=next_step)
-        h = hb[0]
-        host_tier = {
-            "config": "BASELINE configs[2]: same workload, cache_ratio 0 -- every feature row in pinned host DRAM "
-                      "(hipHostMalloc, device-mapped), gathered zero-copy by the same kernel",
-            "steps": args.host_steps, "ms_per_step": h["elapsed"] / args.host_steps * 1e3,
-            "edges_per_s": h["edges_all"] / h["elapsed"],
-            "feature_extract_GBps": h["feat_rate_all"], "rows_per_step": h["rows"] / args.host_steps,
-            "pinned_h2d_copy_GBps": pinned_GBps, "frac_of_pinned_copy": h["feat_rate_all"] / pinned_GBps,
-            "pinned_GiB": N * row_bytes / 2 ** 30, "pin_seconds": t_pin,
-        }
-        cpu_feat = hf.numpy()
-
+    # ---- the headline: complete as soon as the main region, the row check and the gather-alone timing exist ---------
+    # It is printed (and flushed) NOW, and again at the end with the sub-records: the last line wins, and a
+    # sub-record that is slow, stuck or fatal can no longer cost the run its result (at N = 8 the engine child alone
+    # needs a minute of start-up, under a limit somebody else set).
+    gather_kernel = {
+        "local": "k_gather_rows<16-B chunks, IdentRows, ident-dst> (ggms_extract_cached)" if full else
+                 "k_gather_rows<16-B chunks, CachedRows, ident-dst> (ggms_extract_cached)",
+        "replica": "k_gather_rows<16-B chunks, IdentRows, ident-dst> (ggms_extract_cached)" if full else
+                   "k_gather_rows<16-B chunks, CachedRows, ident-dst> (ggms_extract_cached)",
+        "peer": "k_gather_rows<16-B chunks, TieredRows, ident-dst> (ggms_extract_tiered: local shard + peer shards over xGMI)",
+        "hybrid": "k_gather_rows<16-B chunks, TieredRows, ident-dst> (ggms_extract_tiered: replica + local shard + peer "
+                  "shards over xGMI)",
+        "a2a": "k_gather_rows<16-B chunks, PlainRows> at the owner + RCCL all-to-all of ids and rows",
+    }[main_store]
+    res = None
     if rank == 0:
         ext_s = blk["t_extract_ms"] / 1e3
         algo_bytes_per_launch = rows / args.steps * (4 + 2 * row_bytes)
@@ -835,7 +792,7 @@ def main():
                 "workload": f"{args.preset}-shaped power-law CSR N={N} E={meta['num_edge']} f32 dim {dim}, "
                             f"{'neighbours uniform' if not args.neighbour_skew else f'neighbour skew {args.neighbour_skew} (prob. of a degree-proportional pick)'}, "
                             f"fanout {fanouts} {args.sample_type}, batch {args.batch}, "
-                            f"graph in HBM, feature cache_ratio {args.cache_ratio}"
+                            f"{topo_text}, feature cache_ratio {args.cache_ratio}"
                             f"{(' (all rows in HBM, slots in degree-rank order)' if main_store == 'hybrid' else ' (all rows in HBM, node order)') if full else ' (rest in pinned host DRAM)'}, "
                             f"seeds DP over {world} GPU(s), feature store: {main_store}"
                             + (f" ({main_plan.get('replicated_fraction', 0):.2f} of the cached rows on every GPU"
@@ -846,6 +803,8 @@ def main():
                 "streams": "1 (serial)" if args.no_overlap else
                            f"{K} sampling pipeline(s) (batches in flight, RNG pool consumed in batch order) + 1 extract stream",
                 "neighbour_skew": args.neighbour_skew,
+                "seeds_distinct_promise": not args.no_distinct_seeds,
+                **({"topology": topo_record} if topo_record else {}),
                 **({"store_requested": store_requested, "store_error": store_error} if store_error else {}),
                 "not_covered": "the reference's example scripts themselves were not run (they import DGL, absent from "
                                "this image): the line times the operator surface they call; parity is against the "
@@ -861,7 +820,7 @@ def main():
                 "rows_per_step": rows / args.steps,
             },
             "roofline": {
-                "kernel": "k_gather_rows<16-B chunks, ident-dst, nt> (ggms_extract_cached)",
+                "kernel": gather_kernel,
                 "bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                 "frac": achieved / 8000.0, "traffic": traffic,
                 # the READ side alone, rows * (dim * 4 + 4) / t / 8e12 (a gather also writes every byte
@@ -878,21 +837,91 @@ def main():
                 "traffic_source": (tr["source"] + (" (stale: extract.hip changed since; traffic nulled)" if tr["stale"] else
                                                    f" @ extract.hip sha256 {tr['extract_hip_sha256'][:12]}")) if tr else None,
             },
+            "budget": {"budget_s": args.budget_s, "headline_at_s": round(time.perf_counter() - T0, 1)},
         }
-        if sampler_alone_ms is not None:
+        if stores_main is not None:
+            res["stores"] = stores_main
+        print(json.dumps(res), flush=True)  # the headline; the enriched line follows (last line wins)
+
+    # ---- sub-records: one wall-clock budget for all of them; what no longer fits is skipped and says so -------------
+    size_factor = max(0.02, meta["num_edge"] / 1.6e9)  # the default workload = 1
+
+    def left():
+        return args.budget_s - (time.perf_counter() - T0)
+
+    def fits(name, need_s):
+        """Rank 0 decides, every rank follows (the sub-records hold collectives)."""
+        ok = [left() >= need_s]
+        if world > 1:
+            dist.broadcast_object_list(ok, src=0)
+        if not ok[0] and res is not None:
+            res[name] = {"skipped": "budget", "needed_s": round(need_s, 1), "left_s": round(left(), 1)}
+        log(f"sub-record {name}: {'runs' if ok[0] else 'skipped (budget)'}, {left():.0f} s left")
+        return ok[0]
+
+    # ---- the sampler chain with nothing beside it, and the memory-side ceilings it runs against ----------------
+    # (rank 0's GPU; N > 1: every rank does the same work, only rank 0 reports)
+    if not args.no_sampler_roofline and fits("roofline_sampler", 4 + 6 * size_factor):
+        n_alone = max(4, min(args.steps, 20))
+        seeds_alone = [batch_seeds(next_step + k) for k in range(n_alone + 1)]
+        distinct_alone = [seeds_distinct(s) for s in seeds_alone]
+        next_step += n_alone + 1
+        s0 = s_samples[0]
+        barrier()
+        a0, a1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        with torch.cuda.stream(s0):
+            sampler.sample(seeds_alone[0], slot=0, copy_input_nodes=True, distinct=distinct_alone[0])  # warm
+            a0.record(s0)
+            for k in range(n_alone):
+                sampler.sample(seeds_alone[1 + k], slot=k % NSLOT, copy_input_nodes=True, distinct=distinct_alone[1 + k])
+            a1.record(s0)
+        torch.cuda.synchronize()
+        sampler_alone_ms = a0.elapsed_time(a1) / n_alone
+        # a batch that hit a device-side bound here must not pass silently: every batch reports its own status word
+        bad = [int(sampler.counts_slots[k][3 * L + 1].item()) for k in range(NSLOT)]
+        if any(bad):
+            raise SystemExit(f"device status {bad} in the sampler-alone region")
+        # ceilings: random requests on a table the size of the dedup table (one 64-bit word per node id), one launch =
+        # one step's worth of edges.  Returning atomicMin / 4-byte load / both per request (ggms_fabric_probe).
+        import ctypes as C
+        from xgnn_amd import lib as _lib
+        words = N
+        ptab = torch.full((words,), -1, dtype=torch.int64, device=dev)
+        sink = torch.zeros(1, dtype=torch.int32, device=dev)
+        reqs = max(1, int(edges / args.steps))
+        probe = {"table_bytes": words * 8, "requests_per_launch": reqs}
+        salt = 0x7fffff00
+        for kind, name in ((0, "atomic"), (1, "load"), (2, "load_atomic_pair")):
+            p0, p1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            for rep in range(5):
+                if rep == 1:
+                    p0.record()
+                rc = _lib().ggms_fabric_probe(kind, C.c_void_p(ptab.data_ptr()), words, reqs, salt, C.c_void_p(sink.data_ptr()),
+                                              C.c_void_p(torch.cuda.current_stream().cuda_stream))
+                assert rc == 0
+                salt -= 1
+            p1.record()
+            torch.cuda.synchronize()
+            probe[name + "s_per_s"] = reqs / (p0.elapsed_time(p1) / 4 / 1e3)
+        del ptab
+        if res is not None:
             E_step, S_step = edges / args.steps, blk["inputs"] / args.steps
             algo = 12 * S_step + 28 * E_step  # SURVEY 8d: per seed id + indptr pair; per edge neighbour + bucket + COO
             t = sampler_alone_ms / 1e3
             # request floor: one (neighbour load, dedup atomic) pair per edge + one indptr sector per seed, at the
             # rates this device sustains for exactly those requests (measured above, same process, same table size)
             floor_s = E_step / probe["load_atomic_pairs_per_s"] + S_step / probe["loads_per_s"]
-            st = measured_sampler_traffic(args.preset) if args.sample_type == "khop3" and not args.neighbour_skew else None
+            st = (measured_sampler_traffic(args.preset)
+                  if args.sample_type == "khop3" and not args.neighbour_skew and not topo_record else None)
             s_traffic = None
             if st is not None and not st["stale"]:  # PMC bytes per edge (profiled run of this command) x this run's edges / time
                 s_traffic = st["hbm_bytes_per_batch"] / st["edges_per_batch"] * E_step / t / 1e9
             res["roofline_sampler"] = {
-                "kernel": f"sampler chain of one batch alone on one stream: k_ht_insert, k_khop3_fused x {L}, "
-                          f"k_owner_scan_chunked x {L + 1}, k_map_rest_all x 2" if args.sample_type == "khop3" else
+                "kernel": (f"sampler chain of one batch alone on one stream: k_khop3_fused x {L} (the first also enters the "
+                           f"distinct seeds and runs the batch prologue), k_owner_scan_chunked x {L}, k_map_rest_all"
+                           if not args.no_distinct_seeds else
+                           f"sampler chain of one batch alone on one stream: k_ht_insert, k_khop3_fused x {L}, "
+                           f"k_owner_scan_chunked x {L + 1}, k_map_rest_all x 2") if args.sample_type == "khop3" else
                           f"sampler chain of one batch ({args.sample_type}) alone on one stream",
                 "bound": "hbm", "achieved": algo / t / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": algo / t / 8e12,
                 # bytes at the L2's memory side (FETCH_SIZE + WRITE_SIZE of the chain's kernels): 64-byte lines for 4-byte
@@ -913,15 +942,104 @@ def main():
                     "request_floor_ms": floor_s * 1e3, "chain_over_floor": t / floor_s,
                 },
             }
-        if stores is not None:
-            res["stores"] = stores
-        if engine is not None:
-            if "error" not in engine:  # how far the operator surface is from the headline of this run
-                engine["vs_headline_edges_per_s"] = engine["edges_per_s"] / res["value"]
-            res["engine"] = engine
-        if host_tier is not None:
-            res["host_tier"] = host_tier
-        if world == 1 and not args.no_cpu_baseline:
+
+    # ---- N > 1: the other stores, one block each ------------------------------------------------------------------
+    if world > 1:
+        for kind in [k for k in args.other_stores.split(",") if k and k != main_store]:
+            if not fits(f"stores.{kind}", 8 + 35 * size_factor):
+                if res is not None:
+                    res["stores"][kind] = res.pop(f"stores.{kind}")
+                continue
+            extract_main = keep_main = None
+            torch.cuda.empty_cache()
+            rec = None
+            try:  # a store that cannot be built here (memory) must not cost the line its main result
+                ex, keep_main = build_store(kind)
+                b2, next_step = measure(ex, args.steps, 2, 1, first_step=next_step)
+                rec = store_record(b2[0], kind)
+            except (RuntimeError, MemoryError) as e:  # PeerConnectError is one: raised on every rank alike
+                rec = {"error": f"{type(e).__name__}: {str(e)[:200]}"}
+            if res is not None:
+                res["stores"][kind] = rec
+
+    # ---- the same workload through the samgraph.torch surface (child process): arch1 at N = 1, arch6 with N workers ----
+    if full and not args.no_engine and args.sample_type.startswith("khop"):
+        need = (12 + 25 * size_factor) if world == 1 else (25 + 45 * size_factor + 8 * world * size_factor)
+        if fits("engine", need):
+            # the child may use what the budget leaves, minus what this process needs to finish and print
+            child_timeout = max(5.0, min(args.engine_timeout, left() - 10.0))
+            engine = None
+            if world == 1:
+                engine = engine_record(datagen, graph, fanouts, args, log, timeout=child_timeout)
+            else:  # rank 0 runs the child (which forks one engine worker per GPU), the other ranks wait
+                extract_main = keep_main = None  # the engine's workers build their own shards on these GPUs
+                torch.cuda.empty_cache()
+                barrier()
+                if rank == 0:
+                    # the same placement as the main region's: the planned hot prefix on every GPU (0 = pure shards);
+                    # --dist-graph: the topology sharded over the workers' GPUs too (XGNN mode, use_dist_graph)
+                    engine = engine_record(datagen, graph, fanouts, args, log, workers=world,
+                                           force_device=os.environ.get("GGMS_BENCH_DEVICE"),
+                                           replicate=(main_plan.get("replicated_fraction", 0.0)
+                                                      if main_store == "hybrid" else 0.0),
+                                           timeout=child_timeout, dist_graph=args.dist_graph or 0.0)
+                # the other ranks wait on the HOST (the rendezvous store), not inside an RCCL collective: a collective's
+                # kernel would spin on their GPUs for the minute the engine's workers are measuring on them
+                try:
+                    import datetime
+                    store = dist.distributed_c10d._get_default_store()
+                    if rank == 0:
+                        store.set("ggms_bench_engine_done", "1")
+                    else:
+                        store.wait(["ggms_bench_engine_done"], datetime.timedelta(seconds=child_timeout + 60))
+                except Exception as e:  # noqa: BLE001 -- no such store: the collective below is the meeting point
+                    log(f"host-side wait unavailable ({type(e).__name__}: {e}); waiting in the barrier")
+                barrier()
+            if res is not None and engine is not None:
+                if "error" not in engine:  # how far the operator surface is from the headline of this run
+                    engine["vs_headline_edges_per_s"] = engine["edges_per_s"] / res["value"]
+                res["engine"] = engine
+            log("engine sub-record done")
+
+    # ---- N = 1: BASELINE configs[2], every row in pinned host DRAM (cache_ratio 0) -----------------------------
+    cpu_feat = None
+    if world == 1 and full and not args.no_host_tier and fits("host_tier", 4 + 40 * size_factor):
+        cache = keep_main["cache"]
+        t0 = time.perf_counter()
+        hf = torch.empty((N, dim), dtype=torch.float32, pin_memory=True)  # hipHostMalloc, device-mapped
+        t_pin = time.perf_counter() - t0
+        hf.copy_(cache)  # the same rows the HBM tier holds (node order)
+        torch.cuda.synchronize()
+        # the box's pinned-copy rate, the ceiling of this tier: H2D of a 4-GiB slice of the table, 3 times
+        probe_rows = min(N, (4 << 30) // row_bytes)
+        dst = torch.empty((probe_rows, dim), dtype=torch.float32, device=dev)
+        c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        dst.copy_(hf[:probe_rows], non_blocking=True)
+        c0.record()
+        for _ in range(3):
+            dst.copy_(hf[:probe_rows], non_blocking=True)
+        c1.record()
+        torch.cuda.synchronize()
+        pinned_GBps = 3 * probe_rows * row_bytes / (c0.elapsed_time(c1) / 1e3) / 1e9
+        del dst
+
+        def extract_host(nodes, num_max, o, num_dev, counters):  # DoGPUFeatureExtract, dist_loops.cc:585-634
+            ops.gather_scatter(o, hf, nodes, None, num=num_max, num_dev=num_dev)
+        hb, next_step = measure(extract_host, args.host_steps, 1, 1, first_step=next_step)
+        h = hb[0]
+        res["host_tier"] = {
+            "config": "BASELINE configs[2]: same workload, cache_ratio 0 -- every feature row in pinned host DRAM "
+                      "(hipHostMalloc, device-mapped), gathered zero-copy by the same kernel",
+            "steps": args.host_steps, "ms_per_step": h["elapsed"] / args.host_steps * 1e3,
+            "edges_per_s": h["edges_all"] / h["elapsed"],
+            "feature_extract_GBps": h["feat_rate_all"], "rows_per_step": h["rows"] / args.host_steps,
+            "pinned_h2d_copy_GBps": pinned_GBps, "frac_of_pinned_copy": h["feat_rate_all"] / pinned_GBps,
+            "pinned_GiB": N * row_bytes / 2 ** 30, "pin_seconds": t_pin,
+        }
+        cpu_feat = hf.numpy()
+
+    if rank == 0:
+        if world == 1 and not args.no_cpu_baseline and fits("cpu_baseline", args.cpu_seconds * 1.3 + 3 + 25 * size_factor * (cpu_feat is None)):
             if cpu_feat is None:  # no host copy of the table yet (partial cache: host_feat; else generate it)
                 if host_feat is not None:
                     cpu_feat = host_feat.numpy()
@@ -929,7 +1047,8 @@ def main():
                     cpu_feat = np.empty((N, dim), np.float32)
                     feat_rows(torch.arange(N, dtype=torch.int64), torch.from_numpy(cpu_feat))
             res["cpu_baseline"] = cpu_baseline(graph, fanouts, args.batch, cpu_feat, args.cpu_seconds)
-        print(json.dumps(res))
+        res["budget"]["finished_at_s"] = round(time.perf_counter() - T0, 1)
+        print(json.dumps(res), flush=True)
     if world > 1:
         dist.destroy_process_group()
 

@@ -344,6 +344,16 @@ typedef struct {
    * gather and the fabric-heaviest sampler kernel one after the other instead of time-slicing them;
    * the smaller layers still overlap the gather.  NULL = no wait.  Results do not depend on it. */
   ggms_event_t heavy_wait;
+  /* != 0: the caller promises that the seeds are pairwise distinct -- a slice of a shuffled train set is
+   * (cuda_shuffler.cc:89-110); the padded tail of an aligned epoch (dist_shuffler_aligned.cc:46-63) and raw leaf
+   * calls may not be.  FillWithDupRevised(seeds) (dist_loops.cc:105-111) then has nothing to decide: local id =
+   * position, the unique list starts with the seeds as they are.  With the direct table layout the batch skips the
+   * seeds' insert / ordered scan / look-up launches: khop3 enters the seeds into the table inside the first layer's
+   * launch (their indices [0, S) win every atomicMin whenever they arrive; a neighbour instance that got there
+   * first is told so through `lost`, like any other beaten candidate), the other samplers use one small launch.
+   * Results are identical to the general path for distinct seeds; with duplicated seeds they are undefined. */
+  uint32_t seeds_distinct;
+  uint32_t _pad;
 } ggms_sample_extra_t;
 
 /* events for the ordering above (thin hipEvent_t handles, timing disabled) */

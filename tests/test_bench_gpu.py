@@ -48,6 +48,44 @@ def test_single_gpu_line():
     assert en["ms_per_step"] > 0 and en["edges_per_s"] > 0 and en["feature_GBps"] > 0 and en["steps"] == 8
 
 
+def test_headline_is_out_before_the_sub_records_and_the_budget_bounds_them():
+    """The headline line is printed as soon as the main region is measured; the optional sub-records share one wall-clock
+    budget.  Here the engine child never finishes (test hook) and the budget is short: the run still ends with rc 0
+    inside the budget (+ the interpreter's start-up), the first line is a complete headline, the last one carries
+    `engine.error`, and what no longer fitted says `skipped: budget`."""
+    import time
+    env = dict(os.environ, GGMS_BENCH_TEST_ENGINE_SLEEP="600")
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--preset", "tiny", "--steps", "4", "--warmup", "1",
+                        "--batch", "512", "--cpu-seconds", "20", "--budget-s", "45"], capture_output=True, text=True,
+                       timeout=300, cwd=ROOT, env=env)
+    wall = time.time() - t0
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [json.loads(l) for l in r.stdout.strip().splitlines() if l.startswith("{")]
+    assert len(lines) == 2 and wall < 45 + 30, (len(lines), wall)
+    first, last = lines
+    assert KEYS <= set(first) and first["rows_verified"] and "engine" not in first and first["value"] == last["value"]
+    assert first["budget"]["headline_at_s"] < 45
+    assert "error" in last["engine"] and "budget" in last["engine"]["error"]
+    # the child took what the budget left (minus a margin to finish in): what no longer fits after it says so
+    assert last["cpu_baseline"]["skipped"] == "budget" and last["cpu_baseline"]["needed_s"] > last["cpu_baseline"]["left_s"]
+    assert last["budget"]["finished_at_s"] < 45 + 10
+
+
+def test_sampling_through_logical_topology_shards_one_gpu():
+    """--dist-graph 0.5 --topology-shards 2 (N = 1): the timed sampler runs through DeviceDistGraph -- two logical
+    shards in HBM, the other half of the nodes read from the whole CSR in registered host memory; the rows gathered
+    for the sampled input nodes still check against the generator, and the line says what it measured."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--preset", "tiny", "--steps", "4", "--warmup", "1",
+                        "--batch", "512", "--no-cpu-baseline", "--no-host-tier", "--no-engine", "--dist-graph", "0.5",
+                        "--topology-shards", "2"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = _last_json(r.stdout)
+    topo = d["config"]["topology"]
+    assert d["rows_verified"] and topo["logical_shards"] == 2 and 0.3 < topo["cached_node_fraction"] < 0.7
+    assert "registered host memory" in d["config"]["workload"] and d["roofline_sampler"]["alone_ms"] > 0
+
+
 def test_two_ranks_default_is_the_planned_placement():
     """--gpus 2 with no --store: the main region runs on the GGMS placement planned from the per-GPU HBM budget (hybrid:
     hot prefix on every GPU, the rest sharded, one gather kernel over replica / local shard / peer shard); the pure

@@ -115,3 +115,14 @@ def test_graph_generator_is_thread_independent_and_skew_is_degree_proportional()
     half = datagen.make_graph(preset, seed=42, chunk=1 << 16, neighbour_skew=0.5)
     changed = (half["indices"] != a["indices"]).mean()
     assert 0.4 < changed < 0.6  # every neighbour is a degree-proportional pick with probability p, else the uniform one
+
+
+def test_num_cache_node_rule_matches_the_oracle():
+    """use_dist_graph = fraction of the EDGES on the GPUs (dist_engine.cc:225, dist_graph.cu:318-325): the host-side
+    rule of xgnn_amd.ggms_store against the oracle's restatement, edge cases included."""
+    import oracle
+    from graphgen import powerlaw_csr
+    from xgnn_amd import ggms_store
+    ip, _ = powerlaw_csr(5000, mean_deg=12, seed=3)
+    for f in (0.0, 1e-9, 0.1, 0.5, 0.64, 0.999, 1.0):
+        assert ggms_store.num_cache_node_for(ip, f) == oracle.num_cache_node(ip, f), f

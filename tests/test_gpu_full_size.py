@@ -51,6 +51,25 @@ def ops():
     return _ops
 
 
+@pytest.fixture(scope="module")
+def papers():
+    """The papers100M-shaped CSR (N 111,059,956, E 1.62e9), generated once for the module."""
+    from xgnn_amd import datagen
+    return datagen.make_graph("papers100M", seed=42)
+
+
+_ORACLE = {}
+
+
+def papers_oracle(papers, num_states):
+    """The oracle's GCN [5,10,15] batch of the first 8000 train nodes on the plain CSR (cached: a few seconds of CPU)."""
+    if num_states not in _ORACLE:
+        st = oracle.random_states(num_states, 0x5EED)
+        _ORACLE[num_states] = (oracle.do_sample(oracle.KHOP3, papers["indptr"], papers["indices"],
+                                                papers["train_set"][:BATCH], [5, 10, 15], st), st)
+    return _ORACLE[num_states]
+
+
 def coo_properties(ip, ix, seeds, fanouts, inp, layers):
     """layers[i] = (row, col, num_src, num_dst) as host arrays; khop samplers (exactly min(deg, fanout) edges per seed)."""
     L = len(fanouts)
@@ -114,9 +133,62 @@ def test_papers100m_hub_skewed_neighbours_oracle_exact(ops):
     coo_properties(ip, ix, seeds, fanouts, a["inp"], a["layers"])
 
 
-def test_papers100m_gcn_host_tier_and_hbm_tier(ops):
-    from xgnn_amd import datagen
-    g = datagen.make_graph("papers100M", seed=42)
+@pytest.mark.parametrize("P,fraction", [(2, 0.5), (8, 0.5), (8, 1.0)])
+def test_papers100m_sharded_topology_oracle_exact(ops, papers, P, fraction):
+    """XGNN mode's graph (arch6 + use_dist_graph, /root/reference README.md:184; DeviceDistGraph, cuda/dist_graph.h:114-158)
+    at papers100M size: the leading nodes that hold `fraction` of the edges live in P topology shards (node v in shard
+    v % P at row v / P -- P LOGICAL shards in this one process, every one of them in HBM), every other node is read from
+    the whole CSR in hipHostRegister'ed host memory (the last slot, over PCIe).  One GCN [5,10,15] batch sampled through
+    that view is the oracle's batch on the plain CSR: COO, input nodes, RNG pool, bit for bit."""
+    from xgnn_amd import ggms_store
+    ip, ix = papers["indptr"], papers["indices"]
+    N = ip.size - 1
+    ncn = ggms_store.num_cache_node_for(ip, fraction)
+    assert (ncn == N) if fraction >= 1.0 else (0.4 * N < ncn < 0.6 * N)  # the host slot is hit by about half the seeds
+    t_ip, t_ix = dev(ip), dev(ix)
+    pip, pix = ggms_store.topology_shards(t_ip, t_ix, P, ncn)
+    del t_ip, t_ix
+    torch.cuda.empty_cache()
+    # shard p, row r == node p + r P: spot-check the builder against the CSR itself
+    for p_ in (0, P - 1):
+        sp, sx = u32(pip[p_]), None
+        for r in (0, 1, (ncn - 1 - p_) // P):
+            v = p_ + r * P
+            lo, hi = int(sp[r]), int(sp[r + 1])
+            assert np.array_equal(u32(pix[p_][lo:hi]), ix[ip[v]:ip[v + 1]])
+    host_ip, host_ix = ops.RegisteredHost(ip), ops.RegisteredHost(ix)  # slot P: the whole CSR, host memory, zero-copy
+    try:
+        graph = ops.DeviceGraph(None, None, part_indptr=pip + [host_ip.tensor], part_indices=pix + [host_ix.tensor],
+                                num_cache_node=ncn)
+        fanouts, L = [5, 10, 15], 3
+        seeds = papers["train_set"][:BATCH]
+        bs = ops.BatchSampler(graph, fanouts, BATCH, sample_type=ops.KHOP3, seed=0x5EED)
+        bs.sample(dev(seeds), distinct=True)
+        r = bs.result()
+        want, orc_states = papers_oracle(papers, bs.states.shape[0])
+        assert np.array_equal(u32(r["input_nodes"]), want["input_nodes"])
+        for i in range(L):
+            assert np.array_equal(u32(r["layers"][i]["row"]), want["layers"][i]["row"])
+            assert np.array_equal(u32(r["layers"][i]["col"]), want["layers"][i]["col"])
+            assert (r["layers"][i]["num_src"], r["layers"][i]["num_dst"]) == (want["layers"][i]["num_src"], want["layers"][i]["num_dst"])
+        got_states = bs.states.cpu().numpy().view(np.uint32)
+        assert np.array_equal(got_states[:, 0], orc_states["d"]) and np.array_equal(got_states[:, 1:], orc_states["v"])
+        # khop0 reads whole neighbour lists through the same view (leaf call, one layer of the batch's frontier)
+        front = want["input_nodes"][:20_000]
+        src, dst, num = ops.sample_khop0(graph, dev(front), 10)
+        ws, wd = oracle.sample_khop0(ip, ix, front, 10)
+        n = int(num.item())
+        assert n == ws.size and np.array_equal(u32(src, n), ws) and np.array_equal(u32(dst, n), wd)
+        assert ops.device_status() == 0
+        del bs, graph
+    finally:
+        torch.cuda.synchronize()
+        host_ip.close()
+        host_ix.close()
+
+
+def test_papers100m_gcn_host_tier_and_hbm_tier(ops, papers):
+    g = papers
     ip, ix, meta = g["indptr"], g["indices"], g["meta"]
     N, dim = meta["num_node"], meta["feat_dim"]
     assert N == 111_059_956 and dim == 128
@@ -124,9 +196,9 @@ def test_papers100m_gcn_host_tier_and_hbm_tier(ops):
     fanouts, L = [5, 10, 15], 3
     seeds = g["train_set"][:BATCH]
     runs = []
-    for direct in (True, False, True):
+    for direct, distinct in ((True, False), (False, False), (True, True)):  # the third: seeds promised distinct
         bs = ops.BatchSampler(graph, fanouts, BATCH, sample_type=ops.KHOP3, seed=0x5EED, direct_table=direct)
-        bs.sample(dev(seeds))
+        bs.sample(dev(seeds), distinct=distinct)
         r = bs.result()
         runs.append(dict(inp=u32(r["input_nodes"]).copy(),
                          layers=[(u32(l["row"]).copy(), u32(l["col"]).copy(), l["num_src"], l["num_dst"]) for l in r["layers"]],
@@ -141,8 +213,7 @@ def test_papers100m_gcn_host_tier_and_hbm_tier(ops):
             assert np.array_equal(la[0], lb[0]) and np.array_equal(la[1], lb[1]) and la[2:] == lb[2:]
     coo_properties(ip, ix, seeds, fanouts, a["inp"], a["layers"])
     # the oracle on the same batch: bit-exact COO, input nodes and RNG pool
-    orc_states = oracle.random_states(num_states, 0x5EED)
-    want = oracle.do_sample(oracle.KHOP3, ip, ix, seeds, fanouts, orc_states)
+    want, orc_states = papers_oracle(papers, num_states)
     assert np.array_equal(a["inp"], want["input_nodes"])
     for i in range(L):
         assert np.array_equal(a["layers"][i][0], want["layers"][i]["row"])

@@ -29,6 +29,11 @@ def main():
     ap.add_argument("--replicate-percentage", type=float, default=0.0,
                     help="arch6: this fraction of the cached rows (hottest first) on every GPU, the rest sharded "
                          "(config key replicate_percentage; 0 = pure shards)")
+    ap.add_argument("--use-dist-graph", type=float, default=0.0, metavar="FRACTION",
+                    help="arch6: GGMS topology shards (config key use_dist_graph, /root/reference README.md:184) -- the leading "
+                         "nodes that hold this fraction of the EDGES are sharded over the workers' GPUs (node v in shard "
+                         "v %% W at row v / W, peers read over xGMI), every other node is read from the whole CSR in "
+                         "registered host memory; 0 = whole CSR on every GPU")
     ap.add_argument("--arch6", type=int, default=0, metavar="WORKERS",
                     help="the multi-GPU deployment instead of arch1: config + data_init here, one forked worker per GPU "
                          "(sample_init / train_init on cuda:<worker>), feature shards across the workers' GPUs "
@@ -82,6 +87,8 @@ def main_arch6(a):
            "fanout": a.fanout, "num_worker": W, "part_cache": "True", "gpu_extract": "True", "seed": a.seed}
     if a.replicate_percentage > 0:
         cfg["replicate_percentage"] = a.replicate_percentage
+    if a.use_dist_graph > 0:
+        cfg["use_dist_graph"] = a.use_dist_graph
     sam.config(cfg)
     sam.data_init()  # host only: the GPUs are first touched in the workers
     out_dir = tempfile.mkdtemp(prefix="ggms_engine_")
@@ -122,7 +129,8 @@ def main_arch6(a):
     recs = [json.load(open(os.path.join(out_dir, f"w{w}.json"))) for w in range(W)]
     wall = max(r["wall_s"] for r in recs)
     edges = sum(r["edges"] for r in recs)
-    out = {"arch": "arch6", "workers": W, "replicate_percentage": a.replicate_percentage, "steps": recs[0]["steps"], "wall_s": wall, "ms_per_step": wall / recs[0]["steps"] * 1e3,
+    out = {"arch": "arch6", "workers": W, "replicate_percentage": a.replicate_percentage,
+           "cache_percentage": a.cache_percentage, "use_dist_graph": a.use_dist_graph, "steps": recs[0]["steps"], "wall_s": wall, "ms_per_step": wall / recs[0]["steps"] * 1e3,
            "edges": edges, "edges_per_s": edges / wall,
            "sample_edges_per_s": sum(r["edges"] / r["sample_s"] for r in recs if r["sample_s"]),
            "feature_GBps": sum(r["feature_bytes"] / r["copy_s"] / 1e9 for r in recs if r["copy_s"]),

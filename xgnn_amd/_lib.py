@@ -23,7 +23,8 @@ class SampleExtra(C.Structure):
     """ggms_sample_extra_t"""
     _fields_ = [("prob_table", C.c_void_p), ("alias_table", C.c_void_p), ("random_walk_length", C.c_size_t),
                 ("random_walk_restart_prob", C.c_double), ("num_random_walk", C.c_size_t), ("data", C.c_void_p),
-                ("rng_wait", C.c_void_p), ("rng_done", C.c_void_p), ("heavy_wait", C.c_void_p)]
+                ("rng_wait", C.c_void_p), ("rng_done", C.c_void_p), ("heavy_wait", C.c_void_p),
+                ("seeds_distinct", C.c_uint32), ("_pad", C.c_uint32)]
 
 
 class FeatureTiers(C.Structure):

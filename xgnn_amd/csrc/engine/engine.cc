@@ -374,6 +374,22 @@ void Engine::ShufflerInit() {
   cur_step_ = num_local_step_;
   shuf_initialized_ = false;
   SAM_HIP(hipMalloc((void **)&shuf_dev_, std::max<size_t>(1, num_local_data_) * 4));
+  { // a train SET: no node twice (what lets a batch promise distinct seeds to the sampler)
+    std::vector<bool> seen(ds.num_node, false);
+    train_distinct_ = true;
+    for (size_t i = 0; i < origin && train_distinct_; ++i) {
+      if (train[i] >= ds.num_node || seen[train[i]]) train_distinct_ = false;
+      else seen[train[i]] = true;
+    }
+  }
+}
+
+// both copies of a padding node inside [offset, offset + size) of this worker's slice?
+bool Engine::BatchSeedsDistinct(size_t offset, size_t size) const {
+  if (!train_distinct_) return false;
+  for (const auto &pr : pad_pairs_)
+    if (pr.first >= offset && pr.first < offset + size && pr.second >= offset && pr.second < offset + size) return false;
+  return true;
 }
 
 void Engine::Reshuffle() {
@@ -389,6 +405,20 @@ void Engine::Reshuffle() {
   for (size_t i = 0; num_data_ && i < num_data_ - 1; i++) {
     std::uniform_int_distribution<size_t> d(i, num_data_ - 1);
     std::swap(data[i], data[d(g)]);
+  }
+  // where the padding copies went (at most num_worker - 1 nodes appear twice in the aligned epoch)
+  pad_pairs_.clear();
+  if (num_data_ > ds.num_train) {
+    const uint32_t *train = (const uint32_t *)ds.train_set.ptr;
+    std::unordered_map<uint32_t, size_t> first;
+    for (size_t i = 0; i < num_data_ - ds.num_train; ++i) first[train[i]] = (size_t)-1;
+    for (size_t pos = 0; pos < num_data_; ++pos) {
+      auto it = first.find(data[pos]);
+      if (it == first.end()) continue;
+      if (it->second == (size_t)-1) { it->second = pos; continue; }
+      const size_t a = it->second, b = pos, lo = global_data_offset_, hi = global_data_offset_ + num_local_data_;
+      if (a >= lo && a < hi && b >= lo && b < hi) pad_pairs_.emplace_back(a - lo, b - lo);
+    }
   }
   // the previous epoch's batches may still be copying their seeds out of shuf_dev_ on the pipeline streams
   for (auto &P : pipes_)
@@ -623,6 +653,7 @@ void Engine::Presample() {
       const size_t off = s * cfg.batch_size, size = std::min(cfg.batch_size, n_train - off);
       ggms_sample_extra_t extra = extra_;
       extra.data = dat.data();
+      extra.seeds_distinct = train_distinct_ ? 1u : 0u; // slices of a permutation of the train set
       // pipeline 0's table: its version stamp keeps counting when the training batches follow
       SAM_GGMS(ggms_sample_batch(cfg.sample_type, &graph_, d_train + off, size, cfg.fanout.data(), L, &pipes_[0].ht,
                                  states_, num_states_, row.data(), col.data(), d_counts, &extra, ws_, ws_bytes_, stream_));
@@ -846,6 +877,7 @@ bool Engine::EnqueueOne(bool background) {
   SAM_HIP(hipEventRecord(b->ev_start, ss));
   ggms_sample_extra_t extra = extra_;
   extra.data = b->data.data();
+  extra.seeds_distinct = BatchSeedsDistinct(cur_step_ * cfg.batch_size, b->num_seeds) ? 1u : 0u;
   if (pipes_.size() > 1 && cfg.sample_type != GGMS_KHOP0) {
     extra.rng_wait = last_rng_done_;
     extra.rng_done = P.rng_done;

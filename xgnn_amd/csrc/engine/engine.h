@@ -250,6 +250,11 @@ class Engine {
   size_t global_step_offset_ = 0, global_data_offset_ = 0;
   size_t cur_epoch_ = 0, cur_step_ = 0;
   bool shuf_initialized_ = false;
+  // ggms_sample_extra_t.seeds_distinct: the train set holds no node twice (checked once), so a batch's seeds are
+  // distinct unless both copies of a node that pads the aligned epoch (dist_shuffler_aligned.cc:52-54) fall into it
+  bool train_distinct_ = false;
+  std::vector<std::pair<size_t, size_t>> pad_pairs_; // this worker's slice, this epoch: local positions of such copies
+  bool BatchSeedsDistinct(size_t offset, size_t size) const;
   // features
   uint32_t *cache_table_ = nullptr;            // id -> slot (GPUCacheManager::_sampler_gpu_hashtable)
   std::vector<void *> cache_parts_;            // shard base pointers (local or IPC-mapped)

@@ -236,13 +236,16 @@ __host__ __device__ __forceinline__ unsigned long long make_w1(uint32_t version,
 // its own fill is resolved at the end of the batch (table word -> index -> IdxMap).
 struct IdxMap {
   uint32_t base[17];        // first index of segment s, ascending; segment 0 = the seeds
-  const uint32_t *arr[17];  // local ids of segment s, by index - base[s] (seed_local / the layer's row)
+  const uint32_t *arr[17];  // local ids of segment s, by index - base[s] (seed_local / the layer's row);
+                            // arr[0] == NULL: the seeds are distinct, local id = position
   uint32_t n;
   __device__ __forceinline__ uint32_t local_of(uint32_t idx) const {
     uint32_t s = 0;
 #pragma unroll
     for (uint32_t k = 1; k < 17; ++k) s = (k < n && idx >= base[k]) ? k : s;
-    return arr[s][idx - base[s]];
+    const uint32_t *a = arr[s];
+    const uint32_t off = idx - base[s];
+    return a ? a[off] : off;
   }
 };
 

@@ -15,13 +15,45 @@ struct SrcMode {
   }
 };
 
+// What the first kernel of a batch (the insert of the seeds) does on the side: clear the shared scan area's
+// control words + single-pass descriptors, reset the table's item count, record |seeds|.
+struct BatchPrologue {
+  uint32_t *zero_words;
+  uint32_t num_zero;
+  uint32_t *zero_words2; // second range (the chunked owner scan's descriptors)
+  uint32_t num_zero2;
+  uint32_t *num_items;
+  uint64_t *record_n;
+  uint32_t *zero_words3 = nullptr; // third range (fused first layer: the descriptors behind the ones it uses itself)
+  uint32_t num_zero3 = 0;
+  uint32_t items_are_seeds = 0;    // distinct seeds: the table's item count starts at |seeds| instead of 0
+  __device__ __forceinline__ void run(uint64_t n, uint32_t tid, uint32_t nthreads) const { // by ONE workgroup
+    for (uint32_t z = tid; z < num_zero; z += nthreads) zero_words[z] = 0u;
+    for (uint32_t z = tid; z < num_zero2; z += nthreads) zero_words2[z] = 0u;
+    for (uint32_t z = tid; z < num_zero3; z += nthreads) zero_words3[z] = 0u;
+    if (tid == 0) {
+      if (num_items) *num_items = items_are_seeds ? (uint32_t)n : 0u;
+      if (record_n) *record_n = n;
+    }
+  }
+};
+// distinct seeds entered by the first layer's own launch (khop3): the batch prologue rides on it, the seeds become
+// the head of the unique list where they are read
+struct FirstLayer {
+  BatchPrologue pro;
+  uint32_t *n2o;
+};
 // sample_khop.hip
 size_t sample_ws_words(size_t num_input);
 size_t khop0_ws_words(size_t num_input, size_t fanout);
 int sample_khop3_impl(GraphView g, const uint32_t *input, size_t n_max, Count n, uint32_t fanout, uint32_t *out_src,
                       uint32_t *out_dst, uint64_t *num_out_dev, uint32_t *states, uint32_t *workspace,
                       const uint32_t *seed_local, int src_local, hipStream_t s, ScanArea *shared_scan = nullptr,
-                      const DedupInsert *insert = nullptr);
+                      const DedupInsert *insert = nullptr, const FirstLayer *first = nullptr);
+bool khop3_can_fuse_seeds(size_t num_seeds); // every tile of the first layer has a workgroup of its own
+// distinct seeds, any sampler: one launch -- table entries, head of the unique list, batch prologue (hashtable.hip)
+int seed_enter_impl(const ggms_hashtable_t *ht, const uint32_t *seeds, size_t num_seeds, const BatchPrologue &pro,
+                    hipStream_t s);
 int sample_khop0_impl(GraphView g, const uint32_t *input, size_t n_max, Count n, uint32_t fanout, uint32_t *out_src,
                       uint32_t *out_dst, uint64_t *num_out_dev, uint32_t *workspace, const uint32_t *seed_local,
                       int src_local, hipStream_t s, ScanArea *shared_scan = nullptr, const DedupInsert *insert = nullptr);
@@ -55,16 +87,6 @@ int sample_weighted_hash_dedup_impl(const uint32_t *indptr, const uint32_t *indi
 // hashtable.hip
 size_t ht_ws_words(size_t num_input);
 size_t chunk_desc_words(); // 32-bit descriptors of the chunked owner scan: their own piece of a scan area
-// What the first kernel of a batch (the insert of the seeds) does on the side: clear the shared scan area's
-// control words + single-pass descriptors, reset the table's item count, record |seeds|.
-struct BatchPrologue {
-  uint32_t *zero_words;
-  uint32_t num_zero;
-  uint32_t *zero_words2; // second range (the chunked owner scan's descriptors)
-  uint32_t num_zero2;
-  uint32_t *num_items;
-  uint64_t *record_n;
-};
 // the end-of-batch id look-ups of the instances that do not own their key: one job per layer
 struct MapRestJobs {
   uint32_t *row[16];

@@ -110,14 +110,7 @@ __global__ __launch_bounds__(kBlock) void k_ht_insert(Table t, const uint32_t *_
                                                       uint32_t *__restrict__ item_pos, BatchPrologue pro,
                                                       DedupInsert di, uint32_t *err) {
   const uint64_t n = n_arg.get();
-  if (blockIdx.x == 0) {
-    for (uint32_t z = threadIdx.x; z < pro.num_zero; z += kBlock) pro.zero_words[z] = 0u;
-    for (uint32_t z = threadIdx.x; z < pro.num_zero2; z += kBlock) pro.zero_words2[z] = 0u;
-    if (threadIdx.x == 0) {
-      if (pro.num_items) *pro.num_items = 0u;
-      if (pro.record_n) *pro.record_n = n;
-    }
-  }
+  if (blockIdx.x == 0) pro.run(n, threadIdx.x, kBlock);
   for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (uint64_t)gridDim.x * kBlock) {
     const uint32_t key = items[i];
     if (DIRECT) {
@@ -127,6 +120,22 @@ __global__ __launch_bounds__(kBlock) void k_ht_insert(Table t, const uint32_t *_
       item_pos[i] = pos;
       if (pos != 0xffffffffu) atomicMin(t.w1<false>(pos), make_w1(t.version, 1u, (uint32_t)i));
     }
+  }
+}
+
+// Distinct seeds (ggms_sample_extra_t.seeds_distinct), direct layout: FillWithDupRevised(seeds) (dist_loops.cc:105-111)
+// has nothing to decide -- seed i is item i of the unique list and owns its key.  ONE launch instead of insert +
+// ordered scan + look-up: the table entry (index i: smaller than anything a later fill of the batch offers), the
+// head of n2o, the batch prologue (item count = |seeds|).
+__global__ __launch_bounds__(kBlock) void k_seed_enter(unsigned long long *__restrict__ w, uint32_t version,
+                                                       const uint32_t *__restrict__ seeds, Count n_arg,
+                                                       uint32_t *__restrict__ n2o, BatchPrologue pro) {
+  const uint64_t n = n_arg.get();
+  if (blockIdx.x == 0) pro.run(n, threadIdx.x, kBlock);
+  for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (uint64_t)gridDim.x * kBlock) {
+    const uint32_t key = seeds[i];
+    n2o[i] = key;
+    atomicMin(w + key, make_w1(version, 1u, (uint32_t)i)); // not returning: nothing of this batch was entered before
   }
 }
 
@@ -730,6 +739,14 @@ int launch_map_rest_all(const ggms_hashtable_t *ht, const MapRestJobs &jobs, uin
   const int gx = grid_for(max_items ? max_items : 1, kBlock);
   hipLaunchKernelGGL(k_map_rest_all, dim3(gx, num_jobs), dim3(kBlock), 0, s, (const unsigned long long *)ht->o2n, jobs, map,
                      batch_status, device_word, status_out);
+  GGMS_LAUNCH_CHECK();
+  return GGMS_OK;
+}
+
+int seed_enter_impl(const ggms_hashtable_t *ht, const uint32_t *seeds, size_t num_seeds, const BatchPrologue &pro,
+                    hipStream_t s) {
+  hipLaunchKernelGGL(k_seed_enter, dim3(grid_for(num_seeds, kBlock)), dim3(kBlock), 0, s, (unsigned long long *)ht->o2n,
+                     ht->version, seeds, count_of(num_seeds), ht->n2o, pro);
   GGMS_LAUNCH_CHECK();
   return GGMS_OK;
 }

@@ -214,9 +214,9 @@ int ggms_sample_batch(int sample_type, const ggms_graph_t *graph, const ggms_id_
   // FillWithDupRevised(seeds), dist_loops.cc:110-111, + the local ids of the raw seeds (they may repeat): the
   // first layer's `col`.  Its insert kernel is the first kernel of the batch and carries the prologue:
   // scan-area clear, item count reset, num_dst of the first layer = |seeds| (dist_loops.cc:305).
-  const BatchPrologue pro{scan_align(scan.words), (uint32_t)(8 + 2 * lay.scan_tiles),
-                          scan.chunk, (uint32_t)(chunk_desc_words() + (size_t)kTicketSets * kTicketWords), ht->num_items_dev,
-                          counts_dev + 3 * (num_layer - 1) + 2};
+  BatchPrologue pro{scan_align(scan.words), (uint32_t)(8 + 2 * lay.scan_tiles),
+                    scan.chunk, (uint32_t)(chunk_desc_words() + (size_t)kTicketSets * kTicketWords), ht->num_items_dev,
+                    counts_dev + 3 * (num_layer - 1) + 2};
   // direct table = batch mode of the dedup protocol (ggms_device.h): one index space for the whole batch, seeds first
   DedupInsert di{};
   di.cand = item_pos;
@@ -226,8 +226,34 @@ int ggms_sample_batch(int sample_type, const ggms_graph_t *graph, const ggms_id_
   di.map.n = 1;
   di.map.base[0] = 0;
   di.map.arr[0] = seed_local;
-  int rc = ht_fill_impl(ht, seeds, num_seeds, count_of(num_seeds), di, false, scan, nullptr, nullptr, s, seed_local, &pro,
-                        kRestNow, pro.record_n);
+  // Seeds the caller promises to be distinct (ggms_sample_extra_t.seeds_distinct), direct table: seed i is item i of the
+  // unique list and its own local id -- no insert / ordered scan / look-up launches.  khop3 enters them inside the
+  // first layer's launch (FirstLayer), every other sampler with one small launch (k_seed_enter).
+  const bool distinct = extra && extra->seeds_distinct && ht->direct && num_seeds != 0;
+  const bool fuse_seeds = distinct && sample_type == GGMS_KHOP3 && khop3_can_fuse_seeds(num_seeds) &&
+                          c.max_edges[num_layer - 1] != 0;
+  FirstLayer first_layer{};
+  int rc = GGMS_OK;
+  if (distinct) {
+    seed_local = nullptr;       // SrcMode: the first layer's `col` is the seed's position
+    di.map.arr[0] = nullptr;    // IdxMap: segment 0 is the identity
+    pro.items_are_seeds = 1;
+    if (fuse_seeds) {
+      // the prologue rides on the first layer's launch and must leave alone the tile descriptors that launch uses
+      // (words [8, 8 + 2 tiles) of the area; they are epoch-tagged like every descriptor shared inside a batch)
+      const size_t tiles0 = (num_seeds + 127) / 128;
+      pro.num_zero = 8;
+      pro.zero_words3 = pro.zero_words + 8 + 2 * tiles0;
+      pro.num_zero3 = (uint32_t)(lay.scan_tiles > tiles0 ? 2 * (lay.scan_tiles - tiles0) : 0);
+      first_layer.pro = pro;
+      first_layer.n2o = ht->n2o;
+    } else {
+      rc = seed_enter_impl(ht, seeds, num_seeds, pro, s);
+    }
+  } else {
+    rc = ht_fill_impl(ht, seeds, num_seeds, count_of(num_seeds), di, false, scan, nullptr, nullptr, s, seed_local, &pro,
+                      kRestNow, pro.record_n);
+  }
   if (rc != GGMS_OK) return rc;
   uint32_t next_base = (uint32_t)num_seeds;
 
@@ -258,7 +284,8 @@ int ggms_sample_batch(int sample_type, const ggms_graph_t *graph, const ggms_id_
       inserted = ht->direct != 0 && e_max != 0;
       if (inserted) di.tag = next_dedup_tag();
       rc = sample_khop3_impl(g, input, n_max, n, (uint32_t)fanouts[i], col[i], tmp_dst, num_edge, (uint32_t *)states,
-                             samp_ws, first ? seed_local : nullptr, 1, s, &scan, inserted ? &di : nullptr);
+                             samp_ws, first ? seed_local : nullptr, 1, s, &scan, inserted ? &di : nullptr,
+                             first && fuse_seeds ? &first_layer : nullptr);
     } else if (sample_type == GGMS_KHOP0) {
       inserted = ht->direct != 0 && e_max != 0; // khop0 enters its output where it produces it, too
       if (inserted) di.tag = next_dedup_tag();

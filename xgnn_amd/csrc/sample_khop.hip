@@ -103,13 +103,20 @@ struct Khop3TileHelp {
   }
 };
 
-template <int GPW, bool INSERT>
+// FIRST (the first layer of a batch whose seeds are promised distinct; one tile per workgroup, INSERT): the launch is
+// also the batch's first kernel -- workgroup 0 runs the batch prologue (it must not touch the tile descriptors this
+// launch uses: the host keeps them out of its ranges) and every seed is entered where it is read: head of the unique
+// list, table word {pending, position}.  A seed's word is smaller than any neighbour instance's, so it wins whenever it
+// arrives; if a neighbour instance of this launch got there first the seed tells it so through `lost`, exactly as any
+// smaller arrival does (DedupInsert) -- the owner scan and the end-of-batch look-ups need nothing new.
+template <int GPW, bool INSERT, bool FIRST>
 __global__ __launch_bounds__(128 * (4 / GPW)) void k_khop3_fused(GraphView g, const uint32_t *__restrict__ input,
                                                                  Count n_arg, uint32_t fanout, uint32_t fanout_magic,
                                                                  uint32_t *__restrict__ out_src,
                                                                  uint32_t *__restrict__ out_dst, SrcMode sm,
                                                                  uint32_t *__restrict__ states, uint32_t set_mask,
-                                                                 uint32_t multi, FusedScan fs, DedupInsert di) {
+                                                                 uint32_t multi, FusedScan fs, DedupInsert di,
+                                                                 FirstLayer fl) {
   constexpr uint32_t HASH_EMPTY = 0xffffffffu, NT = 128 * (4 / GPW), FLAG_A = 1, FLAG_P = 2;
   extern __shared__ uint32_t s_pos[];  // [128][fanout]: sampled positions of the tile's seeds
   __shared__ uint32_t set_tab[8][128]; // one open-addressing set per group; set_mask + 1 slots in use
@@ -120,6 +127,9 @@ __global__ __launch_bounds__(128 * (4 / GPW)) void k_khop3_fused(GraphView g, co
   const uint32_t lane = threadIdx.x & 63u;
   const bool active = GPW == 4 || lane < 16u * GPW; // lanes that belong to a group
   const uint64_t n = n_arg.get();
+  if constexpr (FIRST) {
+    if (blockIdx.x == 0) fl.pro.run(n, threadIdx.x, NT);
+  }
   const uint32_t y = (threadIdx.x >> 6) * GPW + (lane >> 4), lig = lane & 15u;
   const uint32_t grp_shift = lane & ~15u; // first lane of my group inside the wave
   uint32_t *const tab = set_tab[active ? y : 0];
@@ -145,12 +155,17 @@ __global__ __launch_bounds__(128 * (4 / GPW)) void k_khop3_fused(GraphView g, co
     if (b >= num_tiles) break;
     // ---- 1: lane lig of group y fetches seed k = lig of the group: id -> (list, degree, 2^32/deg)
     uint32_t my_len = 0, my_magic = 0;
+    unsigned long long seed_old = 0; // FIRST: what my seed's table word held (looked at after phase 3)
     if (active) {
       const uint64_t my_index = 128 * b + my_s;
       const uint32_t *ptr = nullptr;
       uint32_t rid = 0;
       if (my_index < n) {
         rid = input[my_index];
+        if constexpr (FIRST) {
+          fl.n2o[my_index] = rid;
+          seed_old = atomicMin(di.w + rid, make_w1(di.version, 1u, (uint32_t)my_index));
+        }
         ptr = g.neighbours(rid, my_len);
         if (my_len > fanout) my_magic = (uint32_t)(4294967296.0 / (double)my_len); // floor(2^32 / len), exact
       }
@@ -280,6 +295,14 @@ __global__ __launch_bounds__(128 * (4 / GPW)) void k_khop3_fused(GraphView g, co
           }
         }
         if (lig == 0) st.store(states + 6 * stream);
+      }
+    }
+    if constexpr (FIRST) { // a neighbour instance of THIS launch held my seed's word: it has just been beaten
+      const uint64_t my_index = 128 * b + my_s;
+      if (active && my_index < n) {
+        const unsigned long long mine = make_w1(di.version, 1u, (uint32_t)my_index);
+        const uint32_t idx = (uint32_t)seed_old;
+        if (seed_old > mine && (seed_old >> 32) == (mine >> 32) && idx >= di.base) di.lost[idx - di.base] = di.tag;
       }
     }
     // ---- 4: base offset of the tile (wave 0); the last tile knows the total
@@ -700,20 +723,22 @@ size_t sample_ws_words(size_t num_input) {
   return num_input + tile_scan_words(num_input) + 16 + 2 * (num_input / 128 + 2) + kTicketWords + 16;
 }
 
-template <int GPW, bool INSERT>
+template <int GPW, bool INSERT, bool FIRST>
 static int launch_khop3_fused(int grid, size_t lds, hipStream_t s, GraphView g, const uint32_t *input, Count n,
                                uint32_t fanout, uint32_t *out_src, uint32_t *out_dst, SrcMode sm, uint32_t *states,
-                               uint32_t set_mask, uint32_t multi, FusedScan fs, DedupInsert di) {
+                               uint32_t set_mask, uint32_t multi, FusedScan fs, DedupInsert di, FirstLayer fl) {
   const uint32_t fanout_magic = (uint32_t)((0x100000000ull + fanout - 1) / fanout); // ceil(2^32 / fanout)
   if (lds > (48u << 10)) { // large fan-outs: more dynamic LDS than the default per-kernel limit (gfx950 has 160 KB)
-    static const int raised = raise_dynamic_lds(reinterpret_cast<const void *>(&k_khop3_fused<GPW, INSERT>), 128 * 127 * 4,
-                                                "k_khop3_fused (fanout >= 96)");
+    static const int raised = raise_dynamic_lds(reinterpret_cast<const void *>(&k_khop3_fused<GPW, INSERT, FIRST>),
+                                                128 * 127 * 4, "k_khop3_fused (fanout >= 96)");
     if (raised != GGMS_OK) return raised;
   }
-  hipLaunchKernelGGL((k_khop3_fused<GPW, INSERT>), dim3(grid), dim3(128 * (4 / GPW)), lds, s, g, input, n, fanout,
-                     fanout_magic, out_src, out_dst, sm, states, set_mask, multi, fs, di);
+  hipLaunchKernelGGL((k_khop3_fused<GPW, INSERT, FIRST>), dim3(grid), dim3(128 * (4 / GPW)), lds, s, g, input, n, fanout,
+                     fanout_magic, out_src, out_dst, sm, states, set_mask, multi, fs, di, fl);
   return GGMS_OK;
 }
+
+bool khop3_can_fuse_seeds(size_t num_seeds) { return (num_seeds + 127) / 128 <= grid_cap(); }
 
 // the whole layer in one launch (see k_khop3_fused).  shared_scan: the batch's scan area (cleared by the batch
 // prologue); else the workspace holds a private one that is cleared here.  insert (direct dedup table): the
@@ -721,8 +746,12 @@ static int launch_khop3_fused(int grid, size_t lds, hipStream_t s, GraphView g, 
 int sample_khop3_impl(GraphView g, const uint32_t *input, size_t n_max, Count n, uint32_t fanout, uint32_t *out_src,
                       uint32_t *out_dst, uint64_t *num_out_dev, uint32_t *states, uint32_t *workspace,
                       const uint32_t *seed_local, int src_local, hipStream_t s, ScanArea *shared_scan,
-                      const DedupInsert *insert) {
+                      const DedupInsert *insert, const FirstLayer *first) {
   const size_t tiles = (n_max + 127) / 128;
+  if (first && (!insert || !shared_scan || !shared_scan->cleared || !khop3_can_fuse_seeds(n_max))) {
+    set_error("sample_khop3: the fused first layer needs the batch's dedup insert, its scan area and one tile per workgroup");
+    return GGMS_ERR_INVALID;
+  }
   uint32_t *ctl = scan_align(shared_scan ? shared_scan->words : workspace);
   // tickets: the batch's next set (zeroed by the batch prologue); a private area keeps its set behind the descriptors
   uint32_t *tick = shared_scan ? take_ticket_set(shared_scan) : ctl + 8 + 2 * (tiles + 1) + 2;
@@ -745,13 +774,17 @@ int sample_khop3_impl(GraphView g, const uint32_t *input, size_t n_max, Count n,
   const uint32_t multi = tiles <= grid_cap() ? 1u : 0u;
   const size_t lds = 128 * (size_t)fanout * sizeof(uint32_t);
   const DedupInsert none{};
+  const FirstLayer nofl{};
   int rc_l = GGMS_OK;
-  if (insert) {
-    if (gpw == 1) rc_l = launch_khop3_fused<1, true>(grid, lds, s, g, input, n, fanout, out_src, out_dst, sm, states, set_mask, multi, fs, *insert);
-    else rc_l = launch_khop3_fused<2, true>(grid, lds, s, g, input, n, fanout, out_src, out_dst, sm, states, set_mask, multi, fs, *insert);
+  if (first) {
+    if (gpw == 1) rc_l = launch_khop3_fused<1, true, true>(grid, lds, s, g, input, n, fanout, out_src, out_dst, sm, states, set_mask, multi, fs, *insert, *first);
+    else rc_l = launch_khop3_fused<2, true, true>(grid, lds, s, g, input, n, fanout, out_src, out_dst, sm, states, set_mask, multi, fs, *insert, *first);
+  } else if (insert) {
+    if (gpw == 1) rc_l = launch_khop3_fused<1, true, false>(grid, lds, s, g, input, n, fanout, out_src, out_dst, sm, states, set_mask, multi, fs, *insert, nofl);
+    else rc_l = launch_khop3_fused<2, true, false>(grid, lds, s, g, input, n, fanout, out_src, out_dst, sm, states, set_mask, multi, fs, *insert, nofl);
   } else {
-    if (gpw == 1) rc_l = launch_khop3_fused<1, false>(grid, lds, s, g, input, n, fanout, out_src, out_dst, sm, states, set_mask, multi, fs, none);
-    else rc_l = launch_khop3_fused<2, false>(grid, lds, s, g, input, n, fanout, out_src, out_dst, sm, states, set_mask, multi, fs, none);
+    if (gpw == 1) rc_l = launch_khop3_fused<1, false, false>(grid, lds, s, g, input, n, fanout, out_src, out_dst, sm, states, set_mask, multi, fs, none, nofl);
+    else rc_l = launch_khop3_fused<2, false, false>(grid, lds, s, g, input, n, fanout, out_src, out_dst, sm, states, set_mask, multi, fs, none, nofl);
   }
   if (rc_l != GGMS_OK) return rc_l;
   GGMS_LAUNCH_CHECK();

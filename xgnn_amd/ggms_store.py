@@ -311,3 +311,46 @@ def shard_rows(feat_rows_fn, rank_list, num_cached, world, rank, dim, dtype, dev
     if n:
         feat_rows_fn(mine, t[:n])
     return t, holder
+
+
+# ---- GGMS topology shards (DistGraph, cuda/dist_graph.cu:228-385) -------------------------------------------------
+def num_cache_node_for(indptr, fraction):
+    """How many leading nodes hold `fraction` of the edges: dist_engine.cc:225 (num_cache_edge = num_edge * fraction)
+    + DistGraph::GraphLoad's scan (dist_graph.cu:318-325).  indptr: uint32 host array."""
+    num_edge = int(indptr[-1])
+    cache_edge = np.uint32(int(num_edge * float(fraction)) & 0xFFFFFFFF)
+    return int(np.searchsorted(indptr[:-1], cache_edge, side="left"))
+
+
+def topology_shards(indptr, indices, num_part, num_cache_node, rows_per_step=1 << 24):
+    """_DatasetPartition (dist_graph.cu:228-272) on the GPU: shard p = the CSR of the nodes v = p (mod num_part),
+    v < num_cache_node, at rows v // num_part.  indptr / indices: int32 device tensors holding the uint32 CSR.
+    Returns (part_indptr, part_indices): two lists of num_part int32 device tensors -- the shards of every worker,
+    for one process that plays all of them (logical shards) or for a worker that keeps its own."""
+    dev = indptr.device
+    P = int(num_part)
+    pip, pix = [], []
+    for p in range(P):
+        nodes = torch.arange(p, num_cache_node, P, dtype=torch.int64, device=dev)
+        start = indptr[nodes].to(torch.int64) & 0xFFFFFFFF
+        end = indptr[nodes + 1].to(torch.int64) & 0xFFFFFFFF
+        deg = end - start
+        ip = torch.zeros(nodes.numel() + 1, dtype=torch.int64, device=dev)
+        torch.cumsum(deg, 0, out=ip[1:])
+        total = int(ip[-1].item())
+        ix = torch.empty(max(total, 1), dtype=torch.int32, device=dev)
+        # rows in blocks: the (row -> edge slots) expansion needs 8-byte temporaries per edge
+        for lo in range(0, nodes.numel(), rows_per_step):
+            hi = min(nodes.numel(), lo + rows_per_step)
+            d = deg[lo:hi]
+            n_e = int((ip[hi] - ip[lo]).item())
+            if n_e == 0:
+                continue
+            # source slot of shard edge k of row j: start[j] + (k - ip[j])
+            shift = torch.repeat_interleave(start[lo:hi] - ip[lo:hi], d)
+            src = torch.arange(int(ip[lo].item()), int(ip[lo].item()) + n_e, dtype=torch.int64, device=dev) + shift
+            ix[int(ip[lo].item()):int(ip[lo].item()) + n_e] = indices[src]
+            del shift, src
+        pip.append(ip.to(torch.int32))  # values < 2^32 kept bit for bit (uint32 in an int32 tensor)
+        pix.append(ix)
+    return pip, pix

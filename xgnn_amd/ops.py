@@ -405,6 +405,37 @@ _TYPESTR = {torch.float32: "<f4", torch.float64: "<f8", torch.float16: "<f2", to
             torch.int32: "<i4", torch.int8: "|i1", torch.int64: "<i8"}
 
 
+class RegisteredHost:
+    """A host array registered for device access (hipHostRegister, mapped): what DistGraph keeps in its last slot --
+    the whole CSR in host memory, read by the sampling kernels over PCIe (dist_graph.cu:367-381) -- and what the
+    `gpu_extract` miss tier is (dist_engine.cc:217-241).  `.tensor` aliases the host pages as a device tensor."""
+
+    def __init__(self, array, device="cuda"):
+        self.array = np.ascontiguousarray(array)  # kept alive: the registration pins THESE pages
+        hip = C.CDLL("libamdhip64.so")
+        self._hip = hip
+        nbytes = self.array.nbytes
+        self._host = C.c_void_p(self.array.ctypes.data)
+        with torch.cuda.device(torch.device(device)):
+            rc = hip.hipHostRegister(self._host, C.c_size_t(nbytes), C.c_uint(2))  # hipHostRegisterMapped
+            if rc != 0:
+                raise _lib.GgmsError(f"hipHostRegister({nbytes} bytes) -> {rc}")
+            dp = C.c_void_p()
+            rc = hip.hipHostGetDevicePointer(C.byref(dp), self._host, C.c_uint(0))
+            if rc != 0:
+                hip.hipHostUnregister(self._host)
+                raise _lib.GgmsError(f"hipHostGetDevicePointer -> {rc}")
+        kind = {4: "<i4", 8: "<i8", 1: "|u1", 2: "<i2"}[self.array.dtype.itemsize]
+        self.ptr = dp.value
+        self.tensor = torch.as_tensor(_RawDevice(self.ptr, self.array.shape, kind), device=torch.device(device))
+
+    def close(self):
+        if self._host is not None:
+            self.tensor = None
+            self._hip.hipHostUnregister(self._host)
+            self._host = None
+
+
 class SharedShard:
     """A GGMS shard that other processes can map: an allocation of its own (hipMalloc), published with
     hipIpcGetMemHandle and opened by peers with hipIpcOpenMemHandle (cuda/dist_graph.cu:228-272)."""
@@ -522,9 +553,11 @@ class BatchSampler:
         except Exception:
             pass
 
-    def sample(self, seeds, slot=0, copy_input_nodes=False, heavy_wait=None):
+    def sample(self, seeds, slot=0, copy_input_nodes=False, heavy_wait=None, distinct=False):
         """Enqueue one batch into output slot `slot`; read counts / row / col / ht.n2o after a sync.
         copy_input_nodes: also copy the unique list (ht.n2o, reused by a later batch) into the slot.
+        distinct: the caller promises pairwise distinct seeds (ggms_sample_extra_t.seeds_distinct) -- a slice of a
+        shuffled train set is; the seeds' insert / ordered scan / look-up launches are then skipped.
         Batch b runs on pipeline b % num_pipelines (its table is `self.ht` until the next call)."""
         _i32(seeds)
         n = seeds.numel()
@@ -544,6 +577,7 @@ class BatchSampler:
             ex.rng_done = self._events[pipe]
         # heavy_wait (torch.cuda.Event): the last layer's sampler launch waits for it (ggms_sample_extra_t.heavy_wait)
         ex.heavy_wait = C.c_void_p(heavy_wait.cuda_event) if heavy_wait is not None else None
+        ex.seeds_distinct = 1 if distinct else 0
         ws = self.wss[pipe]
         # copy_input_nodes: the slot keeps the batch's unique list.  The table's n2o buffer is the caller's
         # (ggms_hashtable_t is plain data), so the batch simply builds the list IN the slot's buffer -- no copy
