@@ -145,11 +145,15 @@ def main():
     def per_batch(match, counter, corr):
         ks = [k for (k, c) in pmc if c == counter and match in k]
         return sum(sum(pmc[(k, counter)]) for k in ks) * corr * 1024
-    batches = sum(len(v) for (k, c), v in pmc.items() if c == "FETCH_SIZE" and "k_ht_insert" in k)
+    # batches of the run: a batch starts with the first layer's launch that also enters the distinct seeds
+    # (k_khop3_fused<.., true, true>) or, on the general path, with the seeds' insert (k_ht_insert) / k_seed_enter
+    batches = sum(len(v) for (k, c), v in pmc.items() if c == "FETCH_SIZE" and
+                  ("k_ht_insert" in k or "k_seed_enter" in k or ("k_khop3_fused<" in k and ", true, true>" in k)))
     if batches:
         parts = {}
         for name, match, corr in (("fused samplers", "k_khop3_fused", 1.0), ("owner scans", "k_owner_scan", 2.0),
-                                  ("look-ups", "k_map_rest_all", 2.0), ("seed insert", "k_ht_insert", 1.0)):
+                                  ("look-ups", "k_map_rest_all", 2.0), ("seed insert", "k_ht_insert", 1.0),
+                                  ("seed enter", "k_seed_enter", 1.0)):
             parts[name] = {"fetch_bytes": per_batch(match, "FETCH_SIZE", corr) / batches,
                            "write_bytes": per_batch(match, "WRITE_SIZE", 1.0) / batches, "fetch_correction": corr}
         total = sum(p["fetch_bytes"] + p["write_bytes"] for p in parts.values())

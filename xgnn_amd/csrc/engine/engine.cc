@@ -714,21 +714,29 @@ void Engine::BuildCache() {
     for (size_t i = 0; i < num_cached_nodes_; ++i) table[rank[i]] = (uint32_t)i; // :197-229
     cache_table_ = (uint32_t *)dev_upload(table.data(), ds.num_node * 4, stream_);
   }
-  if (R) { // this GPU's copy of the hottest rows
-    std::vector<char> rep(R * row_bytes);
-    for (size_t i = 0; i < R; ++i) std::memcpy(&rep[i * row_bytes], feat + (size_t)(rank[i] & ds.feat_mask) * row_bytes, row_bytes);
-    d_replica_ = dev_upload(rep.data(), rep.size(), stream_);
-    SAM_HIP(hipStreamSynchronize(stream_));
-  }
+  // Rows are staged through a bounded host buffer (64 MB at a time), never through a host copy of the whole replica
+  // or shard: at papers100M size a replica is 46 GB, and eight workers of one node would hold eight of them at once.
+  auto upload_rows = [&](size_t first, size_t stride, size_t count) -> void * {
+    void *d = nullptr;
+    // shards are published to the other workers with hipIpc: sized so that a peer can open them (include/ggms.h)
+    SAM_HIP(hipMalloc(&d, ggms_ipc_safe_bytes(std::max<size_t>(count * row_bytes, 16))));
+    const size_t step = std::max<size_t>(1, (64u << 20) / row_bytes);
+    std::vector<char> stage(std::min(count, step) * row_bytes + 16);
+    for (size_t lo = 0; lo < count; lo += step) {
+      const size_t m = std::min(step, count - lo);
+      for (size_t k = 0; k < m; ++k)
+        std::memcpy(&stage[k * row_bytes], feat + (size_t)(rank[first + (lo + k) * stride] & ds.feat_mask) * row_bytes, row_bytes);
+      SAM_HIP(hipMemcpyAsync((char *)d + lo * row_bytes, stage.data(), m * row_bytes, hipMemcpyHostToDevice, stream_));
+      SAM_HIP(hipStreamSynchronize(stream_)); // the staging buffer is refilled next
+    }
+    return d;
+  };
+  if (R) d_replica_ = upload_rows(0, 1, R); // this GPU's copy of the hottest rows
   // DistGraph::FeatureLoad / _PartitionFeature, dist_graph.cu:493-521: rows rank[i], (i - R) == p (mod P)
   const size_t sharded = num_cached_nodes_ - R;
   const size_t my_rows = sharded / P + (p < sharded % P ? 1 : 0);
-  std::vector<char> tmp(std::max<size_t>(my_rows * row_bytes, 16));
-  size_t c = 0;
-  for (size_t i = R + p; i < num_cached_nodes_; i += P, ++c)
-    std::memcpy(&tmp[c * row_bytes], feat + (size_t)(rank[i] & ds.feat_mask) * row_bytes, row_bytes);
   cache_parts_.assign(P, nullptr);
-  cache_parts_[p] = dev_upload(tmp.data(), my_rows * row_bytes, stream_);
+  cache_parts_[p] = upload_rows(R + p, P, my_rows);
   SAM_HIP(hipStreamSynchronize(stream_));
   if (P > 1) { // _DataIpcShare
     SAM_HIP(hipIpcGetMemHandle(&shared_->feat_part[p], cache_parts_[p]));

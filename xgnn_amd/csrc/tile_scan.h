@@ -158,7 +158,7 @@ __device__ __forceinline__ uint32_t scan_lookback(unsigned long long *desc, uint
         const uint64_t tt = (uint64_t)(start - (int64_t)bpos);
         const uint32_t h = help(tt);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the inputs were READ before the word is looked at again
-        const unsigned long long now = __hip_atomic_load(&desc[tt], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long now = __hip_atomic_load(&desc[tt], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
         const uint32_t ntag = (uint32_t)(now >> 32);
         const bool there = (ntag >> 2) == epoch && (ntag & 3u) != 0;
         const unsigned long long mine = scan_desc(epoch, tt == 0 ? FLAG_P : FLAG_A, h);
@@ -253,6 +253,11 @@ __global__ __launch_bounds__(kBlock) void k_tile_scan(ValueF value, EmitF emit, 
         }
         if (lane == 0)
           __hip_atomic_store(&desc[0], scan_desc(epoch, FLAG_P, prefix + running), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // "the owner publishes before it overwrites anything": the word is OUT, device-wide, before the barrier below lets
+        // any wave of this workgroup emit -- a scan that works in place (the hashed table's owner flags) rewrites what a
+        // helper's value() reads, and a helper that still finds the word missing must have read the old input.  A
+        // workgroup-scope barrier alone does not wait for the store (XCD L2s are not coherent); one fence per launch.
+        __threadfence();
       } else {
         if (lane == 0)
           __hip_atomic_store(&desc[tile], scan_desc(epoch, FLAG_A, running), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
