@@ -65,9 +65,13 @@ def parse():
                     help="XGNN mode's topology (use_dist_graph, /root/reference README.md:184): the leading nodes holding this "
                          "fraction of the edges in topology shards (node v in shard v %% P at row v / P), the rest read from "
                          "the whole CSR in registered host memory.  N = 1: the timed sampler runs through --topology-shards "
-                         "LOGICAL shards in this process; N > 1: feeds the `engine` record (arch6 + use_dist_graph, one "
-                         "shard per worker GPU, peers over hipIpc / xGMI), the main region keeps the whole CSR per GPU")
+                         "LOGICAL shards in this process; N > 1: one shard per rank's GPU, peers mapped with hipIpc and read "
+                         "in-kernel over xGMI -- in the main region AND in the `engine` record (arch6 + use_dist_graph)")
     ap.add_argument("--topology-shards", type=int, default=2, help="N = 1 with --dist-graph: logical shards (<= 8)")
+    ap.add_argument("--host-indptr", action="store_true",
+                    help="N = 1 with --dist-graph < 1: keep the host slot's indptr in host memory too (the reference's layout: "
+                         "two dependent PCIe round trips per uncached seed); default: the whole indptr stays in HBM (4 B per "
+                         "node) and only the uncached nodes' neighbour lists are read over PCIe, as the engine does")
     ap.add_argument("--no-sampler-roofline", action="store_true",
                     help="skip the sampler-alone timing and the memory-side rate probe (roofline_sampler)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline: keep sampling mini-batches this long")
@@ -301,7 +305,8 @@ def engine_record(datagen, graph, fanouts, args, log, workers=0, force_device=No
         r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env)
         lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
         if r.returncode != 0 or not lines:
-            return {"error": f"engine child rc {r.returncode}: {r.stderr[-300:]}"}
+            err = [l for l in r.stderr.splitlines() if "FATAL" in l or "Error" in l or "error" in l or "failed" in l]
+            return {"error": f"engine child rc {r.returncode}: " + (" | ".join(err[:3]) if err else r.stderr[-300:])[:600]}
         e = json.loads(lines[-1])
         e["surface"] = ("samgraph.torch config / init / sample_once / get_next_batch (arch1, cache_percentage 1.0) on the "
                         "same graph written to disk in the reference's format, zero-filled feature table; second epoch; "
@@ -422,20 +427,45 @@ def main():
         ncn = ggms_store.num_cache_node_for(graph["indptr"], args.dist_graph)
         pip, pix = ggms_store.topology_shards(indptr, indices, P, ncn)
         if ncn < N:
-            del g, indptr, indices  # the device copy of the whole CSR goes: the host slot serves the uncached nodes
+            # the device copy of the whole `indices` goes: the host slot serves the uncached nodes' neighbour lists
+            topo_keep = (ops.RegisteredHost(graph["indptr"], dev) if args.host_indptr else None,
+                         ops.RegisteredHost(graph["indices"], dev))
+            slot = (topo_keep[0].tensor if args.host_indptr else indptr, topo_keep[1].tensor)
+            del g, indices
+            if args.host_indptr:
+                del indptr
             torch.cuda.empty_cache()
-            topo_keep = (ops.RegisteredHost(graph["indptr"], dev), ops.RegisteredHost(graph["indices"], dev))
-            slot = (topo_keep[0].tensor, topo_keep[1].tensor)
         else:
             slot = (indptr, indices)  # never read: every node is cached
         g = ops.DeviceGraph(None, None, part_indptr=pip + [slot[0]], part_indices=pix + [slot[1]], num_cache_node=ncn)
         topo_record = {"use_dist_graph": args.dist_graph, "logical_shards": P, "num_cache_node": ncn,
                        "cached_node_fraction": ncn / N,
-                       "host_slot": "whole CSR in hipHostRegister'ed host memory, read zero-copy over PCIe" if ncn < N else None}
+                       "host_slot": (("whole CSR" if args.host_indptr else "neighbour lists of the whole CSR (its indptr stays in HBM)")
+                                     + " in hipHostRegister'ed host memory, read zero-copy over PCIe") if ncn < N else None}
         topo_text = (f"graph in {P} logical topology shards in HBM (use_dist_graph {args.dist_graph:g}: the {ncn} leading nodes"
                      + (", every other node read from the whole CSR in registered host memory)" if ncn < N else ")"))
     elif args.dist_graph is not None:
-        topo_text = "graph in HBM (whole CSR per GPU in the main region; --dist-graph feeds the engine record)"
+        # XGNN mode across the ranks (DistGraph, cuda/dist_graph.cu:228-385): rank r keeps topology shard r of the leading
+        # nodes in ITS HBM and publishes it (hipIpc); every rank's sampling kernels read a peer's list heads and
+        # neighbour lists in place over xGMI.  The nodes beyond num_cache_node: indptr in HBM, lists in registered host memory.
+        ncn = ggms_store.num_cache_node_for(graph["indptr"], args.dist_graph)
+        if ncn < N:
+            host_ix = np.array(graph["indices"]) if isinstance(graph["indices"], np.memmap) else graph["indices"]
+            topo_keep = (None, ops.RegisteredHost(host_ix, dev))
+            slot = (indptr, topo_keep[1].tensor)
+        else:
+            slot = (indptr, torch.zeros(4, dtype=torch.int32, device=dev))  # never read: every node is cached
+        topo = ggms_store.TopologyShards(indptr, indices, world, rank, ncn, dist, slot)
+        del g, indices  # the whole CSR's neighbour lists leave this GPU: 1 / world of them stay, in the shard
+        torch.cuda.empty_cache()
+        g = topo.graph
+        topo_keep = (topo, topo_keep)
+        topo_record = {"use_dist_graph": args.dist_graph, "shards": world, "num_cache_node": ncn, "cached_node_fraction": ncn / N,
+                       "placement": "shard r in rank r's HBM, peers mapped with hipIpc and read in-kernel over xGMI",
+                       "host_slot": "neighbour lists of the whole CSR (its indptr stays in HBM) in hipHostRegister'ed host "
+                                    "memory, read zero-copy over PCIe" if ncn < N else None}
+        topo_text = (f"graph in {world} topology shards, one per GPU, peers read over xGMI (use_dist_graph {args.dist_graph:g}: "
+                     f"the {ncn} leading nodes" + (", every other node's list read from registered host memory)" if ncn < N else ")"))
     labels = (torch.arange(N, dtype=torch.int64, device=dev) % meta["num_class"]).contiguous()
 
     def feat_rows(node_ids, out):
@@ -945,22 +975,32 @@ def main():
 
     # ---- N > 1: the other stores, one block each ------------------------------------------------------------------
     if world > 1:
+        import gc
+
+        def other_store(kind, first_step):
+            """One block on another store; everything it built dies with this frame (the next store, and the engine's
+            workers after it, need the HBM)."""
+            ex, keep = build_store(kind)
+            b2, after = measure(ex, args.steps, 2, 1, first_step=first_step)
+            return store_record(b2[0], kind), after
+
         for kind in [k for k in args.other_stores.split(",") if k and k != main_store]:
             if not fits(f"stores.{kind}", 8 + 35 * size_factor):
                 if res is not None:
                     res["stores"][kind] = res.pop(f"stores.{kind}")
                 continue
             extract_main = keep_main = None
+            gc.collect()
             torch.cuda.empty_cache()
             rec = None
             try:  # a store that cannot be built here (memory) must not cost the line its main result
-                ex, keep_main = build_store(kind)
-                b2, next_step = measure(ex, args.steps, 2, 1, first_step=next_step)
-                rec = store_record(b2[0], kind)
+                rec, next_step = other_store(kind, next_step)
             except (RuntimeError, MemoryError) as e:  # PeerConnectError is one: raised on every rank alike
                 rec = {"error": f"{type(e).__name__}: {str(e)[:200]}"}
             if res is not None:
                 res["stores"][kind] = rec
+            gc.collect()
+            torch.cuda.empty_cache()
 
     # ---- the same workload through the samgraph.torch surface (child process): arch1 at N = 1, arch6 with N workers ----
     if full and not args.no_engine and args.sample_type.startswith("khop"):
@@ -973,6 +1013,8 @@ def main():
                 engine = engine_record(datagen, graph, fanouts, args, log, timeout=child_timeout)
             else:  # rank 0 runs the child (which forks one engine worker per GPU), the other ranks wait
                 extract_main = keep_main = None  # the engine's workers build their own shards on these GPUs
+                import gc
+                gc.collect()
                 torch.cuda.empty_cache()
                 barrier()
                 if rank == 0:

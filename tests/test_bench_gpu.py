@@ -86,6 +86,26 @@ def test_sampling_through_logical_topology_shards_one_gpu():
     assert "registered host memory" in d["config"]["workload"] and d["roofline_sampler"]["alone_ms"] > 0
 
 
+def test_two_ranks_xgnn_mode_topology_shards_in_the_main_region():
+    """--gpus 2 --dist-graph 0.5: rank r keeps topology shard r in its HBM, maps the peer's with hipIpc, the other half of
+    the nodes read their lists from registered host memory -- and the batches are the same batches: edges and rows per
+    step equal the run on the whole CSR (same seeds, same generator pool), the gathered rows check out."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(GGMS_BENCH_DEVICE="0", GGMS_BENCH_BACKEND="gloo")
+    lines = []
+    for extra in ([], ["--dist-graph", "0.5"]):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--preset", "tiny", "--steps", "4",
+                            "--warmup", "1", "--batch", "512", "--other-stores", "", "--no-engine", "--no-sampler-roofline"]
+                           + extra, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+        assert r.returncode == 0, r.stderr[-3000:]
+        lines.append(_last_json(r.stdout))
+    plain, xgnn = lines
+    assert xgnn["n_gpus"] == 2 and xgnn["rows_verified"] and xgnn["config"]["topology"]["shards"] == 2
+    assert 0.3 < xgnn["config"]["topology"]["cached_node_fraction"] < 0.7 and "over xGMI" in xgnn["config"]["workload"]
+    assert xgnn["per_gpu"]["edges_per_step"] == plain["per_gpu"]["edges_per_step"]
+    assert xgnn["per_gpu"]["rows_per_step"] == plain["per_gpu"]["rows_per_step"]
+
+
 def test_two_ranks_default_is_the_planned_placement():
     """--gpus 2 with no --store: the main region runs on the GGMS placement planned from the per-GPU HBM budget (hybrid:
     hot prefix on every GPU, the rest sharded, one gather kernel over replica / local shard / peer shard); the pure

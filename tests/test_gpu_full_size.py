@@ -158,7 +158,10 @@ def test_papers100m_sharded_topology_oracle_exact(ops, papers, P, fraction):
             assert np.array_equal(u32(pix[p_][lo:hi]), ix[ip[v]:ip[v + 1]])
     host_ip, host_ix = ops.RegisteredHost(ip), ops.RegisteredHost(ix)  # slot P: the whole CSR, host memory, zero-copy
     try:
-        graph = ops.DeviceGraph(None, None, part_indptr=pip + [host_ip.tensor], part_indices=pix + [host_ix.tensor],
+        # P = 2: the reference's layout (list heads AND lists of slot P on the host); P = 8: the engine's (slot P's
+        # indptr in HBM, its neighbour lists on the host) -- the layout of slot P is the caller's choice
+        slot_ip = host_ip.tensor if P == 2 else dev(ip)
+        graph = ops.DeviceGraph(None, None, part_indptr=pip + [slot_ip], part_indices=pix + [host_ix.tensor],
                                 num_cache_node=ncn)
         fanouts, L = [5, 10, 15], 3
         seeds = papers["train_set"][:BATCH]

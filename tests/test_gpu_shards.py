@@ -143,3 +143,73 @@ def test_shard_size_with_bit31_set_can_be_opened():
             if p.is_alive():
                 p.kill()
     assert res == [(0, True), (1, True)]
+
+
+def _topology_worker(rank, world, port, fraction, q):
+    """XGNN mode's graph across processes: rank r keeps topology shard r, maps the peers' (hipIpc) and samples its own
+    batches through the view; every batch must be the oracle's batch on the plain CSR."""
+    import oracle
+    from graphgen import powerlaw_csr
+    from xgnn_amd import ggms_store, ops
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    ip, ix = powerlaw_csr(40_000, mean_deg=18, seed=8)
+    N = ip.size - 1
+    t_ip = torch.from_numpy(ip.view(np.int32)).to(dev)
+    t_ix = torch.from_numpy(ix.view(np.int32)).to(dev)
+    ncn = ggms_store.num_cache_node_for(ip, fraction)
+    host = None
+    if ncn < N:  # the engine's layout of the last slot: indptr in HBM, neighbour lists in registered host memory
+        host = ops.RegisteredHost(ix, dev)
+        slot = (t_ip, host.tensor)
+    else:
+        slot = (t_ip, torch.zeros(4, dtype=torch.int32, device=dev))
+    topo = ggms_store.TopologyShards(t_ip, t_ix, world, rank, ncn, dist, slot)
+    del t_ix  # only the shard (and the peers' mappings) serve the cached nodes from here on
+    fanouts = [10, 5]
+    ok = True
+    for stype, code, ocode in (("khop3", ops.KHOP3, oracle.KHOP3), ("khop0", ops.KHOP0, oracle.KHOP0)):
+        bs = ops.BatchSampler(topo.graph, fanouts, 1000, sample_type=code, seed=40 + rank)
+        st = oracle.random_states(bs.states.shape[0], 40 + rank) if stype != "khop0" else None
+        rng = np.random.RandomState(7 + rank)
+        for rep in range(2):
+            seeds = rng.permutation(N)[:1000].astype(np.uint32)
+            bs.sample(torch.from_numpy(seeds.view(np.int32)).to(dev), distinct=True)
+            got = bs.result()
+            want = oracle.do_sample(ocode, ip, ix, seeds, fanouts, st)
+            ok = ok and np.array_equal(got["input_nodes"].cpu().numpy().view(np.uint32), want["input_nodes"])
+            for i in range(2):
+                ok = ok and np.array_equal(got["layers"][i]["row"].cpu().numpy().view(np.uint32), want["layers"][i]["row"])
+                ok = ok and np.array_equal(got["layers"][i]["col"].cpu().numpy().view(np.uint32), want["layers"][i]["col"])
+        del bs
+    torch.cuda.synchronize()
+    dist.barrier()  # nobody unmaps a shard a peer may still be reading
+    q.put((rank, ok))
+    dist.barrier()
+    topo.close()
+    if host is not None:
+        host.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,fraction", [(2, 1.0), (2, 0.5), (4, 0.7)])
+def test_topology_shards_across_processes(world, fraction):
+    """DistGraph across processes on the box's one GPU (cuda/dist_graph.cu:228-385): own shard + hipIpc-mapped peers + the
+    host slot behind one DeviceGraph; khop3 and khop0 batches equal the oracle's on every rank."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_topology_worker, args=(r, world, port, fraction, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    try:
+        res = sorted(q.get(timeout=300) for _ in range(world))
+    finally:
+        for p in procs:
+            p.join(timeout=120)
+            if p.is_alive():
+                p.kill()
+    assert res == [(r, True) for r in range(world)]
+    assert all(p.exitcode == 0 for p in procs)

@@ -21,4 +21,5 @@ run shards2_all_cached --dist-graph 1.0 --topology-shards 2 "$@"
 run shards8_all_cached --dist-graph 1.0 --topology-shards 8 "$@"
 run shards2_half_on_host --dist-graph 0.5 --topology-shards 2 "$@"
 run shards8_half_on_host --dist-graph 0.5 --topology-shards 8 "$@"
+run shards2_half_on_host_host_indptr --dist-graph 0.5 --topology-shards 2 --host-indptr "$@"
 run plain_again "$@"

@@ -526,8 +526,12 @@ void Engine::UploadGraph() {
     }
     Barrier("graph shards opened");
   }
-  // slot P: the whole CSR in (device-mapped) host memory, :367-381
-  part_indptr_[P] = (void *)map_host(ds.indptr.ptr, ds.indptr.bytes);
+  // slot P: the whole CSR, :367-381.  Its neighbour lists stay in (device-mapped) host memory as in the reference; its
+  // `indptr` -- 4 B per node, 0.44 GB at papers100M size against 288 GB of HBM -- is kept on the GPU: a seed beyond
+  // num_cache_node then pays ONE PCIe round trip (its sampled positions) instead of two dependent ones (list head, then
+  // positions), and 40 % fewer PCIe reads per batch.  The layout of slot P is not observable through the interface.
+  part_indptr_[P] = dev_upload(ds.indptr.ptr, ds.indptr.bytes, stream_);
+  SAM_HIP(hipStreamSynchronize(stream_));
   part_indices_[P] = (void *)map_host(ds.indices.ptr, ds.indices.bytes);
   // the P + 1 pointers stay on the host: ggms_sample_batch hands them to its kernels by value (include/ggms.h)
   SAM_CHECK(P <= GGMS_MAX_PARTS, "use_dist_graph: at most GGMS_MAX_PARTS topology shards");

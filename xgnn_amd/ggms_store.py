@@ -71,6 +71,57 @@ class PeerConnectError(RuntimeError):
     EVERY rank of the group with the failures of all of them, so the caller may decide together what to do."""
 
 
+def connect_shared(shared_shard, world, rank, dist, group=None, what="shard"):
+    """Publish this rank's shard (an ops.SharedShard) and map every peer's: DistGraph::_DataIpcShare
+    (cuda/dist_graph.cu:274-307) over torch.distributed's byte channel.  Returns the shards' device addresses in this
+    process, by rank.  Every wait on a peer has a deadline; an IPC call that FAILS on any rank raises PeerConnectError
+    on EVERY rank (after closing the mappings that did open), so nobody is left waiting in the next collective."""
+    # the shard must be COMPLETE before a peer may read it: drain this device's queue before publishing (the
+    # fill kernels are asynchronous), and meet the peers again once everybody has mapped everybody (below)
+    if shared_shard.tensor.is_cuda:
+        torch.cuda.synchronize(shared_shard.tensor.device)
+    nbytes = int(np.prod(shared_shard.shape)) * shared_shard.tensor.element_size()
+    me = f"rank {rank} of {world} (device {shared_shard.tensor.device})"
+    failed = None
+    try:
+        mine = shared_shard.export_handle()
+    except Exception as e:  # noqa: BLE001 -- published as "no handle"; reported with the verdicts below
+        mine, failed = None, f"{me}: hipIpcGetMemHandle of its own {what} ({nbytes} bytes): {type(e).__name__}: {e}"
+    if world == 1:
+        handles = [(mine, nbytes)]
+    else:
+        handles = [None] * world
+        # every wait on a peer is bounded (with_deadline): exit with a message instead of hanging
+        with_deadline(lambda: dist.all_gather_object(handles, (mine, nbytes), group=group),
+                      f"{me} waiting for the peers' {what} handles (all_gather): a rank never published its shard")
+    ptrs = []
+    try:
+        for r in range(world):
+            if r == rank:
+                ptrs.append(shared_shard.ptr)
+                continue
+            h, peer_bytes = handles[r]
+            if h is None:  # that rank could not export: it says so itself
+                ptrs.append(0)
+                continue
+            ptrs.append(with_deadline(lambda h=h: shared_shard.import_peer(h),
+                                      f"{me}: hipIpcOpenMemHandle of rank {r}'s {what} ({peer_bytes} bytes) did not return"))
+    except Exception as e:  # noqa: BLE001 -- an open that FAILED (one that hangs ends the process above)
+        failed = failed or f"{me}: {what} of rank {r} ({peer_bytes} bytes): {type(e).__name__}: {e}"
+    if world > 1:
+        # the meeting point after the mapping doubles as the verdict: every rank learns of every failure and all
+        # of them leave together (a rank raising alone would strand the others in the next collective)
+        verdicts = [None] * world
+        with_deadline(lambda: dist.all_gather_object(verdicts, failed, group=group),
+                      f"{me} waiting for the peers after mapping their {what}s: a rank is stuck opening one")
+        failed = "; ".join(v for v in verdicts if v) or None
+    if failed:
+        # nothing will own the mappings that did open: close them here (every rank gets here, see above)
+        shared_shard.release_peers()
+        raise PeerConnectError(failed)
+    return ptrs
+
+
 class HipLeaf:
     """The device operators the store needs, on HIP (xgnn_amd.ops)."""
 
@@ -156,49 +207,7 @@ class FeatureShards:
         takes the shard pointers by value)."""
         assert self.mode == "peer"
         self._shared = shared_shard
-        # the shard must be COMPLETE before a peer may read it: drain this device's queue before publishing (the
-        # fill kernels are asynchronous), and meet the peers again once everybody has mapped everybody (below)
-        if shared_shard.tensor.is_cuda:
-            torch.cuda.synchronize(shared_shard.tensor.device)
-        nbytes = int(np.prod(shared_shard.shape)) * self.shard.element_size()
-        me = f"rank {self.rank} of {self.world} (device {self.shard.device})"
-        failed = None
-        try:
-            mine = shared_shard.export_handle()
-        except Exception as e:  # noqa: BLE001 -- published as "no handle"; reported with the verdicts below
-            mine, failed = None, f"{me}: hipIpcGetMemHandle of its own shard ({nbytes} bytes): {type(e).__name__}: {e}"
-        if self.world == 1:
-            handles = [(mine, nbytes)]
-        else:
-            handles = [None] * self.world
-            # every wait on a peer is bounded (with_deadline): exit with a message instead of hanging
-            with_deadline(lambda: self.dist.all_gather_object(handles, (mine, nbytes), group=self.group),
-                          f"{me} waiting for the peers' shard handles (all_gather): a rank never published its shard")
-        ptrs = []
-        try:
-            for r in range(self.world):
-                if r == self.rank:
-                    ptrs.append(shared_shard.ptr)
-                    continue
-                h, peer_bytes = handles[r]
-                if h is None:  # that rank could not export: it says so itself
-                    ptrs.append(0)
-                    continue
-                ptrs.append(with_deadline(lambda h=h: shared_shard.import_peer(h),
-                                          f"{me}: hipIpcOpenMemHandle of rank {r}'s shard ({peer_bytes} bytes) did not return"))
-        except Exception as e:  # noqa: BLE001 -- an open that FAILED (one that hangs ends the process above)
-            failed = failed or f"{me}: shard of rank {r} ({peer_bytes} bytes): {type(e).__name__}: {e}"
-        if self.world > 1:
-            # the meeting point after the mapping doubles as the verdict: every rank learns of every failure and all
-            # of them leave together (a rank raising alone would strand the others in the next collective)
-            verdicts = [None] * self.world
-            with_deadline(lambda: self.dist.all_gather_object(verdicts, failed, group=self.group),
-                          f"{me} waiting for the peers after mapping their shards: a rank is stuck opening one")
-            failed = "; ".join(v for v in verdicts if v) or None
-        if failed:
-            # nothing will own the mappings that did open: close them here (every rank gets here, see above)
-            shared_shard.release_peers()
-            raise PeerConnectError(failed)
+        ptrs = connect_shared(shared_shard, self.world, self.rank, self.dist, self.group, what="feature shard")
         self.parts_table = self.leaf.pointer_table(ptrs)
         return self
 
@@ -322,15 +331,15 @@ def num_cache_node_for(indptr, fraction):
     return int(np.searchsorted(indptr[:-1], cache_edge, side="left"))
 
 
-def topology_shards(indptr, indices, num_part, num_cache_node, rows_per_step=1 << 24):
+def topology_shards(indptr, indices, num_part, num_cache_node, rows_per_step=1 << 24, only=None):
     """_DatasetPartition (dist_graph.cu:228-272) on the GPU: shard p = the CSR of the nodes v = p (mod num_part),
     v < num_cache_node, at rows v // num_part.  indptr / indices: int32 device tensors holding the uint32 CSR.
-    Returns (part_indptr, part_indices): two lists of num_part int32 device tensors -- the shards of every worker,
-    for one process that plays all of them (logical shards) or for a worker that keeps its own."""
+    Returns (part_indptr, part_indices): two lists of int32 device tensors -- the shards of every worker (one process
+    that plays all of them: logical shards), or with only=p just worker p's own."""
     dev = indptr.device
     P = int(num_part)
     pip, pix = [], []
-    for p in range(P):
+    for p in (range(P) if only is None else [int(only)]):
         nodes = torch.arange(p, num_cache_node, P, dtype=torch.int64, device=dev)
         start = indptr[nodes].to(torch.int64) & 0xFFFFFFFF
         end = indptr[nodes + 1].to(torch.int64) & 0xFFFFFFFF
@@ -354,3 +363,44 @@ def topology_shards(indptr, indices, num_part, num_cache_node, rows_per_step=1 <
         pip.append(ip.to(torch.int32))  # values < 2^32 kept bit for bit (uint32 in an int32 tensor)
         pix.append(ix)
     return pip, pix
+
+
+class TopologyShards:
+    """This rank's view of the sharded topology (DistGraph, cuda/dist_graph.cu:228-385): it builds shard `rank` of the
+    leading num_cache_node nodes, publishes it (two hipIpc allocations: indptr, indices), maps every peer's, and hands
+    out a DeviceGraph whose kernels read a peer's list heads and neighbour lists in place over xGMI.  slot: (indptr,
+    indices) tensors of the whole CSR for the nodes beyond num_cache_node (device or registered host memory)."""
+
+    def __init__(self, indptr, indices, world, rank, num_cache_node, dist, slot, group=None):
+        from . import ops
+        pip, pix = topology_shards(indptr, indices, world, num_cache_node, only=rank)
+        self.holders = []
+        tabs = []
+        for name, t in (("topology indptr shard", pip[0]), ("topology indices shard", pix[0])):
+            h = ops.SharedShard((max(1, t.numel()),), torch.int32, t.device)
+            h.tensor[:t.numel()].copy_(t)
+            self.holders.append(h)
+            tabs.append(connect_shared(h, world, rank, dist, group, what=name))
+        del pip, pix
+        self.num_cache_node, self.world, self.rank = int(num_cache_node), world, rank
+        self._slot = slot
+        self.graph = ops.DeviceGraph(None, None, part_indptr=[_Addr(a) for a in tabs[0]] + [slot[0]],
+                                     part_indices=[_Addr(a) for a in tabs[1]] + [slot[1]], num_cache_node=num_cache_node)
+
+    def close(self):
+        for h in self.holders:
+            h.close()
+        self.holders = []
+
+
+class _Addr:
+    """A device address standing in for a tensor where only data_ptr() / numel() are asked (peer mappings)."""
+
+    def __init__(self, ptr):
+        self._ptr = int(ptr)
+
+    def data_ptr(self):
+        return self._ptr
+
+    def numel(self):
+        return 0
