@@ -68,6 +68,9 @@ def parse():
                          "LOGICAL shards in this process; N > 1: one shard per rank's GPU, peers mapped with hipIpc and read "
                          "in-kernel over xGMI -- in the main region AND in the `engine` record (arch6 + use_dist_graph)")
     ap.add_argument("--topology-shards", type=int, default=2, help="N = 1 with --dist-graph: logical shards (<= 8)")
+    ap.add_argument("--no-xgnn-mode", action="store_true",
+                    help="N > 1 without --dist-graph: skip the `xgnn_mode` sub-record (one block with the topology sharded "
+                         "over the GPUs as well, use_dist_graph 1.0)")
     ap.add_argument("--host-indptr", action="store_true",
                     help="N = 1 with --dist-graph < 1: keep the host slot's indptr in host memory too (the reference's layout: "
                          "two dependent PCIe round trips per uncached seed); default: the whole indptr stays in HBM (4 B per "
@@ -537,8 +540,19 @@ def main():
         if R:
             replica = torch.empty((R, dim), dtype=torch.float32, device=dev)
             feat_rows(order[:R], replica)
-        shard, holder = ggms_store.shard_rows(feat_rows, order[R:], num_cached - R, world, rank, dim, torch.float32,
-                                              dev, shared=(kind != "a2a"))
+        try:
+            shard, holder = ggms_store.shard_rows(feat_rows, order[R:], num_cached - R, world, rank, dim, torch.float32,
+                                                  dev, shared=(kind != "a2a"))
+        except (RuntimeError, MemoryError) as e:
+            if kind == "a2a":
+                raise
+            # this rank cannot build its shard (memory): the peers are about to exchange handles -- walk through the same
+            # collectives with the reason, so that every rank raises PeerConnectError together (and takes the same turn)
+            replica = table = None
+            torch.cuda.empty_cache()
+            ggms_store.connect_shared(ggms_store.FailedShard(f"{type(e).__name__}: {e}"), world, rank, dist,
+                                      what="feature shard")
+            raise  # not reached: the verdict above raises on every rank
         st = ggms_store.FeatureShards(shard, table, world, rank, mode="a2a" if kind == "a2a" else "peer", dist=dist,
                                       host_feat=host_feat, replica=replica)
         log(f"store {kind}: shard filled")
@@ -888,6 +902,32 @@ def main():
             res[name] = {"skipped": "budget", "needed_s": round(need_s, 1), "left_s": round(left(), 1)}
         log(f"sub-record {name}: {'runs' if ok[0] else 'skipped (budget)'}, {left():.0f} s left")
         return ok[0]
+
+    # ---- N > 1: the same store with the TOPOLOGY sharded too (XGNN mode, use_dist_graph 1.0), one block -------------
+    # The main region keeps the whole CSR on every GPU (6.9 GB of 288: the MI355X-first placement); this block is the
+    # reference's defining configuration beside it: rank r keeps topology shard r, every list head and neighbour read of
+    # a node in a peer's shard crosses xGMI inside the sampling kernels.
+    if world > 1 and args.dist_graph is None and not args.no_xgnn_mode and fits("xgnn_mode", 8 + 14 * size_factor):
+        sampler_main, topo, rec = sampler, None, None
+        try:
+            topo = ggms_store.TopologyShards(indptr, indices, world, rank, N, dist, (indptr, indices))
+            sampler = ops.BatchSampler(topo.graph, fanouts, args.batch, sample_type=code, seed=0x5EED + rank, device=dev,
+                                       num_slots=NSLOT, num_pipelines=K, **extra_kw)
+            bx, next_step = measure(extract_main, args.steps, 2, 1, first_step=next_step)
+            rec = {**store_record(bx[0], main_store), "use_dist_graph": 1.0,
+                   "what": f"one block of the main region's workload with the topology in {world} shards, one per GPU "
+                           "(node v in shard v % N at row v / N, DeviceDistGraph): peers' list heads and neighbour lists "
+                           "read in-kernel over xGMI through hipIpc mappings; feature store as in the main region",
+                   "vs_main_edges_per_s": bx[0]["edges_all"] / bx[0]["elapsed"] / (edges_all / elapsed)}
+        except (RuntimeError, MemoryError) as e:
+            rec = {"error": f"{type(e).__name__}: {str(e)[:300]}"}
+        sampler = sampler_main
+        barrier()  # nobody unmaps a shard a peer's kernels may still be reading
+        if topo is not None:
+            topo.close()
+        topo = None
+        if res is not None:
+            res["xgnn_mode"] = rec
 
     # ---- the sampler chain with nothing beside it, and the memory-side ceilings it runs against ----------------
     # (rank 0's GPU; N > 1: every rank does the same work, only rank 0 reports)

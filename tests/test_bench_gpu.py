@@ -127,6 +127,10 @@ def test_two_ranks_default_is_the_planned_placement():
     assert 0 <= st["hybrid"]["remote_row_fraction"] < st["peer"]["remote_row_fraction"]
     assert st["hybrid"]["replicated_fraction"] > 0.9 and st["hybrid"]["hbm_budget_gb"] == 48.0
     assert st["hybrid"]["edges_per_s"] == d["value"]
+    # beside it, by default: the same store with the topology sharded over the GPUs too (XGNN mode)
+    x = d["xgnn_mode"]
+    assert "error" not in x, x
+    assert x["use_dist_graph"] == 1.0 and x["edges_per_s"] > 0 and 0.2 < x["vs_main_edges_per_s"] < 2.0
 
 
 _BROKEN_IPC = """

@@ -164,3 +164,50 @@ def test_a_refused_ipc_call_on_one_rank_is_raised_on_every_rank(tmp_path, where)
         assert "REFUSED" in out and "rank 1 of 2" in out and "in step" in out and "MAPPED" not in out
         assert "RELEASED" in out  # nobody is left owning a peer mapping
         assert ("hipIpcOpenMemHandle: invalid device pointer" if where == "import" else "hipIpcGetMemHandle") in out
+
+
+_OOM_SCRIPT = """
+import os, sys, time
+sys.path.insert(0, {root!r})
+import torch, torch.distributed as dist
+from xgnn_amd import ggms_store
+rank = int(sys.argv[1])
+
+class HostShard:
+    def __init__(self):
+        self.tensor = torch.zeros((8, 4)); self.shape = (8, 4); self.ptr = self.tensor.data_ptr()
+    def export_handle(self): return b"h" * 64
+    def import_peer(self, h): return 1234
+    def release_peers(self): print("RELEASED")
+
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=sys.argv[2])
+dist.init_process_group("gloo", rank=rank, world_size=2)
+# rank 1 "ran out of memory" building its shard: it still takes part in the exchange, with its reason
+sh = ggms_store.FailedShard("OutOfMemoryError: tried to allocate 28.4 GiB") if rank == 1 else HostShard()
+try:
+    ggms_store.connect_shared(sh, 2, rank, dist, what="feature shard")
+    print("MAPPED")
+except ggms_store.PeerConnectError as e:
+    print("REFUSED", e)
+dist.barrier()
+print("in step")
+"""
+
+
+def test_a_rank_that_cannot_build_its_shard_is_a_verdict_of_every_rank(tmp_path):
+    """One rank fails BEFORE the handle exchange (out of memory while filling its shard): it walks through the same
+    collectives with its reason (ggms_store.FailedShard), every rank raises PeerConnectError with that reason, nobody
+    waits for a deadline and the group stays in step."""
+    script = tmp_path / "oom.py"
+    script.write_text(_OOM_SCRIPT.format(root=ROOT))
+    port = str(_free_port())
+    env = dict(os.environ, GGMS_IPC_TIMEOUT_S="30")
+    t0 = time.time()
+    ps = [subprocess.Popen([sys.executable, str(script), str(r), port], env=env, stdout=subprocess.PIPE,
+                           stderr=subprocess.PIPE, text=True) for r in (0, 1)]
+    outs = [p.communicate(timeout=120) for p in ps]
+    assert time.time() - t0 < 25  # nobody sat out the 30-s deadline
+    for p, (out, err) in zip(ps, outs):
+        assert p.returncode == 0, err[-1000:]
+        assert "REFUSED" in out and "could not build its feature shard" in out and "28.4 GiB" in out
+        assert "in step" in out and "MAPPED" not in out

@@ -52,7 +52,9 @@ for fanouts in ([5, 5, 5], [10, 5]) if walk else ([25, 10], [5, 10, 15]):
     t0 = time.time()
     for b in range(nb):
         with torch.cuda.stream(streams[b % K]):
-            bs.sample(t_seeds[b], slot=b, copy_input_nodes=True)
+            # every other batch with the distinct-seed promise (its seeds are a slice of a permutation): the fused /
+            # one-launch seed paths and the general insert + scan + look-up path interleave on the same tables
+            bs.sample(t_seeds[b], slot=b, copy_input_nodes=True, distinct=(b % 2 == 0))
         with torch.cuda.stream(noise):  # an HBM stream beside the samplers, like the feature gather
             noise_dst.copy_(noise_src)
     torch.cuda.synchronize()
@@ -60,6 +62,7 @@ for fanouts in ([5, 5, 5], [10, 5]) if walk else ([25, 10], [5, 10, 15]):
     for b in range(nb):
         want = oracle.do_sample(ocode, ip, ix, seeds[b], fanouts, states, **okw)
         c = bs.counts_slots[b].cpu().tolist()
+        assert c[3 * L + 1] == 0, (fanouts, b, "batch status word", c[3 * L + 1])
         assert np.array_equal(u32(bs.input_nodes[b], c[3 * L]), want["input_nodes"]), (fanouts, b, "input_nodes")
         for i in range(L):
             wl = want["layers"][i]

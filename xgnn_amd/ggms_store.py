@@ -71,22 +71,39 @@ class PeerConnectError(RuntimeError):
     EVERY rank of the group with the failures of all of them, so the caller may decide together what to do."""
 
 
+class FailedShard:
+    """Stands in for a shard this rank could not build: connect_shared(FailedShard(reason), ...) takes part in the
+    handle exchange and the verdict and raises PeerConnectError on every rank, this one's reason included."""
+
+    def __init__(self, reason):
+        self.reason = str(reason)[:300]
+
+    def release_peers(self):
+        pass
+
+
 def connect_shared(shared_shard, world, rank, dist, group=None, what="shard"):
     """Publish this rank's shard (an ops.SharedShard) and map every peer's: DistGraph::_DataIpcShare
     (cuda/dist_graph.cu:274-307) over torch.distributed's byte channel.  Returns the shards' device addresses in this
     process, by rank.  Every wait on a peer has a deadline; an IPC call that FAILS on any rank raises PeerConnectError
     on EVERY rank (after closing the mappings that did open), so nobody is left waiting in the next collective."""
-    # the shard must be COMPLETE before a peer may read it: drain this device's queue before publishing (the
-    # fill kernels are asynchronous), and meet the peers again once everybody has mapped everybody (below)
-    if shared_shard.tensor.is_cuda:
-        torch.cuda.synchronize(shared_shard.tensor.device)
-    nbytes = int(np.prod(shared_shard.shape)) * shared_shard.tensor.element_size()
-    me = f"rank {rank} of {world} (device {shared_shard.tensor.device})"
-    failed = None
-    try:
-        mine = shared_shard.export_handle()
-    except Exception as e:  # noqa: BLE001 -- published as "no handle"; reported with the verdicts below
-        mine, failed = None, f"{me}: hipIpcGetMemHandle of its own {what} ({nbytes} bytes): {type(e).__name__}: {e}"
+    if isinstance(shared_shard, FailedShard):
+        # this rank could not even build its shard (out of memory, ...): it still walks through the same collectives --
+        # publishing "no handle" and its reason -- so that every rank gets the same verdict instead of waiting for it
+        me = f"rank {rank} of {world}"
+        nbytes, mine, failed = 0, None, f"{me}: could not build its {what}: {shared_shard.reason}"
+    else:
+        # the shard must be COMPLETE before a peer may read it: drain this device's queue before publishing (the
+        # fill kernels are asynchronous), and meet the peers again once everybody has mapped everybody (below)
+        if shared_shard.tensor.is_cuda:
+            torch.cuda.synchronize(shared_shard.tensor.device)
+        nbytes = int(np.prod(shared_shard.shape)) * shared_shard.tensor.element_size()
+        me = f"rank {rank} of {world} (device {shared_shard.tensor.device})"
+        failed = None
+        try:
+            mine = shared_shard.export_handle()
+        except Exception as e:  # noqa: BLE001 -- published as "no handle"; reported with the verdicts below
+            mine, failed = None, f"{me}: hipIpcGetMemHandle of its own {what} ({nbytes} bytes): {type(e).__name__}: {e}"
     if world == 1:
         handles = [(mine, nbytes)]
     else:
@@ -97,6 +114,8 @@ def connect_shared(shared_shard, world, rank, dist, group=None, what="shard"):
     ptrs = []
     try:
         for r in range(world):
+            if isinstance(shared_shard, FailedShard):
+                break
             if r == rank:
                 ptrs.append(shared_shard.ptr)
                 continue
