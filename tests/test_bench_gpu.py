@@ -95,7 +95,8 @@ def test_two_ranks_xgnn_mode_topology_shards_in_the_main_region():
     lines = []
     for extra in ([], ["--dist-graph", "0.5"]):
         r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--preset", "tiny", "--steps", "4",
-                            "--warmup", "1", "--batch", "512", "--other-stores", "", "--no-engine", "--no-sampler-roofline"]
+                            "--warmup", "1", "--batch", "512", "--other-stores", "", "--no-engine", "--no-sampler-roofline",
+                            "--repeats", "1", "--no-xgnn-mode"]  # one block: the line reports exactly these batches
                            + extra, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
         assert r.returncode == 0, r.stderr[-3000:]
         lines.append(_last_json(r.stdout))
