@@ -85,6 +85,8 @@ def parse():
                          "khop0, whose generator is re-seeded per launch -- its batches do not have to consume a shared "
                          "generator pool in order, so a second one in flight fills the first one's latency chains "
                          "(profiles/r03_ab_pipelines_products.txt)")
+    ap.add_argument("--slots", type=int, default=0,
+                    help="batch slots (a batch's outputs stay valid until its extract is done); default pipelines + 1")
     ap.add_argument("--heavy-after-gather", action="store_true",
                     help="the last (largest) layer's sampler launch of batch k+1 waits for the gather of batch k: the two "
                          "fabric-heaviest kernels run one after the other, the smaller layers still overlap the gather")
@@ -585,7 +587,7 @@ def main():
     if args.pipelines is None:
         args.pipelines = 2 if args.sample_type == "khop0" else 1
     K = 1 if args.no_overlap else max(1, args.pipelines)
-    NSLOT = K + 1
+    NSLOT = args.slots if args.slots else K + 1
     sampler = ops.BatchSampler(g, fanouts, args.batch, sample_type=code, seed=0x5EED + rank, device=dev,
                                num_slots=NSLOT, num_pipelines=K, **extra_kw)
     out = [torch.empty((sampler.max_unique, dim), dtype=torch.float32, device=dev) for _ in range(NSLOT)]

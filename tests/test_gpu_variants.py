@@ -159,6 +159,23 @@ def test_distinct_seed_promise_gives_the_oracles_batch(ops, stype, fanouts, nsee
     assert ops.device_status() == 0
 
 
+def test_distinct_seeds_beyond_one_tile_per_workgroup(ops):
+    """khop3 enters distinct seeds inside the first layer's launch only while every tile has a workgroup of its own
+    (<= 2048 tiles = 262144 seeds); a larger first layer takes the one-launch k_seed_enter + the ticketed layer kernel.
+    300 000 distinct seeds: the oracle's batch."""
+    ip, ix = powerlaw_csr(400_000, mean_deg=6, seed=12)
+    g = ops.DeviceGraph(P_dev(ip), P_dev(ix))
+    fanouts, nseed = [3, 2], 300_000
+    bs = ops.BatchSampler(g, fanouts, nseed, sample_type=ops.KHOP3, seed=21)
+    st = oracle.random_states(bs.states.shape[0], 21)
+    rng = np.random.RandomState(5)
+    for rep in range(2):
+        seeds = rng.permutation(400_000)[:nseed].astype(np.uint32)
+        bs.sample(P_dev(seeds), distinct=True)
+        _batch_equal(bs.result(), oracle.do_sample(oracle.KHOP3, ip, ix, seeds, fanouts, st), 2)
+    assert ops.device_status() == 0
+
+
 def test_distinct_seed_batches_in_flight(ops):
     """Three pipelines, seven batches, every one with the distinct-seed promise: batch order on the RNG pool holds and
     every batch equals the one-at-a-time loop's (each pipeline's prologue rides on its own first-layer launch)."""

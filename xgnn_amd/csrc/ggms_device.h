@@ -99,7 +99,7 @@ struct PtrSet {
   T *p[N];
   __device__ __forceinline__ T *pick(uint32_t k) const {
     T *r = p[0];
-#pragma unroll
+#pragma unroll 1 // one scalar load + one select per round: the N pointers need not sit in SGPRs all at once
     for (uint32_t i = 1; i < N; ++i) r = (k == i) ? p[i] : r;
     return r;
   }
@@ -240,11 +240,17 @@ struct IdxMap {
                             // arr[0] == NULL: the seeds are distinct, local id = position
   uint32_t n;
   __device__ __forceinline__ uint32_t local_of(uint32_t idx) const {
-    uint32_t s = 0;
-#pragma unroll
-    for (uint32_t k = 1; k < 17; ++k) s = (k < n && idx >= base[k]) ? k : s;
-    const uint32_t *a = arr[s];
-    const uint32_t off = idx - base[s];
+    // n - 1 <= L rounds (uniform trip count) of scalar loads from the kernel arguments + per-lane selects: the 34 words
+    // of the two arrays are not all kept in SGPRs (the fused sampler spills SGPRs as it is)
+    uint32_t b = base[0];
+    const uint32_t *a = arr[0];
+#pragma unroll 1
+    for (uint32_t k = 1; k < n; ++k) {
+      const bool ge = idx >= base[k];
+      b = ge ? base[k] : b;
+      a = ge ? arr[k] : a;
+    }
+    const uint32_t off = idx - b;
     return a ? a[off] : off;
   }
 };

@@ -110,7 +110,7 @@ struct Khop3TileHelp {
 // arrives; if a neighbour instance of this launch got there first the seed tells it so through `lost`, exactly as any
 // smaller arrival does (DedupInsert) -- the owner scan and the end-of-batch look-ups need nothing new.
 template <int GPW, bool INSERT, bool FIRST>
-__global__ __launch_bounds__(128 * (4 / GPW)) void k_khop3_fused(GraphView g, const uint32_t *__restrict__ input,
+__global__ __launch_bounds__(128 * (4 / GPW), 6) void k_khop3_fused(GraphView g, const uint32_t *__restrict__ input,
                                                                  Count n_arg, uint32_t fanout, uint32_t fanout_magic,
                                                                  uint32_t *__restrict__ out_src,
                                                                  uint32_t *__restrict__ out_dst, SrcMode sm,
