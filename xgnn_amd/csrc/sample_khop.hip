@@ -77,9 +77,12 @@ __device__ __forceinline__ uint32_t row_shr(uint32_t v) {
 }
 
 // Only seeds with more neighbours than `fanout` enter the serial loop; the "take them all" seeds consume no
-// draws.  GPW = groups per wave64: 4 packs the lanes (large frontiers: the loop is issue-bound), 1 gives every
-// group a wave of its own (small frontiers: the chip has idle SIMDs and a group no longer waits for its three
-// neighbours); the idle lanes of a sparse wave still work in phase 5.
+// draws.  GPW = groups per wave64: 1 gives every group a wave of its own (small frontiers: the chip has idle SIMDs and
+// a group does not wait for a neighbour), 2 beyond 256 tiles; the idle lanes of a sparse wave still work in phase 5.
+// Registers: the kernel is held at 79 VGPRs (6 waves per SIMD, __launch_bounds__'s second argument; 8 waves would
+// spill) and its look-ups into argument arrays (IdxMap, PtrSet) are short runtime loops, not unrolled selects -- the
+// 16-way unrolled form kept 34 argument words live and made the kernel spill 122 SGPRs
+// (profiles/r04_ab_vs_r03_same_box.txt, r04_ab_khop3_waves_per_simd.txt).
 // what tile t's descriptor holds -- the edges its 128 seeds will produce -- computed by one wave from the kernel's input
 // (scan_lookback's Help: a look-back that has waited long enough no longer depends on tile t's workgroup running)
 struct Khop3TileHelp {
