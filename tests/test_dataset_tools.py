@@ -126,3 +126,21 @@ def test_num_cache_node_rule_matches_the_oracle():
     ip, _ = powerlaw_csr(5000, mean_deg=12, seed=3)
     for f in (0.0, 1e-9, 0.1, 0.5, 0.64, 0.999, 1.0):
         assert ggms_store.num_cache_node_for(ip, f) == oracle.num_cache_node(ip, f), f
+
+
+def test_launch_constant_divisor_arithmetic():
+    """ggms_device.h Divisor: v / d and v % d as one multiply-high by floor(2^32 / d) (d = 1: 2^32 - 1) and ONE fix-up.
+    The same arithmetic in exact integers, for every shard count the kernels carry and a spread of others, on the edges
+    of the 32-bit range and on random ids: the claim "q' is q or q - 1" that the kernels rely on."""
+    import numpy as np
+    rng = np.random.RandomState(0)
+    v = np.concatenate([np.arange(0, 4096, dtype=np.uint64), (1 << 32) - 1 - np.arange(0, 4096, dtype=np.uint64),
+                        rng.randint(0, 1 << 32, size=2_000_000, dtype=np.uint64)])
+    for d in list(range(1, 65)) + [100, 1000, 65535, 65536, 65537, (1 << 31) - 1, 1 << 31, (1 << 32) - 1]:
+        magic = np.uint64(0xFFFFFFFF if d <= 1 else (1 << 32) // d)
+        q = (v * magic) >> np.uint64(32)
+        r = v - q * np.uint64(d)
+        assert (r < np.uint64(2 * d)).all(), d          # one fix-up is enough
+        up = r >= np.uint64(d)
+        q, r = q + up.astype(np.uint64), r - up.astype(np.uint64) * np.uint64(d)
+        assert np.array_equal(q, v // np.uint64(d)) and np.array_equal(r, v % np.uint64(d)), d
