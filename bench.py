@@ -887,7 +887,10 @@ def main():
         }
         if stores_main is not None:
             res["stores"] = stores_main
-        print(json.dumps(res), flush=True)  # the headline; the enriched line follows (last line wins)
+        # N > 1: the headline goes to stdout NOW and the enriched line follows (the last line wins) -- the multi-GPU
+        # run is the one whose sub-records (stores, engine child with a minute of start-up) can be slow or stuck under a
+        # limit somebody else set.  N = 1 keeps the contract's ONE line on stdout; its early headline goes to stderr.
+        print(json.dumps(res), flush=True, file=(sys.stdout if world > 1 else sys.stderr))
 
     # ---- sub-records: one wall-clock budget for all of them; what no longer fits is skipped and says so -------------
     size_factor = max(0.02, meta["num_edge"] / 1.6e9)  # the default workload = 1

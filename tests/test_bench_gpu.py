@@ -49,10 +49,11 @@ def test_single_gpu_line():
 
 
 def test_headline_is_out_before_the_sub_records_and_the_budget_bounds_them():
-    """The headline line is printed as soon as the main region is measured; the optional sub-records share one wall-clock
-    budget.  Here the engine child never finishes (test hook) and the budget is short: the run still ends with rc 0
-    inside the budget (+ the interpreter's start-up), the first line is a complete headline, the last one carries
-    `engine.error`, and what no longer fitted says `skipped: budget`."""
+    """The headline line is out as soon as the main region is measured (stdout at N > 1, stderr at N = 1, where stdout keeps
+    the contract's single line); the optional sub-records share one wall-clock budget.  Here the engine child never
+    finishes (test hook) and the budget is short: the run still ends with rc 0 inside the budget (+ the interpreter's
+    start-up), the early line is a complete headline, the final one carries `engine.error`, and what no longer fitted
+    says `skipped: budget`."""
     import time
     env = dict(os.environ, GGMS_BENCH_TEST_ENGINE_SLEEP="600")
     t0 = time.time()
@@ -62,8 +63,10 @@ def test_headline_is_out_before_the_sub_records_and_the_budget_bounds_them():
     wall = time.time() - t0
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [json.loads(l) for l in r.stdout.strip().splitlines() if l.startswith("{")]
-    assert len(lines) == 2 and wall < 45 + 30, (len(lines), wall)
-    first, last = lines
+    early = [json.loads(l) for l in r.stderr.strip().splitlines() if l.startswith("{")]
+    # N = 1: ONE line on stdout (the contract), the early headline on stderr; N > 1 prints both on stdout, last line wins
+    assert len(lines) == 1 and len(early) == 1 and wall < 45 + 30, (len(lines), len(early), wall)
+    first, last = early[0], lines[0]
     assert KEYS <= set(first) and first["rows_verified"] and "engine" not in first and first["value"] == last["value"]
     assert first["budget"]["headline_at_s"] < 45
     assert "error" in last["engine"] and "budget" in last["engine"]["error"]
@@ -118,6 +121,7 @@ def test_two_ranks_default_is_the_planned_placement():
                        capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
     assert r.returncode == 0, r.stderr[-3000:]
     d = _last_json(r.stdout)
+    assert len([l for l in r.stdout.splitlines() if l.startswith("{")]) == 2  # N > 1: headline first, enriched line last
     assert KEYS <= set(d) and d["n_gpus"] == 2 and "feature store: hybrid" in d["config"]["workload"]
     assert "48-GB per-GPU budget" in d["config"]["workload"]
     st = d["stores"]
