@@ -54,6 +54,12 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-tier", action="store_true", help="skip the cache_ratio 0 sub-record (configs[2])")
     ap.add_argument("--no-engine", action="store_true", help="skip the `engine` sub-record (samgraph.torch surface, child process)")
+    ap.add_argument("--no-configs", action="store_true",
+                    help="N = 1: skip the `configs` sub-record (the other single-GPU BASELINE configurations, each one block "
+                         "of this script in a child process: products GraphSAGE [25,10] = configs[1], Friendster-scale PinSAGE)")
+    ap.add_argument("--no-staged-host", action="store_true",
+                    help="N = 1: skip `host_tier.staged` (cache 0 / 0.64 through the engine's host-staged path, gpu_extract off)")
+    ap.add_argument("--no-xgmi-probe", action="store_true", help="N > 1: skip the `xgmi` sub-record (link probe)")
     ap.add_argument("--engine-timeout", type=float, default=300.0,
                     help="upper bound of the engine child's run time; the wall-clock budget may leave it less")
     ap.add_argument("--budget-s", type=float, default=400.0,
@@ -278,61 +284,88 @@ def scratch_dir(need_bytes, prefix):
     return tempfile.mkdtemp(prefix=prefix)
 
 
-def engine_record(datagen, graph, fanouts, args, log, workers=0, force_device=None, replicate=0.0, timeout=None,
-                  dist_graph=0.0):
+class DatasetDir:
+    """The run's graph in the reference's on-disk format (without feat.bin / label.bin: the loader then maps zero-filled
+    tables, engine.cc:LoadDataset), written ONCE on first use -- the engine children of several sub-records share it."""
+
+    def __init__(self, datagen, graph, log):
+        self.datagen, self.graph, self.log, self.dir = datagen, graph, log, None
+
+    def path(self):
+        if self.dir is None:
+            g = self.graph
+            self.dir = scratch_dir(g["indptr"].nbytes + g["indices"].nbytes + 8 * g["indptr"].size, "ggms_bench_ds_")
+            t0 = time.perf_counter()
+            self.datagen.write_dataset(self.dir, g, minimal=True)
+            self.log(f"engine: dataset written in {time.perf_counter() - t0:.1f} s")
+        return self.dir
+
+    def close(self):
+        if self.dir is not None:
+            import shutil
+            shutil.rmtree(self.dir, ignore_errors=True)
+            self.dir = None
+
+
+def child_json(cmd, timeout, env=None, what="child"):
+    """Run a child process under a timeout; -> its last JSON line, or {"error": ...} (a failure is recorded, never
+    propagated: a sub-record must not cost the line its headline)."""
+    import subprocess
+    env = dict(os.environ if env is None else env)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "GROUP_RANK", "ROLE_RANK", "LOCAL_WORLD_SIZE"):
+        env.pop(k, None)  # the child is not a rank of this job
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env)
+    except subprocess.TimeoutExpired:
+        return {"error": f"{what} exceeded the {timeout:.0f} s the wall-clock budget left it (--budget-s)"}
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    if r.returncode != 0 or not lines:
+        err = [l for l in r.stderr.splitlines() if "FATAL" in l or "Error" in l or "error" in l or "failed" in l]
+        return {"error": f"{what} rc {r.returncode}: " + (" | ".join(err[:3]) if err else r.stderr[-300:])[:600]}
+    try:
+        return json.loads(lines[-1])
+    except ValueError as e:
+        return {"error": f"{what}: unparsable line ({e})"}
+
+
+def engine_record(ds, fanouts, args, log, workers=0, force_device=None, replicate=0.0, timeout=None, dist_graph=0.0):
     """The same workload through the operator surface north_star names (samgraph.torch: config / init / sample_once /
     get_next_batch) in a CHILD process: the graph is written in the reference's on-disk format without feat.bin /
     label.bin (the loader then maps zero-filled tables, engine.cc:199-235 -- topology and sizes are the real ones), one
     warm-up epoch, one reported epoch; rates from the reference's own log items (tools/engine_epoch.py).
     workers > 0: the multi-GPU deployment (arch6) -- the child forks one engine worker per GPU, feature shards across
     the workers' GPUs behind hipIpc (part_cache + gpu_extract), every worker samples its slice of the epoch."""
-    import shutil
-    import subprocess
-    import tempfile
-    d = scratch_dir(graph["indptr"].nbytes + graph["indices"].nbytes + 8 * graph["indptr"].size, "ggms_bench_ds_")
-    try:
-        t0 = time.perf_counter()
-        datagen.write_dataset(d, graph, minimal=True)
-        log(f"engine: dataset written in {time.perf_counter() - t0:.1f} s")
-        env = dict(os.environ)
-        env.setdefault("SAMGRAPH_IPC_TIMEOUT_S", "90")  # a worker that cannot reach its peers ends the child, not the bench
-        for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):  # the child is not a rank of this job
-            env.pop(k, None)
-        if force_device is not None:  # one-GPU rehearsal: every engine worker on that device
-            env["SAMGRAPH_FORCE_DEVICE"] = str(force_device)
-        timeout = args.engine_timeout if timeout is None else timeout
-        cmd = ([sys.executable, os.path.join(ROOT, "tools", "engine_epoch.py"), d, "--fanout"] + [str(f) for f in fanouts]
-               + ["--batch-size", str(args.batch), "--sample-type", args.sample_type, "--cache-percentage", "1.0"]
-               + (["--arch6", str(workers), "--replicate-percentage", f"{replicate:.6f}"] if workers else [])
-               + (["--use-dist-graph", f"{dist_graph:.6f}"] if workers and dist_graph else []))
-        if os.environ.get("GGMS_BENCH_TEST_ENGINE_SLEEP"):  # test hook: a child that outlives whatever it is given
-            cmd = [sys.executable, "-c", f"import time; time.sleep({float(os.environ['GGMS_BENCH_TEST_ENGINE_SLEEP'])})"]
-        r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env)
-        lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
-        if r.returncode != 0 or not lines:
-            err = [l for l in r.stderr.splitlines() if "FATAL" in l or "Error" in l or "error" in l or "failed" in l]
-            return {"error": f"engine child rc {r.returncode}: " + (" | ".join(err[:3]) if err else r.stderr[-300:])[:600]}
-        e = json.loads(lines[-1])
-        e["surface"] = ("samgraph.torch config / init / sample_once / get_next_batch (arch1, cache_percentage 1.0) on the "
-                        "same graph written to disk in the reference's format, zero-filled feature table; second epoch; "
-                        "sample_edges_per_s and feature_GBps from kLogEpochNumSample / kLogEpochSampleTime and "
-                        "kLogEpochFeatureBytes / kLogEpochCopyTime" if not workers else
-                        f"samgraph.torch arch6: data_init in the parent, {workers} forked workers (sample_init / train_init / "
-                        "sample_once / get_next_batch), feature table sharded over the workers' GPUs (part_cache, gpu_extract, "
-                        "hipIpc peers"
-                        + (f"; the {replicate:.2f} hottest of the rows on every GPU (replicate_percentage), the rest sharded"
-                           if replicate else "")
-                        + "), "
-                        + (f"topology sharded over the workers' GPUs (use_dist_graph {dist_graph:g}: the leading nodes holding "
-                           "that fraction of the edges, peers over hipIpc; the rest from the whole CSR in registered host "
-                           "memory)" if dist_graph else "whole CSR on every GPU")
-                        + "; second epoch, the slowest worker's wall time; rates summed "
-                        "over the workers from the reference's log items")
+    d = ds.path()
+    env = dict(os.environ)
+    env.setdefault("SAMGRAPH_IPC_TIMEOUT_S", "90")  # a worker that cannot reach its peers ends the child, not the bench
+    if force_device is not None:  # one-GPU rehearsal: every engine worker on that device
+        env["SAMGRAPH_FORCE_DEVICE"] = str(force_device)
+    timeout = args.engine_timeout if timeout is None else timeout
+    cmd = ([sys.executable, os.path.join(ROOT, "tools", "engine_epoch.py"), d, "--fanout"] + [str(f) for f in fanouts]
+           + ["--batch-size", str(args.batch), "--sample-type", args.sample_type, "--cache-percentage", "1.0"]
+           + (["--arch6", str(workers), "--replicate-percentage", f"{replicate:.6f}"] if workers else [])
+           + (["--use-dist-graph", f"{dist_graph:.6f}"] if workers and dist_graph else []))
+    if os.environ.get("GGMS_BENCH_TEST_ENGINE_SLEEP"):  # test hook: a child that outlives whatever it is given
+        cmd = [sys.executable, "-c", f"import time; time.sleep({float(os.environ['GGMS_BENCH_TEST_ENGINE_SLEEP'])})"]
+    e = child_json(cmd, timeout, env, what="engine child")
+    if "error" in e:
         return e
-    except subprocess.TimeoutExpired:
-        return {"error": f"engine child exceeded the {timeout:.0f} s the wall-clock budget left it (--budget-s, --engine-timeout)"}
-    finally:
-        shutil.rmtree(d, ignore_errors=True)
+    e["surface"] = ("samgraph.torch config / init / sample_once / get_next_batch (arch1, cache_percentage 1.0) on the "
+                    "same graph written to disk in the reference's format, zero-filled feature table; second epoch; "
+                    "sample_edges_per_s and feature_GBps from kLogEpochNumSample / kLogEpochSampleTime and "
+                    "kLogEpochFeatureBytes / kLogEpochCopyTime" if not workers else
+                    f"samgraph.torch arch6: data_init in the parent, {workers} forked workers (sample_init / train_init / "
+                    "sample_once / get_next_batch), feature table sharded over the workers' GPUs (part_cache, gpu_extract, "
+                    "hipIpc peers"
+                    + (f"; the {replicate:.2f} hottest of the rows on every GPU (replicate_percentage), the rest sharded"
+                       if replicate else "")
+                    + "), "
+                    + (f"topology sharded over the workers' GPUs (use_dist_graph {dist_graph:g}: the leading nodes holding "
+                       "that fraction of the edges, peers over hipIpc; the rest from the whole CSR in registered host "
+                       "memory)" if dist_graph else "whole CSR on every GPU")
+                    + "; second epoch, the slowest worker's wall time; rates summed "
+                    "over the workers from the reference's log items")
+    return e
 
 
 def shared_graph(datagen, args, world, local_rank, dist):
@@ -399,6 +432,16 @@ def main():
     dev = torch.device("cuda", dev_index)
 
     from xgnn_amd import datagen, ggms_store, ops, parallel
+
+    # ---- N > 1, before anything is placed: can every GPU of the group reach every other (hipDeviceCanAccessPeer per pair,
+    # PartitionSolver::DetectTopo_child, cuda/dist_graph.cu:812-818)?  Every rank holds the same matrix and takes the same
+    # turn: the sharded stores need it, whole-table replicas do not.
+    preflight = None
+    if world > 1:
+        preflight = ggms_store.peer_access_preflight(world, rank, dist, dev_index, ggms_store.HipProbeLeaf(dev))
+        if preflight["refused"] and args.dist_graph is not None:
+            raise SystemExit(f"bench.py: --dist-graph needs P2P access between every pair of GPUs; refused [reader, owner]: "
+                             f"{preflight['refused']}")
 
     t_start = time.perf_counter()
     if os.environ.get("GGMS_BENCH_VERBOSE"):  # where is a stuck rank?  Python stacks every 2 minutes
@@ -725,6 +768,9 @@ def main():
     repeats = max(1, args.repeats)
     store_requested, store_error = main_store, None
     try:
+        if preflight and preflight["refused"] and main_store in ("peer", "hybrid"):
+            raise ggms_store.PeerConnectError("hipDeviceCanAccessPeer refuses [reader, owner] " + str(preflight["refused"])
+                                              + ": the sharded stores dereference peer HBM in place")
         extract_main, keep_main = build_store(main_store)
     except ggms_store.PeerConnectError as e:
         # a shard could not be exported / mapped on this node (every rank sees the same verdict and takes the same
@@ -806,6 +852,30 @@ def main():
                   "shards over xGMI)",
         "a2a": "k_gather_rows<16-B chunks, PlainRows> at the owner + RCCL all-to-all of ids and rows",
     }[main_store]
+    # ---- what THIS box sustains (boxes of one pool differ by a few per cent; the line carries its own yardstick):
+    # a device-to-device copy (read + write bytes per second, the guide's 6.29 TB/s figure) and a pinned H2D copy
+    box = None
+    if rank == 0:
+        import ctypes as C
+        from xgnn_amd import lib as _lib
+        n_copy = 1 << 30
+        a_buf = torch.empty(n_copy, dtype=torch.uint8, device=dev)
+        b_buf = torch.zeros(n_copy, dtype=torch.uint8, device=dev)
+        rate = C.c_double(0)
+        rc = _lib().ggms_link_probe_copy(C.c_void_p(a_buf.data_ptr()), C.c_void_p(b_buf.data_ptr()), n_copy, 5, C.byref(rate),
+                                         C.c_void_p(torch.cuda.current_stream().cuda_stream))
+        d2d = 2.0 * rate.value if rc == 0 else None
+        n_pin = 256 << 20
+        h_buf = torch.empty(n_pin, dtype=torch.uint8, pin_memory=True)
+        rc = _lib().ggms_link_probe_copy(C.c_void_p(a_buf.data_ptr()), C.c_void_p(h_buf.data_ptr()), n_pin, 3, C.byref(rate),
+                                         C.c_void_p(torch.cuda.current_stream().cuda_stream))
+        h2d = rate.value if rc == 0 else None
+        del a_buf, b_buf, h_buf
+        box = {"d2d_copy_GBps": d2d, "pinned_h2d_GBps": h2d,
+               "what": "hipMemcpyAsync of 1 GiB device to device (bytes read + written per second; the guide's MI355X figure "
+                       "is 6290) and of 256 MiB from hipHostMalloc memory; atomics_per_s / loads_per_s are added by the "
+                       "sampler roofline's probe",
+               "d2d_over_guide": d2d / 6290.0 if d2d else None}
     res = None
     if rank == 0:
         ext_s = blk["t_extract_ms"] / 1e3
@@ -872,6 +942,10 @@ def main():
                 # the READ side alone, rows * (dim * 4 + 4) / t / 8e12 (a gather also writes every byte
                 # it reads, so this figure cannot exceed half of what the memory system sustains)
                 "hbm_read_frac": rows / args.steps * (row_bytes + 4) / avg_launch_s / 8e12,
+                # north_star's target is stated on this read-only figure; a gather writes every byte it reads, so the
+                # figure cannot pass HALF of what a device-to-device copy sustains on the box (guide: 6.29 of 8 TB/s)
+                "hbm_read_frac_target": 0.60,
+                "hbm_read_frac_ceiling_for_a_copy": (box["d2d_copy_GBps"] / 2 / 8000.0) if box and box["d2d_copy_GBps"] else 0.393,
                 # same launch with nothing beside it: in the pipeline the gather shares HBM with the sampling kernels
                 "frac_alone": None if serial_us is None else
                 serial_rows * (4 + 2 * row_bytes) / (serial_us * 1e-6) / 1e9 / 8000.0,
@@ -883,8 +957,16 @@ def main():
                 "traffic_source": (tr["source"] + (" (stale: extract.hip changed since; traffic nulled)" if tr["stale"] else
                                                    f" @ extract.hip sha256 {tr['extract_hip_sha256'][:12]}")) if tr else None,
             },
+            "box": box,
+            # the headline normalised by the box's own copy rate against the guide's figure: comparable across boxes
+            "value_over_box": (edges_all / elapsed) / box["d2d_over_guide"] if box and box["d2d_over_guide"] else None,
             "budget": {"budget_s": args.budget_s, "headline_at_s": round(time.perf_counter() - T0, 1)},
         }
+        if preflight is not None:
+            res["peer_access"] = {"devices": preflight["devices"], "can_access": preflight["can_access"],
+                                  "refused": preflight["refused"],
+                                  "what": "hipDeviceCanAccessPeer [reader][owner], asked by every rank for its own row "
+                                          "before anything was placed (ranks sharing a device reach each other)"}
         if stores_main is not None:
             res["stores"] = stores_main
         # N > 1: the headline goes to stdout NOW and the enriched line follows (the last line wins) -- the multi-GPU
@@ -908,6 +990,35 @@ def main():
         log(f"sub-record {name}: {'runs' if ok[0] else 'skipped (budget)'}, {left():.0f} s left")
         return ok[0]
 
+    # ---- N > 1: what the xGMI links carry, measured the way the stores use them (ggms_store.link_probe) ---------------
+    # and next to every sharded store's xgmi bytes the remote time they predict: bytes per GPU and step / inbound rate
+    xgmi = None
+    if world > 1 and not args.no_xgmi_probe and fits("xgmi", 6 + 0.15 * world * world):
+        try:
+            xgmi = ggms_store.link_probe(world, rank, dist, ggms_store.HipProbeLeaf(dev))
+        except (RuntimeError, MemoryError) as e:  # PeerConnectError: raised on every rank alike
+            xgmi = {"error": f"{type(e).__name__}: {str(e)[:300]}"}
+        if res is not None:
+            res["xgmi"] = xgmi
+
+    def predict_remote(rec):
+        """stores.<kind> + the probe: xgmi bytes one GPU pulls per step over the rate its inbound links sustained when every
+        rank pulled from all its peers at once -> the time the remote rows alone need (they overlap the local rows
+        inside one gather kernel: the step cannot be shorter than this, and need not be longer than local + this)."""
+        if not isinstance(rec, dict) or "xgmi_bytes_per_step" not in rec:
+            return rec
+        per_gpu = rec["xgmi_bytes_per_step"] / world
+        rec["xgmi_bytes_per_step_per_gpu"] = per_gpu
+        inbound = (xgmi or {}).get("inbound_all_peers_min_GBps")
+        if inbound:
+            rec["predicted_remote_ms_per_step"] = per_gpu / (inbound * 1e9) * 1e3
+            rec["predicted_remote_formula"] = "xgmi_bytes_per_step / n_gpus / xgmi.inbound_all_peers_min_GBps"
+        return rec
+
+    if res is not None and "stores" in res:
+        for k in list(res["stores"]):
+            res["stores"][k] = predict_remote(res["stores"][k])
+
     # ---- N > 1: the same store with the TOPOLOGY sharded too (XGNN mode, use_dist_graph 1.0), one block -------------
     # The main region keeps the whole CSR on every GPU (6.9 GB of 288: the MI355X-first placement); this block is the
     # reference's defining configuration beside it: rank r keeps topology shard r, every list head and neighbour read of
@@ -919,7 +1030,7 @@ def main():
             sampler = ops.BatchSampler(topo.graph, fanouts, args.batch, sample_type=code, seed=0x5EED + rank, device=dev,
                                        num_slots=NSLOT, num_pipelines=K, **extra_kw)
             bx, next_step = measure(extract_main, args.steps, 2, 1, first_step=next_step)
-            rec = {**store_record(bx[0], main_store), "use_dist_graph": 1.0,
+            rec = {**predict_remote(store_record(bx[0], main_store)), "use_dist_graph": 1.0,
                    "what": f"one block of the main region's workload with the topology in {world} shards, one per GPU "
                            "(node v in shard v % N at row v / N, DeviceDistGraph): peers' list heads and neighbour lists "
                            "read in-kernel over xGMI through hipIpc mappings; feature store as in the main region",
@@ -979,6 +1090,9 @@ def main():
             torch.cuda.synchronize()
             probe[name + "s_per_s"] = reqs / (p0.elapsed_time(p1) / 4 / 1e3)
         del ptab
+        if res is not None and res.get("box"):
+            res["box"].update(atomics_per_s=probe["atomics_per_s"], loads_per_s=probe["loads_per_s"],
+                              load_atomic_pairs_per_s=probe["load_atomic_pairs_per_s"])
         if res is not None:
             E_step, S_step = edges / args.steps, blk["inputs"] / args.steps
             algo = 12 * S_step + 28 * E_step  # per seed id + indptr pair; per edge neighbour + bucket + COO
@@ -1043,10 +1157,11 @@ def main():
             except (RuntimeError, MemoryError) as e:  # PeerConnectError is one: raised on every rank alike
                 rec = {"error": f"{type(e).__name__}: {str(e)[:200]}"}
             if res is not None:
-                res["stores"][kind] = rec
+                res["stores"][kind] = predict_remote(rec)
             gc.collect()
             torch.cuda.empty_cache()
 
+    ds_dir = DatasetDir(datagen, graph, log)  # written on first use, shared by the engine children below
     # ---- the same workload through the samgraph.torch surface (child process): arch1 at N = 1, arch6 with N workers ----
     if full and not args.no_engine and args.sample_type.startswith("khop"):
         need = (12 + 25 * size_factor) if world == 1 else (25 + 45 * size_factor + 8 * world * size_factor)
@@ -1055,7 +1170,7 @@ def main():
             child_timeout = max(5.0, min(args.engine_timeout, left() - 10.0))
             engine = None
             if world == 1:
-                engine = engine_record(datagen, graph, fanouts, args, log, timeout=child_timeout)
+                engine = engine_record(ds_dir, fanouts, args, log, timeout=child_timeout)
             else:  # rank 0 runs the child (which forks one engine worker per GPU), the other ranks wait
                 extract_main = keep_main = None  # the engine's workers build their own shards on these GPUs
                 import gc
@@ -1065,7 +1180,7 @@ def main():
                 if rank == 0:
                     # the same placement as the main region's: the planned hot prefix on every GPU (0 = pure shards);
                     # --dist-graph: the topology sharded over the workers' GPUs too (XGNN mode, use_dist_graph)
-                    engine = engine_record(datagen, graph, fanouts, args, log, workers=world,
+                    engine = engine_record(ds_dir, fanouts, args, log, workers=world,
                                            force_device=os.environ.get("GGMS_BENCH_DEVICE"),
                                            replicate=(main_plan.get("replicated_fraction", 0.0)
                                                       if main_store == "hybrid" else 0.0),
@@ -1087,6 +1202,72 @@ def main():
                     engine["vs_headline_edges_per_s"] = engine["edges_per_s"] / res["value"]
                 res["engine"] = engine
             log("engine sub-record done")
+
+    default_workload = (world == 1 and args.preset == "papers100M" and args.sample_type == "khop3" and full
+                        and not topo_record and not args.neighbour_skew and args.fanout == "5,10,15")
+    # test hook: treat this run as the default workload and run the `configs` children on this preset (small sizes)
+    test_configs = os.environ.get("GGMS_BENCH_TEST_CONFIGS")
+    if test_configs and world == 1 and full:
+        default_workload = True
+
+    # ---- N = 1: the other single-GPU configurations BASELINE.json names, one block of this script each (child process) ---
+    if default_workload and not args.no_configs:
+        me = [sys.executable, os.path.abspath(__file__), "--no-engine", "--no-host-tier", "--no-cpu-baseline",
+              "--no-sampler-roofline", "--no-configs", "--steps", str(args.steps), "--warmup", str(args.warmup),
+              "--repeats", str(repeats)]
+        res["configs"] = {}
+        for name, flags, need, what in (
+                ("products_graphsage_25_10", ["--preset", "products"], 12.0,
+                 "BASELINE configs[1]: ogbn-products-shaped CSR, GraphSAGE fanout [25,10], graph + features in HBM"),
+                ("friendster_pinsage_rw", ["--preset", "friendster", "--sample-type", "random_walk", "--fanout", "5,5,5"], 30.0,
+                 "BASELINE configs[4]'s workload on one GPU: Friendster-scale power-law CSR, 256-dim f32 rows, PinSAGE "
+                 "random walk (length 3, restart 0.5, 4 walks, top-5, 3 layers)"),
+                ("papers100M_graphsage_25_10", ["--fanout", "25,10"], 30.0,
+                 "BASELINE configs[3]'s workload on one GPU: papers100M-shaped CSR, GraphSAGE fanout [25,10]")):
+            if test_configs:
+                flags = (["--preset", test_configs, "--batch", str(args.batch)]
+                         + (["--sample-type", "random_walk", "--fanout", "5,5,5"] if "pinsage" in name else []))
+            if not fits(f"configs.{name}", need):
+                res["configs"][name] = res.pop(f"configs.{name}")
+                continue
+            r = child_json(me + flags, timeout=max(10.0, min(300.0, left() - 10.0)), what=f"bench.py {' '.join(flags)}")
+            if "error" not in r:
+                rf = r["roofline"]
+                r = {"what": what, "workload": r["config"]["workload"], "ms_per_step": r["ms_per_step"], "edges_per_s": r["value"],
+                     "feature_extract_GBps": r["feature_extract_GBps"], "gather_frac": rf["frac"],
+                     "gather_frac_alone": rf["frac_alone"], "rows_verified": r["rows_verified"],
+                     "edges_per_step": r["per_gpu"]["edges_per_step"], "rows_per_step": r["per_gpu"]["rows_per_step"],
+                     "spread": r["repeats"]["spread"]}
+            res["configs"][name] = r
+        log("configs sub-record done")
+
+    # ---- N = 1: BASELINE configs[2] the way the reference runs it -- the HOST-STAGED path (gpu_extract off): miss ids to
+    # the host, rows gathered by the host cores into pinned memory, copied down, scattered (dist_loops.cc:1015-1207,
+    # dist_loops_arch6.cc:111-133), through the engine in a child process; cache 0 (every row) and 0.64 (the README's
+    # quick-start cache).  Quoted against the only numbers the reference publishes for this path.
+    staged = None
+    if default_workload and not args.no_host_tier and not args.no_staged_host:
+        staged = {"reference_published": {"cpu_gather_GBps": [33.71, 60.21], "h2d_GBps": 23.33, "combine_miss_GBps": 619.77,
+                                          "source": "study/host-extract-speed-amount/data.dat:2-16 (papers100M, GraphSAGE "
+                                                    "2-hop, degree cache 1-40 %; 8 x V100 box, PCIe 3)"}}
+        for cache in (0.0, 0.64):
+            name = f"cache_{cache:g}"
+            if not fits(f"staged.{name}", 10 + 35 * size_factor):
+                staged[name] = res.pop(f"staged.{name}")
+                continue
+            env = dict(os.environ, SAMGRAPH_IPC_TIMEOUT_S="90")
+            n_ep = (len(train) + args.batch - 1) // args.batch  # batches of the (single) epoch the child has to spend
+            st_warm, st_serial, st_over = (3, 10, 20) if n_ep >= 36 else (1, max(1, (n_ep - 2) // 3), max(1, (n_ep - 2) // 3))
+            cmd = ([sys.executable, os.path.join(ROOT, "tools", "engine_epoch.py"), ds_dir.path(), "--staged-host", "--fanout"]
+                   + [str(f) for f in fanouts] + ["--batch-size", str(args.batch), "--cache-percentage", str(cache),
+                                                  "--staged-warm", str(st_warm), "--staged-steps", str(st_serial), str(st_over)])
+            r = child_json(cmd, timeout=max(10.0, min(300.0, left() - 10.0)), env=env, what="staged-host engine child")
+            if "error" not in r and r.get("serial") and r.get("overlapped"):
+                sr, ov = r["serial"], r["overlapped"]
+                bound = min(x for x in (sr["cpu_gather_GBps"], sr["h2d_GBps"]) if x)
+                ov["over_min_of_cpu_gather_and_h2d"] = ov["effective_GBps"] / bound
+            staged[name] = r
+        log("staged host tier done")
 
     # ---- N = 1: BASELINE configs[2], every row in pinned host DRAM (cache_ratio 0) -----------------------------
     cpu_feat = None
@@ -1124,6 +1305,11 @@ def main():
             "pinned_GiB": N * row_bytes / 2 ** 30, "pin_seconds": t_pin,
         }
         cpu_feat = hf.numpy()
+    if staged is not None:
+        if isinstance(res.get("host_tier"), dict):
+            res["host_tier"]["staged"] = staged
+        else:
+            res["host_tier_staged"] = staged
 
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline and fits("cpu_baseline", args.cpu_seconds * 1.3 + 3 + 25 * size_factor * (cpu_feat is None)):
@@ -1136,6 +1322,7 @@ def main():
             res["cpu_baseline"] = cpu_baseline(graph, fanouts, args.batch, cpu_feat, args.cpu_seconds)
         res["budget"]["finished_at_s"] = round(time.perf_counter() - T0, 1)
         print(json.dumps(res), flush=True)
+    ds_dir.close()
     if world > 1:
         dist.destroy_process_group()
 

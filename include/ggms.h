@@ -417,6 +417,15 @@ int ggms_get_miss_cache_index(const ggms_id_t *table, const ggms_id_t *nodes,
                               ggms_id_t *cache_dst_index,
                               uint64_t *num_cache_dev, void *workspace,
                               size_t workspace_bytes, ggms_stream_t stream);
+/* the same with the batch size left on the device (num_nodes = upper bound that sizes the launch and the
+ * workspace; num_nodes_dev NULL = num_nodes is exact): the split can be enqueued right behind the sampler. */
+int ggms_get_miss_cache_index_dev(const ggms_id_t *table, const ggms_id_t *nodes,
+                                  size_t num_nodes, const uint64_t *num_nodes_dev,
+                                  ggms_id_t *miss_src_index, ggms_id_t *miss_dst_index,
+                                  uint64_t *num_miss_dev, ggms_id_t *cache_src_index,
+                                  ggms_id_t *cache_dst_index, uint64_t *num_cache_dev,
+                                  void *workspace, size_t workspace_bytes,
+                                  ggms_stream_t stream);
 /* combine_cache_data :254-275, extract_miss_data :233-252, combine_miss_data
  * :209-231: out[dst_index[i], :] = src[src_index[i], :]; a NULL index means
  * the identity.  num may be overridden by a device count (num_dev != NULL;
@@ -496,6 +505,42 @@ int ggms_device_free(void *ptr);
 int ggms_ipc_export(const void *ptr, void *handle);
 int ggms_ipc_import(const void *handle, void **ptr);   /* peer HBM, read in-kernel over xGMI */
 int ggms_ipc_release(void *ptr);
+
+/* ---------------------------------------------------------------------------
+ * Link / topology probe -- PartitionSolver::DetectTopo, DetectTopo_child, LoadTopoFromFile
+ * (cuda/dist_graph.cu:684-726, 779-884, 886-938): P2P reachability of every GPU pair + one timed 128-MiB copy per
+ * reachable pair, kept in the text file the reference's solver reads ("GPU Count" / "P2P Matrix" / "Bandwidth Matrix";
+ * a file written by either implementation loads in the other).
+ *   ggms_detect_topology   for ONE process that sees every GPU (the engine's forked probe child): it creates a context
+ *                          on every device -- never call it from a bench rank or an engine worker.
+ *                          can_access[i][j] = hipDeviceCanAccessPeer(i, j), 1 on the diagonal; copy_GBps[i][j] = GB/s of
+ *                          a copy INTO device i FROM device j (diagonal: local copy, 2 x bytes, as the reference counts it).
+ *   ggms_peer_access       one pair, from a process that must not touch the peer device (no context is created on it).
+ *   ggms_link_probe_copy / _gather   what a rank of the one-process-per-GPU deployment measures on the hipIpc mappings
+ *                          it already holds: a timed copy out of a mapping, and the product's own gather kernel
+ *                          (ggms_gather_scatter_partition) reading random rows of it -- one part = one peer alone, all
+ *                          parts = the rank's whole inbound xGMI.  Unlike the operators above these two SYNCHRONISE the
+ *                          stream (they return a rate).
+ * ------------------------------------------------------------------------- */
+#define GGMS_TOPO_MAX_DEVICE 16
+typedef struct {
+  int32_t num_device;
+  int32_t _pad;
+  int32_t can_access[GGMS_TOPO_MAX_DEVICE][GGMS_TOPO_MAX_DEVICE];
+  double copy_GBps[GGMS_TOPO_MAX_DEVICE][GGMS_TOPO_MAX_DEVICE];
+} ggms_topology_t;
+int ggms_device_count(int *count);
+int ggms_peer_access(int device, int peer, int *can_access);
+int ggms_detect_topology(ggms_topology_t *topo, size_t probe_bytes /* 0 = 128 MiB */, int reps);
+int ggms_topology_write_host(const ggms_topology_t *topo, const char *path, const char *device_order);
+int ggms_topology_read_host(ggms_topology_t *topo, const char *path);
+int ggms_link_probe_copy(void *dst, const void *src, size_t bytes, int reps, double *GBps_host,
+                         ggms_stream_t stream);
+/* out: num_rows x row_bytes; parts: HOST array of num_part (<= GGMS_MAX_PARTS) base pointers, each holding
+ * rows_per_part rows; index_ws: num_rows ids of device scratch; row_bytes a multiple of 4. */
+int ggms_link_probe_gather(void *out, const void *const *parts, uint32_t num_part, size_t rows_per_part,
+                           size_t row_bytes, size_t num_rows, uint32_t seed, int reps, ggms_id_t *index_ws,
+                           double *GBps_host, ggms_stream_t stream);
 
 /* The exchange form of the remote gather: instead of dereferencing
  * peer pointers inside the gather kernel (ggms_extract_cached with num_part > 0),

@@ -48,6 +48,41 @@ def test_single_gpu_line():
     assert en["ms_per_step"] > 0 and en["edges_per_s"] > 0 and en["feature_GBps"] > 0 and en["steps"] == 8
 
 
+def test_single_gpu_line_carries_its_box_the_other_configs_and_the_staged_host_tier():
+    """the N = 1 line carries `box` (what this box sustains: the yardstick between boxes) and
+    `value_over_box`, the north_star read-fraction target next to the ceiling a copy can reach, a `configs` sub-record
+    (the other single-GPU BASELINE configurations, one child each -- here on the tiny preset through the test hook) and
+    `host_tier.staged` (the engine's host-staged path, cache 0 and 0.64: per-phase rates of the serial sequence, effective
+    rate of the chunked pipeline)."""
+    env = dict(os.environ, GGMS_BENCH_TEST_CONFIGS="tiny")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--preset", "tiny", "--steps", "4", "--warmup", "1",
+                        "--batch", "512", "--no-cpu-baseline", "--no-engine"], capture_output=True, text=True, timeout=900,
+                       cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = _last_json(r.stdout)
+    box = d["box"]
+    assert box["d2d_copy_GBps"] > 500 and box["pinned_h2d_GBps"] > 1 and box["atomics_per_s"] > 1e9 and box["loads_per_s"] > 1e9
+    assert abs(d["value_over_box"] - d["value"] / box["d2d_over_guide"]) < 1e-6 * d["value_over_box"]
+    rf = d["roofline"]
+    assert rf["hbm_read_frac_target"] == 0.60 and 0.2 < rf["hbm_read_frac_ceiling_for_a_copy"] < 0.5
+    cf = d["configs"]
+    assert set(cf) == {"products_graphsage_25_10", "friendster_pinsage_rw", "papers100M_graphsage_25_10"}
+    for name, c in cf.items():
+        assert "error" not in c, (name, c)
+        assert c["ms_per_step"] > 0 and c["edges_per_s"] > 0 and c["feature_extract_GBps"] > 0 and c["rows_verified"]
+        assert 0 < c["gather_frac"] < 1
+    assert "random_walk" in cf["friendster_pinsage_rw"]["workload"]
+    st = d["host_tier"]["staged"]
+    assert st["reference_published"]["h2d_GBps"] == 23.33
+    for name in ("cache_0", "cache_0.64"):
+        c = st[name]
+        assert "error" not in c, (name, c)
+        sr, ov = c["serial"], c["overlapped"]
+        assert sr["cpu_gather_GBps"] > 0 and sr["h2d_GBps"] > 0 and sr["effective_GBps"] > 0
+        assert (sr["combine_miss_GBps"] is None) == (name == "cache_0")  # no cache: rows land in the batch, nothing to scatter
+        assert ov["effective_GBps"] > 0 and ov["over_min_of_cpu_gather_and_h2d"] > 0 and ov["edges_per_s"] > 0
+
+
 def test_headline_is_out_before_the_sub_records_and_the_budget_bounds_them():
     """The headline line is out as soon as the main region is measured (stdout at N > 1, stderr at N = 1, where stdout keeps
     the contract's single line); the optional sub-records share one wall-clock budget.  Here the engine child never

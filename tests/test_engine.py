@@ -333,6 +333,12 @@ def test_arch1_feature_dtypes(tmp_path, dtype):
     # copied down asynchronously (dist_loops.cc:1076-1207), hits from the (partitioned) cache
     dict(cache_percentage="0.3"),
     dict(cache_percentage="0.3", part_cache="True", use_dist_graph="1.0"),
+    # the same path as the reference runs it -- one phase at a time, each behind its own wait (first epoch), then chunked
+    dict(cache_percentage="0.3", staged_serial_epochs="1"),
+    # cache 0 without gpu_extract (DoIdCopy + DoCPUFeatureExtract + DoFeatureCopy, dist_loops_arch6.cc:111-133):
+    # every row gathered by the host team, chunks copied straight into the batch
+    dict(cache_percentage="0"),
+    dict(cache_percentage="0", staged_serial_epochs="2"),
     # hybrid store: the hotter half of the cached slots on every GPU, the rest sharded (replica + shards + host rows
     # behind one gather, ggms_extract_tiered)
     dict(cache_percentage="0.4", part_cache="True", gpu_extract="True", use_dist_graph="1.0", replicate_percentage="0.5"),
@@ -343,7 +349,8 @@ def test_arch6_two_workers_one_gpu(tmp_path, opts):
     (both mapped onto the single GPU of the test box by SAMGRAPH_FORCE_DEVICE)."""
     d = make_dataset(tmp_path / "ds")
     prefix = str(tmp_path / "out")
-    env = dict(os.environ, SAMGRAPH_FORCE_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    # the host-staged path moves its miss rows in chunks: small ones here, so that a batch takes several
+    env = dict(os.environ, SAMGRAPH_FORCE_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0", SAMGRAPH_STAGED_CHUNK_ROWS="100")
     r = subprocess.run([sys.executable, DRIVER, d["path"], prefix, "arch6", "2", "seed=7", "batch_size=64",
                         "fanout=5 4"] + [f"{k}={v}" for k, v in opts.items()],
                        capture_output=True, text=True, timeout=900, env=env)
@@ -352,6 +359,9 @@ def test_arch6_two_workers_one_gpu(tmp_path, opts):
         want = _oracle_batches(d, w, 2, 64, 2, [5, 4], 7, arch6=True)
         npz = np.load(f"{prefix}.w{w}.npz")
         _check(npz, want, 2)
+        if float(opts["cache_percentage"]) == 0 and "gpu_extract" not in opts:  # host-staged, no cache: every row is a miss
+            for key, wv in want.items():
+                assert float(npz[f"{key}:miss_bytes"]) == wv["res"]["input_nodes"].size * d["feat"].shape[1] * 4
         if float(opts["cache_percentage"]) > 0:
             # misses are exactly the input nodes outside the cached prefix of the rank list
             from xgnn_amd import datagen
@@ -362,6 +372,29 @@ def test_arch6_two_workers_one_gpu(tmp_path, opts):
             for key, wv in want.items():
                 nmiss = int((~cached[wv["res"]["input_nodes"]]).sum())
                 assert float(npz[f"{key}:miss_bytes"]) == nmiss * d["feat"].shape[1] * 4
+
+
+@pytest.mark.gpu
+def test_arch6_padding_copies_in_one_batch_take_the_general_path(tmp_path):
+    """the engine promises distinct seeds to the sampler batch by batch (train set checked once, the padding
+    copies of the aligned epoch located per Reshuffle).  Here the promise must be WITHDRAWN: 100 train nodes over three
+    workers are padded with two copies (dist_shuffler_aligned.cc:52-54), a worker's whole slice of 34 is one batch, so
+    in some epochs both copies of a padding node are seeds of one batch -- those batches must come out as the oracle's
+    (duplicated seeds deduplicated by FillWithDupRevised), the others through the distinct-seed path."""
+    d = make_dataset(tmp_path / "ds", num_train=100)
+    prefix = str(tmp_path / "out")
+    W, epochs = 3, 8
+    env = dict(os.environ, SAMGRAPH_FORCE_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, DRIVER, d["path"], prefix, "arch6", str(W), "seed=7", "batch_size=64", "fanout=5 4",
+                        "cache_percentage=0.4", "part_cache=True", "gpu_extract=True", f"num_epoch={epochs}"],
+                       capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    both = 0
+    for w in range(W):
+        want = _oracle_batches(d, w, W, 64, epochs, [5, 4], 7, arch6=True)
+        _check(np.load(f"{prefix}.w{w}.npz"), want, 2)
+        both += sum(np.unique(v["seeds"]).size != v["seeds"].size for v in want.values())
+    assert both >= 1  # the case this test exists for did occur (the shuffle is seeded by the epoch number)
 
 
 @pytest.mark.gpu

@@ -211,3 +211,157 @@ def test_a_rank_that_cannot_build_its_shard_is_a_verdict_of_every_rank(tmp_path)
         assert p.returncode == 0, err[-1000:]
         assert "REFUSED" in out and "could not build its feature shard" in out and "28.4 GiB" in out
         assert "in step" in out and "MAPPED" not in out
+
+
+_TOPO_SCRIPT = """
+import os, sys
+sys.path.insert(0, {root!r})
+import torch, torch.distributed as dist
+from xgnn_amd import ggms_store
+rank, mode = int(sys.argv[1]), sys.argv[3]
+
+class HostShard:  # what TopologyShards needs of ops.SharedShard, on the host
+    made = 0
+    def __init__(self, shape, dtype, device):
+        HostShard.made += 1
+        if mode == "alloc" and rank == 1 and HostShard.made == 2:
+            raise RuntimeError("ggms_device_alloc failed (status -2): out of memory")
+        self.tensor = torch.zeros(shape, dtype=dtype); self.shape = tuple(shape); self.ptr = self.tensor.data_ptr()
+        self.no = HostShard.made
+    def export_handle(self): return b"h" * 64
+    def import_peer(self, h):
+        if mode == "import2" and rank == 1 and self.no == 2:
+            raise RuntimeError("hipIpcOpenMemHandle: invalid device pointer")
+        return 1234
+    def release_peers(self): print("RELEASED", self.no)
+    def close(self): print("CLOSED", self.no)
+
+def build(indptr, indices, world, ncn, only=None):
+    if mode == "build" and rank == 1:
+        raise MemoryError("tried to allocate 13.2 GiB")
+    return ggms_store.topology_shards(indptr, indices, world, ncn, only=only)
+
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=sys.argv[2])
+dist.init_process_group("gloo", rank=rank, world_size=2)
+ip = torch.tensor([0, 2, 3, 5, 6], dtype=torch.int32)
+ix = torch.tensor([1, 2, 0, 3, 0, 2], dtype=torch.int32)
+try:
+    t = ggms_store.TopologyShards(ip, ix, 2, rank, 4, dist, (ip, ix), shard_alloc=HostShard, build=build)
+    print("MAPPED", t.graph.c.num_part, t.graph.c.num_cache_node)
+except ggms_store.PeerConnectError as e:
+    print("REFUSED", e)
+dist.barrier()   # the group is still in step
+print("in step")
+"""
+
+
+@pytest.mark.parametrize("mode", ["build", "alloc", "import2", "fine"])
+def test_topology_shards_failures_are_a_verdict_of_every_rank(tmp_path, mode):
+    """a rank whose topology shard cannot be built ('build': out of memory in topology_shards) or
+    allocated ('alloc': the second SharedShard) never used to enter the handle exchange, and its peers sat out the
+    deadline in all_gather_object.  Now it walks through the exchange as a FailedShard: both ranks raise
+    PeerConnectError with its reason and stay in step; what was allocated or mapped before is released ('import2': the
+    SECOND exchange fails -- the indptr holder and its mappings are closed too)."""
+    script = tmp_path / "topo.py"
+    script.write_text(_TOPO_SCRIPT.format(root=ROOT))
+    port = str(_free_port())
+    env = dict(os.environ, GGMS_IPC_TIMEOUT_S="30")
+    t0 = time.time()
+    ps = [subprocess.Popen([sys.executable, str(script), str(r), port, mode], env=env, stdout=subprocess.PIPE,
+                           stderr=subprocess.PIPE, text=True) for r in (0, 1)]
+    outs = [p.communicate(timeout=120) for p in ps]
+    assert time.time() - t0 < 25  # nobody sat out the 30-s deadline
+    for r, (p, (out, err)) in enumerate(zip(ps, outs)):
+        assert p.returncode == 0, err[-1000:]
+        assert "in step" in out
+        if mode == "fine":
+            assert "MAPPED 2 4" in out and "REFUSED" not in out
+            continue
+        assert "REFUSED" in out and "MAPPED" not in out and "rank 1 of 2" in out
+        if mode == "build":
+            assert "could not build its topology indptr shard" in out and "13.2 GiB" in out
+            assert "CLOSED 1" in out and "CLOSED 2" in out if r == 0 else "CLOSED" not in out  # rank 1 never allocated
+        if mode == "alloc":
+            assert "could not build its topology indptr shard" in out and "out of memory" in out
+            assert "CLOSED 1" in out  # both ranks drop what they did allocate
+        if mode == "import2":
+            assert "topology indices shard" in out and "invalid device pointer" in out
+            assert "CLOSED 1" in out and "CLOSED 2" in out  # the first exchange's holder goes too
+
+
+def test_more_shards_than_the_kernels_carry_is_refused_before_anything_is_built():
+    """a group larger than GGMS_MAX_PARTS used to exchange handles and map peers before its first
+    gather returned GGMS_ERR_INVALID; the stores now refuse it up front."""
+    import torch
+    from xgnn_amd import ggms_store, ops
+    with pytest.raises(ValueError, match="GGMS_MAX_PARTS"):
+        ggms_store.FeatureShards(torch.zeros((4, 4)), None, 9, 0, mode="peer", leaf=object())
+    ggms_store.FeatureShards(torch.zeros((4, 4)), None, 9, 0, mode="a2a", leaf=object())  # no pointers by value there
+    with pytest.raises(ValueError, match="GGMS_MAX_PARTS"):
+        ggms_store.TopologyShards(None, None, 9, 0, 0, None, (None, None))
+    with pytest.raises(ValueError, match="GGMS_MAX_PARTS"):
+        ops.PartTable(list(range(10)))
+    ops.PartTable(list(range(9)))  # topology: 8 shards + the host slot
+
+
+_PROBE_SCRIPT = """
+import os, sys
+sys.path.insert(0, {root!r})
+import torch, torch.distributed as dist
+from xgnn_amd import ggms_store
+rank, mode = int(sys.argv[1]), sys.argv[3]
+
+class Holder:
+    def __init__(self, fill): self.tensor = torch.full((8, 4), fill, dtype=torch.int32); self.shape = (8, 4); self.ptr = 1000 + fill
+    def export_handle(self): return bytes([self.ptr - 1000]) * 64
+    def import_peer(self, h): return 1000 + h[0] if mode != "crossed" else 1000 + rank + 1   # 'crossed': maps its OWN buffer
+    def release_peers(self): pass
+    def close(self): print("CLOSED")
+
+class Leaf:  # what link_probe / peer_access_preflight need of the device, on the host
+    def peer_access(self, dev, peer): return 0 if (mode == "refused" and dev == 1 and peer == 0) else 1
+    def shard(self, rows, words, fill): return Holder(fill)
+    def scratch(self, nbytes): return [0]
+    def copy_rate(self, dst, src_ptr, nbytes, reps): dst[0] = src_ptr - 1000; return 100.0 * rank + (src_ptr - 1000)
+    def gather_rate(self, out, ptrs, rpp, rb, n, seed, reps, ws): return 10.0 * rank + sum(p - 1000 for p in ptrs)
+    def first_word(self, t): return t[0]
+
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=sys.argv[2])
+dist.init_process_group("gloo", rank=rank, world_size=2)
+pre = ggms_store.peer_access_preflight(2, rank, dist, rank, Leaf())
+print("PRE", pre)
+try:
+    rec = ggms_store.link_probe(2, rank, dist, Leaf(), probe_bytes=4096, row_bytes=512, reps=1)
+    print("REC", rec["per_pair_copy_GBps"], rec["per_pair_gather_GBps"], rec["inbound_all_peers_gather_GBps"],
+          rec["inbound_all_peers_min_GBps"], rec["per_pair_gather_min_GBps"])
+except ggms_store.PeerConnectError as e:
+    print("REFUSED", e)
+dist.barrier()
+print("in step")
+"""
+
+
+@pytest.mark.parametrize("mode", ["fine", "refused", "crossed"])
+def test_link_probe_plumbing_two_ranks(tmp_path, mode):
+    """The xGMI probe's host logic on two gloo ranks with a stand-in device: the preflight matrix is the same on both
+    ranks and names the refused pair; the probe's matrices are [reader][owner] with every rank's row in place; a mapping
+    that does not show its owner's memory is a PeerConnectError on EVERY rank; the probe buffer is released either way."""
+    script = tmp_path / "probe.py"
+    script.write_text(_PROBE_SCRIPT.format(root=ROOT))
+    port = str(_free_port())
+    env = dict(os.environ, GGMS_IPC_TIMEOUT_S="30")
+    ps = [subprocess.Popen([sys.executable, str(script), str(r), port, mode], env=env, stdout=subprocess.PIPE,
+                           stderr=subprocess.PIPE, text=True) for r in (0, 1)]
+    outs = [p.communicate(timeout=120) for p in ps]
+    for p, (out, err) in zip(ps, outs):
+        assert p.returncode == 0, err[-1000:]
+        assert "in step" in out and "CLOSED" in out
+        if mode == "refused":
+            assert "'refused': [[1, 0]]" in out and "'devices': [0, 1]" in out
+        else:
+            assert "'refused': []" in out
+        if mode == "crossed":
+            assert "REFUSED" in out and "do not show their owner's memory" in out and "[0, 1]" in out and "[1, 0]" in out
+        else:
+            # copy: 100 * reader + (owner + 1); gather: 10 * reader + (owner + 1); inbound: 10 * reader + (peer + 1)
+            assert "REC [[1.0, 2.0], [101.0, 102.0]] [[1.0, 2.0], [11.0, 12.0]] [2.0, 11.0] 2.0 2.0" in out

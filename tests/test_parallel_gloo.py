@@ -217,3 +217,30 @@ def test_plan_replication_fills_the_budget():
         r = plan_replication(n, row, world, budget)
         used = r * row + -(-(n - r) // world) * row
         assert 0 < r < n and used <= budget < used + world * row * 2    # the largest prefix that fits
+
+
+def test_topology_shards_blocks_are_bounded_by_edges():
+    """_DatasetPartition (dist_graph.cu:228-272) restated on tensors: every shard count, cached prefix and block size
+    (one block, blocks smaller than a hub's list, blocks of a few lists) gives the shards a plain loop gives."""
+    import torch
+    from xgnn_amd import ggms_store
+    rng = np.random.default_rng(0)
+    n = 3000
+    deg = rng.integers(0, 40, n)
+    deg[7] = 2500  # a hub longer than the small block sizes
+    ip = np.zeros(n + 1, np.int64)
+    ip[1:] = np.cumsum(deg)
+    ix = rng.integers(0, n, ip[-1]).astype(np.int32)
+    tip, tix = torch.from_numpy(ip.astype(np.int32)), torch.from_numpy(ix)
+    for P in (1, 2, 3, 8):
+        for ncn in (n, n // 2, 17, 2, 0):
+            for step in (1 << 26, 100, 4000):
+                pip, pix = ggms_store.topology_shards(tip, tix, P, ncn, edges_per_step=step)
+                for p in range(P):
+                    nodes = np.arange(p, ncn, P)
+                    want_ip = np.zeros(len(nodes) + 1, np.int64)
+                    want_ip[1:] = np.cumsum(deg[nodes])
+                    want_ix = (np.concatenate([ix[ip[v]:ip[v + 1]] for v in nodes]) if want_ip[-1]
+                               else np.zeros(0, np.int32))
+                    assert np.array_equal(pip[p].numpy(), want_ip.astype(np.int32)), (P, ncn, step, p)
+                    assert np.array_equal(pix[p].numpy()[:want_ip[-1]], want_ix), (P, ncn, step, p)

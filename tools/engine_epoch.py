@@ -38,7 +38,20 @@ def main():
                     help="the multi-GPU deployment instead of arch1: config + data_init here, one forked worker per GPU "
                          "(sample_init / train_init on cuda:<worker>), feature shards across the workers' GPUs "
                          "(part_cache + gpu_extract), every worker samples its slice of the epoch")
+    ap.add_argument("--staged-host", action="store_true",
+                    help="the host-staged feature path (arch6, one worker, gpu_extract OFF: miss ids to the host, rows "
+                         "gathered by --host-threads cores into pinned memory, copied down, scattered; "
+                         "dist_loops.cc:1015-1207).  After a few warm-up batches a stretch runs the reference's SERIAL "
+                         "sequence with every phase behind its own wait (per-phase rates, as "
+                         "study/host-extract-speed-amount/data.dat reports them), then one the chunked pipeline (effective rate).  The zero-filled stand-in table "
+                         "is given real pages first (SAMGRAPH_FILL_FAKE_FEAT)")
+    ap.add_argument("--host-threads", type=int, default=0, help="--staged-host: omp_thread_num (0 = the cores this process may use)")
+    ap.add_argument("--staged-steps", type=int, nargs=2, default=[10, 20], metavar=("SERIAL", "OVERLAPPED"),
+                    help="--staged-host: measured batches per stretch (each preceded by --staged-warm warm-up batches)")
+    ap.add_argument("--staged-warm", type=int, default=3)
     a = ap.parse_args()
+    if a.staged_host:
+        return main_staged_host(a)
     if a.arch6:
         return main_arch6(a)
     import samgraph.torch as sam
@@ -68,6 +81,77 @@ def main():
                "edges_per_s": ns / wall, "sample_edges_per_s": ns / ts if ts else None,
                "feature_GBps": fb / tc / 1e9 if tc else None, "feature_bytes": fb,
                "log_items": {"kLogEpochSampleTime": ts, "kLogEpochCopyTime": tc}, "init_s": t_init}
+    sam.shutdown()
+    print(json.dumps(out), flush=True)
+
+
+def usable_cores():
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return n
+
+
+def main_staged_host(a):
+    """arch6, ONE worker in this process (no peers to fork for), gpu_extract off.  cache_percentage 0 = BASELINE
+    configs[2] the way the reference runs it (every row through the host cores and one PCIe copy); > 0 = the miss path
+    of a partial cache (the setting of study/host-extract-speed-amount).  One epoch, three stretches of batches:
+    warm-up, the reference's SERIAL sequence (each phase behind its own wait: per-phase rates as data.dat reports
+    them), the chunked pipeline (effective rate over the wall clock)."""
+    os.environ.setdefault("SAMGRAPH_FILL_FAKE_FEAT", "1")
+    import samgraph.torch as sam
+    threads = a.host_threads or usable_cores()
+    warm, n_serial, n_over = a.staged_warm, a.staged_steps[0], a.staged_steps[1]
+    cfg = {"dataset_path": a.dataset, "_arch": sam.builtin_archs["arch6"]["arch"], "_sample_type": sam.sample_types[a.sample_type],
+           "batch_size": a.batch_size, "num_epoch": 1, "_cache_policy": sam.cache_policies["degree"],
+           "cache_percentage": a.cache_percentage, "max_sampling_jobs": 10, "max_copying_jobs": 1, "omp_thread_num": threads,
+           "num_layer": len(a.fanout), "num_hidden": 256, "lr": 0.003, "dropout": 0.5, "num_fanout": len(a.fanout),
+           "fanout": a.fanout, "num_worker": 1, "seed": a.seed, "staged_serial_steps": warm + n_serial,
+           # batches are enqueued exactly when asked for: a stretch's wall clock then covers its own batches only
+           "lookahead": 0}
+    t0 = time.perf_counter()
+    sam.config(cfg)
+    sam.data_init()
+    sam.sample_init(0, "cuda:0")
+    sam.train_init(0, "cuda:0")
+    t_init = time.perf_counter() - t0
+    steps = sam.num_local_step()
+    assert steps >= 2 * warm + n_serial + n_over, "train set too small for the staged-host stretches"
+    out = {"arch": "arch6, 1 worker, gpu_extract off", "cache_percentage": a.cache_percentage, "host_threads": threads,
+           "init_s": t_init}
+
+    def stretch(n):
+        keys, t0 = [], time.perf_counter()
+        for _ in range(n):
+            sam.sample_once()
+            keys.append(sam.get_next_batch())
+        wall = time.perf_counter() - t0
+        item = lambda k: sum(sam.get_log_step_value_by_key(key, k) for key in keys)  # noqa: E731
+        return wall, item
+
+    stretch(warm)
+    wall, item = stretch(n_serial)  # kLogL3Cache{ExtractMiss, CopyMiss, CombineMiss, CombineCache}Time = 46 .. 49
+    miss, feat = item(sam.kLogL1MissBytes), item(sam.kLogL1FeatureBytes)
+    g, c, m, h = item(46), item(47), item(48), item(49)
+    out["serial"] = {"steps": n_serial, "ms_per_step": wall / n_serial * 1e3, "miss_MB_per_step": miss / n_serial / 1e6,
+                     "cpu_gather_GBps": miss / g / 1e9 if g else None, "h2d_GBps": miss / c / 1e9 if c else None,
+                     "combine_miss_GBps": miss / m / 1e9 if m and a.cache_percentage > 0 else None,
+                     "combine_cache_GBps": (feat - miss) / h / 1e9 if h and feat > miss else None,
+                     "effective_GBps": miss / (g + c + m) / 1e9 if g + c + m else None,
+                     "phase_ms_per_step": {"cpu_gather": g / n_serial * 1e3, "h2d": c / n_serial * 1e3,
+                                           "combine_miss": m / n_serial * 1e3, "combine_cache": h / n_serial * 1e3}}
+    stretch(warm)
+    wall, item = stretch(n_over)
+    miss, g = item(sam.kLogL1MissBytes), item(46)
+    out["overlapped"] = {"steps": n_over, "ms_per_step": wall / n_over * 1e3, "miss_MB_per_step": miss / n_over / 1e6,
+                         "cpu_gather_busy_GBps": miss / g / 1e9 if g else None,
+                         # miss bytes over the wall clock of the stretch: sampling, split and the hits' combine included
+                         "effective_GBps": miss / wall / 1e9,
+                         "edges_per_s": item(sam.kLogL1NumSample) / wall}
     sam.shutdown()
     print(json.dumps(out), flush=True)
 

@@ -34,6 +34,12 @@ class FeatureTiers(C.Structure):
                 ("host_feat", C.c_void_p), ("host_row_mask", C.c_uint32), ("_pad", C.c_uint32)]
 
 
+class Topology(C.Structure):
+    """ggms_topology_t"""
+    _fields_ = [("num_device", C.c_int32), ("_pad", C.c_int32), ("can_access", (C.c_int32 * 16) * 16),
+                ("copy_GBps", (C.c_double * 16) * 16)]
+
+
 class HashTable(C.Structure):
     """ggms_hashtable_t"""
     _fields_ = [("o2n", C.c_void_p), ("n2o", C.c_void_p), ("num_items_dev", C.c_void_p),
@@ -94,6 +100,7 @@ SYMBOLS = {
     "ggms_count_nodes": (_i, [_vp, _vp, _sz, _vp, _vp]),
     "ggms_cache_index_workspace_bytes": (_sz, [_sz]),
     "ggms_get_miss_cache_index": (_i, [_vp, _vp, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "ggms_get_miss_cache_index_dev": (_i, [_vp, _vp, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "ggms_gather_scatter": (_i, [_vp, _vp, _vp, _vp, _sz, _vp, _sz, _i, _vp]),
     "ggms_gather_scatter_partition": (_i, [_vp, _vp, _u32, _vp, _vp, _sz, _vp, _sz, _i, _vp]),
     "ggms_extract_cached": (_i, [_vp, _vp, _sz, _vp, _vp, _vp, _u32, _vp, _sz, _i, _vp, _vp]),
@@ -103,7 +110,16 @@ SYMBOLS = {
     "ggms_gather_scatter_masked": (_i, [_vp, _vp, _vp, _vp, _sz, _vp, _sz, _i, _u32, _vp]),
     "ggms_ipc_safe_bytes": (_sz, [_sz]),
     "ggms_extract_tiered": (_i, [_vp, _vp, _sz, _vp, C.POINTER(FeatureTiers), _sz, _i, _vp, _vp]),
+    "ggms_device_count": (_i, [C.POINTER(_i)]),
+    "ggms_peer_access": (_i, [_i, _i, C.POINTER(_i)]),
+    "ggms_detect_topology": (_i, [C.POINTER(Topology), _sz, _i]),
+    "ggms_topology_write_host": (_i, [C.POINTER(Topology), C.c_char_p, C.c_char_p]),
+    "ggms_topology_read_host": (_i, [C.POINTER(Topology), C.c_char_p]),
+    "ggms_link_probe_copy": (_i, [_vp, _vp, _sz, _i, C.POINTER(C.c_double), _vp]),
+    "ggms_link_probe_gather": (_i, [_vp, _vp, _u32, _sz, _sz, _sz, _u32, _i, _vp, C.POINTER(C.c_double), _vp]),
 }
+
+ABI_VERSION = 3  # include/ggms.h as this binding declares it (struct layouts, host / device pointer conventions)
 
 
 def lib():
@@ -119,6 +135,10 @@ def lib():
             fn = getattr(h, name)  # AttributeError if the symbol is not exported
             fn.restype = res
             fn.argtypes = args
+        # a stale build (another struct layout, pointer tables on the other side of the bus) must not be called at all
+        if h.ggms_abi_version() != ABI_VERSION:
+            raise GgmsError(f"{LIB_PATH} has ABI version {h.ggms_abi_version()}, this binding is written for "
+                            f"{ABI_VERSION}: rebuild it (`make -C xgnn_amd/csrc`)")
         _LIB = h
     return _LIB
 

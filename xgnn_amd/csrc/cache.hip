@@ -170,10 +170,11 @@ size_t ggms_cache_index_workspace_bytes(size_t num_nodes) {
   return (tile_scan_words(num_nodes) + 16) * sizeof(uint32_t);
 }
 
-int ggms_get_miss_cache_index(const ggms_id_t *table, const ggms_id_t *nodes, size_t num_nodes,
-                              ggms_id_t *miss_src_index, ggms_id_t *miss_dst_index, uint64_t *num_miss_dev,
-                              ggms_id_t *cache_src_index, ggms_id_t *cache_dst_index, uint64_t *num_cache_dev,
-                              void *workspace, size_t workspace_bytes, ggms_stream_t stream) {
+int ggms_get_miss_cache_index_dev(const ggms_id_t *table, const ggms_id_t *nodes, size_t num_nodes,
+                                  const uint64_t *num_nodes_dev, ggms_id_t *miss_src_index, ggms_id_t *miss_dst_index,
+                                  uint64_t *num_miss_dev, ggms_id_t *cache_src_index, ggms_id_t *cache_dst_index,
+                                  uint64_t *num_cache_dev, void *workspace, size_t workspace_bytes,
+                                  ggms_stream_t stream) {
   GGMS_CHECK_ARG(num_miss_dev && num_cache_dev);
   hipStream_t s = to_stream(stream);
   GGMS_HIP(hipMemsetAsync(num_miss_dev, 0, sizeof(uint64_t), s));
@@ -182,11 +183,19 @@ int ggms_get_miss_cache_index(const ggms_id_t *table, const ggms_id_t *nodes, si
   GGMS_CHECK_ARG(table && nodes && miss_src_index && miss_dst_index && cache_src_index && cache_dst_index);
   GGMS_CHECK_ARG(workspace && workspace_bytes >= ggms_cache_index_workspace_bytes(num_nodes));
   GGMS_CHECK_ARG(num_nodes < (1ull << 32));
-  const Count n = count_of(num_nodes);
+  const Count n = count_of(num_nodes, num_nodes_dev);
   return tile_scan(MissFlag{table, nodes},
                    SplitEmit{table, nodes, miss_src_index, miss_dst_index, cache_src_index, cache_dst_index,
                              num_miss_dev, num_cache_dev, n},
                    num_nodes, n, ScanArea{(uint32_t *)workspace, false}, nullptr, nullptr, nullptr, s);
+}
+
+int ggms_get_miss_cache_index(const ggms_id_t *table, const ggms_id_t *nodes, size_t num_nodes,
+                              ggms_id_t *miss_src_index, ggms_id_t *miss_dst_index, uint64_t *num_miss_dev,
+                              ggms_id_t *cache_src_index, ggms_id_t *cache_dst_index, uint64_t *num_cache_dev,
+                              void *workspace, size_t workspace_bytes, ggms_stream_t stream) {
+  return ggms_get_miss_cache_index_dev(table, nodes, num_nodes, nullptr, miss_src_index, miss_dst_index, num_miss_dev,
+                                       cache_src_index, cache_dst_index, num_cache_dev, workspace, workspace_bytes, stream);
 }
 
 int ggms_owner_histogram(const ggms_id_t *table, const ggms_id_t *nodes, size_t num_nodes,

@@ -6,7 +6,9 @@
 #include <fcntl.h>
 #include <pthread.h>
 #include <sys/mman.h>
+#include <signal.h>
 #include <sys/stat.h>
+#include <sys/wait.h>
 #include <unistd.h>
 
 #include <algorithm>
@@ -140,6 +142,8 @@ void Engine::Configure(const std::unordered_map<std::string, std::string> &kv_in
   if (kv.count("seed")) { cfg.has_seed = true; cfg.seed = std::stoull(kv["seed"]); }
   if (kv.count("hash_table")) cfg.direct_table = kv["hash_table"] != "hashed";
   if (kv.count("lookahead")) cfg.lookahead = std::stoull(kv["lookahead"]);
+  if (kv.count("staged_serial_epochs")) cfg.staged_serial_epochs = std::stoull(kv["staged_serial_epochs"]);
+  if (kv.count("staged_serial_steps")) cfg.staged_serial_steps = std::stoull(kv["staged_serial_steps"]);
   if (kv.count("pipelines")) cfg.pipelines = std::max<size_t>(1, std::min<size_t>(4, std::stoull(kv["pipelines"])));
   if (cfg.lookahead + 1 < cfg.pipelines) cfg.pipelines = cfg.lookahead + 1; // nothing to overlap without batches ahead
   SAM_CHECK(cfg.sample_type >= GGMS_KHOP0 && cfg.sample_type <= GGMS_KHOP3, "unknown sample type");
@@ -147,6 +151,10 @@ void Engine::Configure(const std::unordered_map<std::string, std::string> &kv_in
       cfg.sample_type == GGMS_WEIGHTED_KHOP_PREFIX ||
       cfg.sample_type == GGMS_WEIGHTED_KHOP_HASH_DEDUP) // dist_loops.cc:167-168,171-172,209-210,219-220,227-228
     SAM_CHECK(!cfg.use_dist_graph, "this algorithm not support DistGraph engine");
+  // shard base pointers travel in the kernels' arguments (include/ggms.h, GGMS_MAX_PARTS): a larger group is refused
+  // HERE, before any shard is built, exported or mapped (the reference's device pointer tables take any num_part)
+  if (cfg.arch == kArch6 && (cfg.use_dist_graph || cfg.part_cache))
+    SAM_CHECK(cfg.num_worker <= GGMS_MAX_PARTS, "use_dist_graph / part_cache: at most GGMS_MAX_PARTS (8) workers share a sharded store");
   cfg.configured = true;
 }
 
@@ -242,6 +250,16 @@ void Engine::LoadDataset() {
     SAM_CHECK(ds.feat.ptr != MAP_FAILED, "feature mmap failed");
     ds.feat.shared_anon = true;
     ds.feat_is_fake = true;
+    // An anonymous mapping nobody has written is ONE zero page behind every address: a host gather of such a table reads
+    // 4 KB over and over and measures the cache.  SAMGRAPH_FILL_FAKE_FEAT=1 gives every page a frame of its own (and the
+    // rows a checkable content: 32-bit word w of the table holds w), filled by omp_thread_num threads.
+    if (getenv("SAMGRAPH_FILL_FAKE_FEAT")) {
+      Team team((int)cfg.omp_thread_num);
+      uint32_t *words = (uint32_t *)ds.feat.ptr;
+      team.ParallelFor(ds.feat.bytes / 4, [&](size_t lo, size_t hi, int) {
+        for (size_t w = lo; w < hi; ++w) words[w] = (uint32_t)w;
+      });
+    }
   }
   if (file_exists(cfg.dataset_path + "label.bin")) {
     ds.label = MapFile("label.bin", ds.num_node * 8, share);
@@ -289,9 +307,93 @@ void Engine::DataInit() {
     shared_->arrived.store(0);
     shared_->generation.store(0);
     shared_->num_worker = (int)cfg.num_worker;
+    // DistGraph::DistGraph -> PartitionSolver (dist_graph.cu:592-594): which GPUs reach which, before anything is placed
+    if (cfg.num_worker > 1 && (cfg.use_dist_graph || cfg.part_cache)) DetectTopo();
   }
   prof.LogInit(/*kLogInitL2LoadDataset*/ 6, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
   data_ready_ = true;
+}
+
+static double ipc_timeout_s();
+
+// PartitionSolver::PartitionSolver + DetectTopo (dist_graph.cu:673-726): the parent must not touch the GPU before it
+// forks its workers, so -- like the reference -- the probe runs in a forked child that sees every device: P2P
+// reachability of every pair and a timed 128-MiB copy per reachable pair (ggms_detect_topology), kept in the
+// reference's file format (read back here; reused by later runs on the same node, `SAMGRAPH_TOPO_FILE` names it).
+// What the answer is used for: workers dereference each other's shards in place (DeviceDistGraph / DeviceDistFeature),
+// so a pair of workers' GPUs that cannot reach each other is fatal HERE, with the pair named, instead of as a refused
+// hipIpcOpenMemHandle after every shard has been built.  The reference's solver goes on to search clique placements
+// for partially connected NVLink boxes (:728-777); an MI355X node is one clique (every GPU pair has its own xGMI
+// link), so the placement is the modulo sharding of the whole group and the matrix is logged, not searched.
+// A probe that cannot run (no device visible to the child, child killed) is a warning: placement does not depend on it.
+void Engine::DetectTopo() {
+  if (getenv("SAMGRAPH_FORCE_DEVICE")) return; // one-GPU rehearsal: every worker on one device, nothing to probe
+  std::string file;
+  if (const char *e = getenv("SAMGRAPH_TOPO_FILE")) {
+    file = e;
+  } else {
+    const char *vis = getenv("HIP_VISIBLE_DEVICES");
+    if (!vis) vis = getenv("ROCR_VISIBLE_DEVICES");
+    std::string tag = vis ? vis : "all";
+    for (auto &c : tag) if (!isalnum((unsigned char)c)) c = '_';
+    const char *tmp = getenv("TMPDIR");
+    file = std::string(tmp && *tmp ? tmp : "/tmp") + "/.detect_topo_amd_" + std::to_string((long)getuid()) + "_" + tag; // Constant::kDetectTopoFile
+  }
+  auto usable = [&](const ggms_topology_t &t) { return t.num_device >= (int)cfg.num_worker; };
+  const auto t0 = std::chrono::steady_clock::now();
+  bool probed = false;
+  if (ggms_topology_read_host(&topo_, file.c_str()) != GGMS_OK || !usable(topo_)) {
+    const pid_t pid = fork();
+    SAM_CHECK(pid != -1, "fork of the topology probe failed");
+    if (pid == 0) { // DetectTopo_child, :779-884
+      ggms_topology_t t;
+      int rc = ggms_detect_topology(&t, 0, 2);
+      if (rc != GGMS_OK) fprintf(stderr, "[samgraph-amd] topology probe: %s\n", ggms_last_error());
+      if (rc == GGMS_OK) rc = ggms_topology_write_host(&t, file.c_str(), "HIP_VISIBLE_DEVICES order");
+      _exit(rc == GGMS_OK ? 0 : 1);
+    }
+    int wstatus = 0;
+    bool done = false;
+    while (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() < std::min(120.0, ipc_timeout_s())) {
+      const pid_t r = waitpid(pid, &wstatus, WNOHANG);
+      if (r == pid || r == -1) { done = true; break; }
+      usleep(20000);
+    }
+    if (!done) { // a probe that hangs must not hold the run
+      kill(pid, SIGKILL);
+      waitpid(pid, &wstatus, 0);
+      wstatus = -1;
+    }
+    probed = done && WIFEXITED(wstatus) && WEXITSTATUS(wstatus) == 0;
+    if (!probed || ggms_topology_read_host(&topo_, file.c_str()) != GGMS_OK) {
+      fprintf(stderr, "[samgraph-amd] warning: the topology probe did not complete (%s); placing %zu modulo shards without it\n",
+              done ? "child failed" : "child timed out", cfg.num_worker);
+      return;
+    }
+  }
+  SAM_CHECK(usable(topo_), "arch6 with " + std::to_string(cfg.num_worker) + " workers, but the node shows " +
+                               std::to_string(topo_.num_device) + " GPUs (" + file + ")");
+  topo_valid_ = true;
+  for (size_t i = 0; i < cfg.num_worker; ++i)
+    for (size_t j = 0; j < cfg.num_worker; ++j)
+      if (i != j && !topo_.can_access[i][j])
+        fatal(__FILE__, __LINE__, "GPU " + std::to_string(i) + " cannot access GPU " + std::to_string(j) +
+                                      " (hipDeviceCanAccessPeer, " + file + "): workers read each other's GGMS shards in "
+                                      "place (use_dist_graph / part_cache), which needs P2P access between every pair of "
+                                      "their GPUs");
+  std::ostringstream ss; // "Topology Detect Debug", :714-722
+  ss << "topology (" << (probed ? "probed in " : "read from " + file + " in ")
+     << std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() << " s): GB/s INTO row FROM column\n";
+  char cell[32];
+  for (size_t i = 0; i < cfg.num_worker; ++i) {
+    for (size_t j = 0; j < cfg.num_worker; ++j) {
+      snprintf(cell, sizeof(cell), "%8.1f ", topo_.copy_GBps[i][j]);
+      ss << cell;
+    }
+    ss << "\n";
+  }
+  log_info(ss.str());
+  prof.LogInit(/*kLogInitL3DistGraphDetectTopo: extension slot*/ 40, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
 }
 
 // Every wait on another worker has a deadline (SAMGRAPH_IPC_TIMEOUT_S, default 300 s): a worker that died, or a
@@ -683,7 +785,11 @@ void Engine::BuildCache() {
   // gathers through zero-copy in gpu_extract mode, dist_loops.cc:938-974)
   label_src_ = dev_upload(ds.label.ptr, ds.label.bytes, stream_);
   if (!cfg.UseGPUCache()) {
-    if (cfg.arch == kArch1 || !cfg.gpu_extract) {
+    if (cfg.arch == kArch6 && !cfg.gpu_extract) {
+      // cache 0 without gpu_extract: the table stays in host memory and every row takes the host-staged path
+      // (DoIdCopy + DoCPUFeatureExtract + DoFeatureCopy, dist_loops_arch6.cc:111-133; StagedExtract)
+      feat_src_ = nullptr;
+    } else if (cfg.arch == kArch1) {
       // arch1: the whole table lives in HBM and is gathered directly (cuda_loops_arch1.cc:61)
       d_feat_ = dev_upload(feat, ds.feat.bytes, stream_);
       feat_src_ = d_feat_;
@@ -720,19 +826,33 @@ void Engine::BuildCache() {
   }
   // Rows are staged through a bounded host buffer (64 MB at a time), never through a host copy of the whole replica
   // or shard: at papers100M size a replica is 46 GB, and eight workers of one node would hold eight of them at once.
+  // ... gathered by the host team (omp_thread_num threads) into TWO pinned buffers: the cores fill one while the copy
+  // engine drains the other (one thread and one pageable buffer took a minute per 46-GB replica).
+  Team team((int)std::max<size_t>(1, cfg.omp_thread_num));
+  const size_t step = std::max<size_t>(1, (64u << 20) / row_bytes);
+  char *stage[2] = {nullptr, nullptr};
+  hipEvent_t drained[2];
+  for (int k = 0; k < 2; ++k) {
+    SAM_HIP(hipHostMalloc((void **)&stage[k], step * row_bytes + 16));
+    SAM_HIP(hipEventCreateWithFlags(&drained[k], hipEventDisableTiming));
+  }
   auto upload_rows = [&](size_t first, size_t stride, size_t count) -> void * {
     void *d = nullptr;
     // shards are published to the other workers with hipIpc: sized so that a peer can open them (include/ggms.h)
     SAM_HIP(hipMalloc(&d, ggms_ipc_safe_bytes(std::max<size_t>(count * row_bytes, 16))));
-    const size_t step = std::max<size_t>(1, (64u << 20) / row_bytes);
-    std::vector<char> stage(std::min(count, step) * row_bytes + 16);
-    for (size_t lo = 0; lo < count; lo += step) {
+    size_t k = 0;
+    for (size_t lo = 0; lo < count; lo += step, ++k) {
       const size_t m = std::min(step, count - lo);
-      for (size_t k = 0; k < m; ++k)
-        std::memcpy(&stage[k * row_bytes], feat + (size_t)(rank[first + (lo + k) * stride] & ds.feat_mask) * row_bytes, row_bytes);
-      SAM_HIP(hipMemcpyAsync((char *)d + lo * row_bytes, stage.data(), m * row_bytes, hipMemcpyHostToDevice, stream_));
-      SAM_HIP(hipStreamSynchronize(stream_)); // the staging buffer is refilled next
+      char *buf = stage[k & 1];
+      if (k >= 2) SAM_HIP(hipEventSynchronize(drained[k & 1])); // the copy that last read this buffer is done
+      team.ParallelFor(m, [&](size_t a, size_t b, int) {
+        for (size_t i = a; i < b; ++i)
+          std::memcpy(buf + i * row_bytes, feat + (size_t)(rank[first + (lo + i) * stride] & ds.feat_mask) * row_bytes, row_bytes);
+      });
+      SAM_HIP(hipMemcpyAsync((char *)d + lo * row_bytes, buf, m * row_bytes, hipMemcpyHostToDevice, stream_));
+      SAM_HIP(hipEventRecord(drained[k & 1], stream_));
     }
+    SAM_HIP(hipStreamSynchronize(stream_));
     return d;
   };
   if (R) d_replica_ = upload_rows(0, 1, R); // this GPU's copy of the hottest rows
@@ -752,8 +872,13 @@ void Engine::BuildCache() {
   }
   SAM_CHECK(P <= GGMS_MAX_PARTS, "part_cache: at most GGMS_MAX_PARTS feature shards");
   num_cache_part_ = cfg.part_cache ? P : 0;
-  // miss tier: pinned host memory read by the gather kernel itself (GPUExtractMissData, :573-625)
-  feat_src_ = map_host(ds.feat.ptr, ds.feat.bytes);
+  for (int k = 0; k < 2; ++k) {
+    (void)hipHostFree(stage[k]);
+    (void)hipEventDestroy(drained[k]);
+  }
+  // miss tier: pinned host memory read by the gather kernel itself (GPUExtractMissData, :573-625); the host-staged
+  // path (`gpu_extract` off) reads the table with the host cores instead and needs no device mapping of it
+  feat_src_ = cfg.gpu_extract ? map_host(ds.feat.ptr, ds.feat.bytes) : nullptr;
   SAM_HIP(hipStreamSynchronize(stream_));
 }
 
@@ -791,9 +916,12 @@ void Engine::TrainInit(int worker_id, const std::string &ctx) {
     SAM_HIP(hipMalloc((void **)&b->counts_dev, (3 * L + 8) * 8));
     SAM_HIP(hipMemset(b->counts_dev, 0, (3 * L + 8) * 8));
     if (StagedHostTier()) { // index arrays of GetMissCacheIndex + pinned / device staging of the miss rows
-      for (uint32_t **p : {&b->miss_src, &b->miss_dst, &b->hit_src, &b->hit_dst}) SAM_HIP(hipMalloc((void **)p, max_unique_ * 4));
-      SAM_HIP(hipMalloc(&b->idx_ws, ggms_cache_index_workspace_bytes(max_unique_)));
-      SAM_HIP(hipMalloc(&b->miss_rows_dev, max_unique_ * row_bytes));
+      if (cache_table_) { // (no cache: no split, and the rows land in the batch's feature buffer directly)
+        for (uint32_t **p : {&b->miss_src, &b->miss_dst, &b->hit_src, &b->hit_dst}) SAM_HIP(hipMalloc((void **)p, max_unique_ * 4));
+        SAM_HIP(hipMalloc(&b->idx_ws, ggms_cache_index_workspace_bytes(max_unique_)));
+        SAM_HIP(hipMalloc(&b->miss_rows_dev, max_unique_ * row_bytes));
+      }
+      SAM_HIP(hipEventCreateWithFlags(&b->ev_ids, hipEventDisableTiming));
       SAM_HIP(hipHostMalloc(&b->miss_rows_host, max_unique_ * row_bytes));
       SAM_HIP(hipHostMalloc((void **)&b->miss_ids_host, max_unique_ * 4));
     }
@@ -954,12 +1082,59 @@ bool Engine::EnqueueOne(bool background) {
   return true;
 }
 
-// arch6 without `gpu_extract` (the reference's SGNN mode): DoArch6GetCacheMissIndex + DoCacheIdCopyToCPU +
-// DoArch6CacheFeatureCopy (dist_loops.cc:1015-1207) -- split the input nodes into hits and misses on the GPU, bring
-// the miss ids to the host, gather their rows with the host threads into PINNED memory (hipHostMalloc), send them
-// down with ONE asynchronous copy, scatter them (combine_miss_data) and gather the hits from the cache shards
-// (combine_cache_data[_for_partition]).  Two short host waits per batch (counts, miss ids), as in the reference;
-// the zero-copy gather (`gpu_extract` on) needs none and reads pinned memory at 0.94-0.96 of the copy rate.
+// ---- the host-staged feature path: arch6 without `gpu_extract` (the reference's SGNN mode) --------------------------
+// Reference, cache > 0: DoArch6GetCacheMissIndex + DoCacheIdCopyToCPU + DoArch6CacheFeatureCopy (dist_loops.cc:1015-1207:
+// split on the GPU, miss ids to the host, ExtractMissData on the CPU, ONE H2D copy, CombineMissData, CombineCacheData --
+// every phase behind a StreamSync); cache 0: DoIdCopy + DoCPUFeatureExtract + DoFeatureCopy (dist_loops.cc:481-583,
+// dist_loops_arch6.cc:111-133).  Same data flow here, as a pipeline:
+//   * the split is enqueued right behind the sampler with the batch size left on the device
+//     (ggms_get_miss_cache_index_dev), the hit rows are combined from the cache shards while the host works;
+//   * the miss rows go through pinned memory (hipHostMalloc) in CHUNKS: the host team gathers chunk k + 1 while chunk k's
+//     asynchronous H2D copy and its scatter into the batch run -- the copy engine, the combine kernel and the cores
+//     overlap instead of taking turns, and the last chunks of batch k overlap the first of batch k + 1;
+//   * cache 0: every row is a miss and lands where it belongs -- chunks are copied straight into the batch's feature
+//     buffer, no split and no combine;
+//   * two short host waits per batch (sizes, miss ids) instead of one per phase.
+// `staged_serial_epochs` / `staged_serial_steps` (config keys: the first N epochs / batches) or SAMGRAPH_STAGED_SERIAL=1:
+// the reference's serial sequence instead, every phase
+// timed behind its own wait and logged under the reference's items (kLogL3CacheExtractMissTime ...): the per-phase
+// rates of study/host-extract-speed-amount/data.dat are measured this way.
+
+// one row into pinned memory: streaming stores (no read-for-ownership of a buffer the CPU never reads back)
+static inline void copy_row_stream(char *dst, const char *src, size_t bytes) {
+  typedef long long v2di __attribute__((vector_size(16), aligned(1)));
+  typedef long long v2da __attribute__((vector_size(16)));
+  size_t i = 0;
+  if (((uintptr_t)dst & 15) == 0)
+    for (; i + 16 <= bytes; i += 16) __builtin_nontemporal_store(*(const v2di *)(src + i), (v2da *)(dst + i));
+  if (i < bytes) std::memcpy(dst + i, src + i, bytes - i);
+}
+
+static inline void store_fence() { // streaming stores are weakly ordered: drain them before the DMA engine is told to read
+#if defined(__x86_64__) && !defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("sfence" ::: "memory");
+#else
+  std::atomic_thread_fence(std::memory_order_seq_cst);
+#endif
+}
+
+void Engine::HostGatherRows(char *rows, const uint32_t *ids, size_t first, size_t count) {
+  const char *feat = (const char *)ds.feat.ptr;
+  const size_t row_bytes = ds.feat_dim * ggms_dtype_bytes(ds.feat_dtype);
+  const uint32_t mask = ds.feat_mask;
+  host_team_->ParallelFor(count, [&](size_t lo, size_t hi, int) { // ExtractMissData, cuda_cache_manager_host.cc:268-300
+    constexpr size_t kAhead = 8; // rows: a random 512-byte row is 8 cache lines nobody has asked for yet
+    for (size_t i = lo; i < hi; ++i) {
+      if (i + kAhead < hi) {
+        const char *nx = feat + (size_t)(ids[first + i + kAhead] & mask) * row_bytes;
+        for (size_t o = 0; o < row_bytes; o += 64) __builtin_prefetch(nx + o, 0, 0);
+      }
+      copy_row_stream(rows + (first + i) * row_bytes, feat + (size_t)(ids[first + i] & mask) * row_bytes, row_bytes);
+    }
+    store_fence();
+  });
+}
+
 void Engine::StagedExtract(Batch *b, hipStream_t xs) {
   const uint32_t L = (uint32_t)cfg.fanout.size();
   const size_t row_bytes = ds.feat_dim * ggms_dtype_bytes(ds.feat_dtype);
@@ -967,40 +1142,97 @@ void Engine::StagedExtract(Batch *b, hipStream_t xs) {
     host_team_ = std::make_unique<Team>((int)std::max<size_t>(1, cfg.omp_thread_num));
     log_info("staged extract: host team of " + std::to_string(host_team_->size()) + " threads (omp_thread_num)");
   }
+  static const bool env_serial = getenv("SAMGRAPH_STAGED_SERIAL") != nullptr;
+  const bool serial = env_serial || cur_epoch_ < cfg.staged_serial_epochs || staged_batches_ < cfg.staged_serial_steps;
+  ++staged_batches_;
+  const bool have_cache = cache_table_ != nullptr;
   uint64_t *n_in = b->counts_dev + 3 * L, *n_miss = b->counts_dev + 3 * L + 2, *n_hit = b->counts_dev + 3 * L + 3;
+  using clk = std::chrono::steady_clock;
+  auto since = [](clk::time_point t) { return std::chrono::duration<double>(clk::now() - t).count(); };
+  double t_index = 0, t_ids = 0, t_gather = 0, t_copy = 0, t_comb_miss = 0, t_comb_hit = 0;
+  auto t0 = clk::now();
+  // 0. split (GetMissCacheIndex) behind the sampler, sizes to the host: wait 1
+  if (have_cache)
+    SAM_GGMS(ggms_get_miss_cache_index_dev(cache_table_, b->input_nodes, max_unique_, n_in, b->miss_src, b->miss_dst, n_miss,
+                                           b->hit_src, b->hit_dst, n_hit, b->idx_ws,
+                                           ggms_cache_index_workspace_bytes(max_unique_), xs));
   SAM_HIP(hipMemcpyAsync(b->counts, b->counts_dev, (3 * L + 8) * 8, hipMemcpyDeviceToHost, xs));
-  SAM_HIP(hipStreamSynchronize(xs)); // the batch is sampled: its size is known on the host
-  const size_t num_input = b->counts[3 * L];
-  (void)n_in;
-  if (num_input == 0) return;
-  SAM_GGMS(ggms_get_miss_cache_index(cache_table_, b->input_nodes, num_input, b->miss_src, b->miss_dst, n_miss, b->hit_src,
-                                     b->hit_dst, n_hit, b->idx_ws, ggms_cache_index_workspace_bytes(max_unique_), xs));
-  SAM_HIP(hipMemcpyAsync(b->counts + 3 * L + 2, n_miss, 16, hipMemcpyDeviceToHost, xs));
   SAM_HIP(hipStreamSynchronize(xs));
-  const size_t num_miss = b->counts[3 * L + 2], num_hit = b->counts[3 * L + 3];
-  SAM_CHECK(num_miss + num_hit == num_input, "CHECK_EQ(num_miss + num_cache, num_input), dist_loops.cc:1047");
-  if (num_miss) {
-    SAM_HIP(hipMemcpyAsync(b->miss_ids_host, b->miss_src, num_miss * 4, hipMemcpyDeviceToHost, xs)); // DoCacheIdCopyToCPU
-    SAM_HIP(hipStreamSynchronize(xs));
-    const char *feat = (const char *)ds.feat.ptr;
-    char *rows = (char *)b->miss_rows_host;
-    const uint32_t *ids = b->miss_ids_host;
-    const uint32_t mask = ds.feat_mask;
-    host_team_->ParallelFor(num_miss, [&](size_t lo, size_t hi, int) { // ExtractMissData on the CPU, _host.cc:268-300
-      for (size_t i = lo; i < hi; ++i) std::memcpy(rows + i * row_bytes, feat + (size_t)(ids[i] & mask) * row_bytes, row_bytes);
-    });
-    SAM_HIP(hipMemcpyAsync(b->miss_rows_dev, rows, num_miss * row_bytes, hipMemcpyHostToDevice, xs));
-    SAM_GGMS(ggms_gather_scatter(b->feat, b->miss_rows_dev, nullptr, b->miss_dst, num_miss, nullptr, ds.feat_dim,
-                                 ds.feat_dtype, xs)); // CombineMissData
+  const size_t num_input = b->counts[3 * L];
+  size_t num_miss = have_cache ? b->counts[3 * L + 2] : num_input, num_hit = have_cache ? b->counts[3 * L + 3] : 0;
+  if (!have_cache) { // every row comes from the host tier: the counters say so too
+    b->counts[3 * L + 2] = num_input;
+    SAM_HIP(hipMemcpyAsync(n_miss, b->counts + 3 * L + 2, 8, hipMemcpyHostToDevice, xs));
   }
-  if (num_hit) { // CombineCacheData
+  SAM_CHECK(num_miss + num_hit == num_input, "CHECK_EQ(num_miss + num_cache, num_input), dist_loops.cc:1047");
+  t_index = since(t0);
+  if (num_input == 0) return;
+  // 1. miss ids to the host (DoCacheIdCopyToCPU / DoIdCopy): wait 2 -- the hit rows are combined meanwhile
+  const uint32_t *ids_dev = have_cache ? b->miss_src : b->input_nodes;
+  t0 = clk::now();
+  if (num_miss) SAM_HIP(hipMemcpyAsync(b->miss_ids_host, ids_dev, num_miss * 4, hipMemcpyDeviceToHost, xs));
+  SAM_HIP(hipEventRecord(b->ev_ids, xs));
+  auto combine_hits = [&] { // CombineCacheData
+    if (!num_hit) return;
     if (num_cache_part_ == 0)
       SAM_GGMS(ggms_gather_scatter(b->feat, cache_parts_[0], b->hit_src, b->hit_dst, num_hit, nullptr, ds.feat_dim,
                                    ds.feat_dtype, xs));
     else
       SAM_GGMS(ggms_gather_scatter_partition(b->feat, (const void *const *)cache_parts_.data(), num_cache_part_, b->hit_src,
                                              b->hit_dst, num_hit, nullptr, ds.feat_dim, ds.feat_dtype, xs));
+  };
+  if (!serial) combine_hits(); // on the GPU while the cores gather
+  SAM_HIP(hipEventSynchronize(b->ev_ids));
+  t_ids = since(t0);
+  char *rows = (char *)b->miss_rows_host;
+  // where a chunk of miss rows lands on the device: the staging area (scattered by CombineMissData), or -- no cache,
+  // rows in batch order -- the batch's feature buffer itself
+  char *land = have_cache ? (char *)b->miss_rows_dev : (char *)b->feat;
+  if (serial) { // the reference's sequence, one phase at a time
+    t0 = clk::now();
+    HostGatherRows(rows, b->miss_ids_host, 0, num_miss);
+    t_gather = since(t0);
+    t0 = clk::now();
+    if (num_miss) SAM_HIP(hipMemcpyAsync(land, rows, num_miss * row_bytes, hipMemcpyHostToDevice, xs));
+    SAM_HIP(hipStreamSynchronize(xs));
+    t_copy = since(t0);
+    t0 = clk::now();
+    if (have_cache && num_miss)
+      SAM_GGMS(ggms_gather_scatter(b->feat, b->miss_rows_dev, nullptr, b->miss_dst, num_miss, nullptr, ds.feat_dim,
+                                   ds.feat_dtype, xs)); // CombineMissData
+    SAM_HIP(hipStreamSynchronize(xs));
+    t_comb_miss = since(t0);
+    t0 = clk::now();
+    combine_hits();
+    SAM_HIP(hipStreamSynchronize(xs));
+    t_comb_hit = since(t0);
+  } else {
+    static const size_t chunk_mb = [] { const char *e = getenv("SAMGRAPH_STAGED_CHUNK_MB"); const long v = e ? atol(e) : 0; return (size_t)(v > 0 ? v : 16); }();
+    static const size_t chunk_rows = [] { const char *e = getenv("SAMGRAPH_STAGED_CHUNK_ROWS"); const long v = e ? atol(e) : 0; return (size_t)(v > 0 ? v : 0); }(); // test hook
+    const size_t chunk = chunk_rows ? chunk_rows : std::max<size_t>(1024, (chunk_mb << 20) / row_bytes);
+    for (size_t lo = 0; lo < num_miss; lo += chunk) {
+      const size_t m = std::min(chunk, num_miss - lo);
+      t0 = clk::now();
+      HostGatherRows(rows, b->miss_ids_host, lo, m);
+      t_gather += since(t0);
+      // chunk lo of the pinned buffer is complete: copy engine + combine kernel take it from here, the cores go on
+      SAM_HIP(hipMemcpyAsync(land + lo * row_bytes, rows + lo * row_bytes, m * row_bytes, hipMemcpyHostToDevice, xs));
+      if (have_cache)
+        SAM_GGMS(ggms_gather_scatter(b->feat, (char *)b->miss_rows_dev + lo * row_bytes, nullptr, b->miss_dst + lo, m, nullptr,
+                                     ds.feat_dim, ds.feat_dtype, xs)); // CombineMissData of this chunk
+    }
   }
+  // the reference's step items (profiler.h:111-116: 44 .. 49); overlapped mode: the host's own busy time per phase
+  prof.LogStep(b->key, 44, t_index);
+  prof.LogStep(b->key, 45, t_ids);
+  prof.LogStep(b->key, 46, t_gather);
+  prof.LogStep(b->key, 47, t_copy);
+  prof.LogStep(b->key, 48, t_comb_miss);
+  prof.LogStep(b->key, 49, t_comb_hit);
+  prof.LogEpochAdd(b->key, 20 /*extension: host gather seconds of the staged path*/, t_gather);
+  prof.LogEpochAdd(b->key, 21 /*extension: H2D seconds (serial mode)*/, t_copy);
+  prof.LogEpochAdd(b->key, 22 /*extension: combine-miss seconds (serial mode)*/, t_comb_miss);
+  prof.LogEpochAdd(b->key, 23 /*extension: combine-cache seconds (serial mode)*/, t_comb_hit);
 }
 
 // block until the batch is complete, publish sizes, log the items the scripts read

@@ -77,6 +77,8 @@ struct RunConfig {
                         // measured on papers100M-shaped GCN: a second pipeline loses 2-3 % (the step is bound by the memory
                         // fabric, not by sampler latency) and costs a second 8 B x num_node table
   size_t presample_epoch = 0;
+  size_t staged_serial_epochs = 0; // host-staged path: the first N epochs run the reference's serial, per-phase-timed sequence
+  size_t staged_serial_steps = 0;  // ... or this worker's first N batches
   bool UsePresample() const { return UseGPUCache() && (cache_policy == 2 /*kCacheByPreSample*/); }
   bool UseGPUCache() const { return cache_percentage > 0 && arch != kArch1; } // run_config.h:124-126
 };
@@ -147,8 +149,9 @@ struct Batch {
   // arch6 with `gpu_extract` off: the host-staged miss path (dist_loops.cc:1015-1207)
   uint32_t *miss_src = nullptr, *miss_dst = nullptr, *hit_src = nullptr, *hit_dst = nullptr;
   void *idx_ws = nullptr, *miss_rows_dev = nullptr;
-  void *miss_rows_host = nullptr;   // hipHostMalloc (pinned): CPU-gathered miss rows, then one async H2D copy
+  void *miss_rows_host = nullptr;   // hipHostMalloc (pinned): CPU-gathered miss rows, copied down chunk by chunk
   uint32_t *miss_ids_host = nullptr; // hipHostMalloc
+  hipEvent_t ev_ids = nullptr;       // the miss ids have reached the host
 };
 
 class Engine {
@@ -193,14 +196,20 @@ class Engine {
   bool ShufflerNext(Batch *b, hipStream_t copy_stream); // false at end of training
   void Reshuffle();
   // GGMS
+  void DetectTopo(); // PartitionSolver::DetectTopo (dist_graph.cu:684-726): P2P reachability + link rates, probed in a forked child
+  ggms_topology_t topo_{};
+  bool topo_valid_ = false;
   void UploadGraph();
   void Presample();
   void BuildCache();
   Batch *AcquireSlot(bool background);
   // `gpu_extract` off (SGNN mode of arch6): miss ids -> host, CPU gather into pinned memory, async H2D, combine
-  bool StagedHostTier() const { return cfg.arch == kArch6 && cfg.UseGPUCache() && !cfg.gpu_extract && cache_table_ != nullptr; }
+  // (a partial cache: its table exists; no cache at all: every row is a miss.  A FULL cache has no table and no misses.)
+  bool StagedHostTier() const { return cfg.arch == kArch6 && !cfg.gpu_extract && (cache_table_ != nullptr || !cfg.UseGPUCache()); }
   void StagedExtract(Batch *b, hipStream_t xs);
+  void HostGatherRows(char *rows, const uint32_t *ids, size_t first, size_t count); // ExtractMissData on the host team
   std::unique_ptr<class Team> host_team_;
+  size_t staged_batches_ = 0;
   void SanityCheckBatch(const uint32_t *seeds, size_t n); // SAMGRAPH_SANITY_CHECK
   std::vector<bool> sanity_seen_;
   uint32_t *node_access_dev_ = nullptr; // SAMGRAPH_LOG_NODE_ACCESS[_SIMPLE]: visits per node (input nodes of every batch)

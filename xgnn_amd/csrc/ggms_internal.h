@@ -54,9 +54,20 @@ bool khop3_can_fuse_seeds(size_t num_seeds); // every tile of the first layer ha
 // distinct seeds, any sampler: one launch -- table entries, head of the unique list, batch prologue (hashtable.hip)
 int seed_enter_impl(const ggms_hashtable_t *ht, const uint32_t *seeds, size_t num_seeds, const BatchPrologue &pro,
                     hipStream_t s);
+// distinct seeds entered by khop0's plan pass (the first kernel of the batch): table words, head of the unique list,
+// batch prologue -- k_seed_enter's work without its launch
+struct SeedEnter {
+  unsigned long long *w;
+  uint32_t version;
+  uint32_t *n2o;
+  BatchPrologue pro;
+};
+bool khop0_can_enter_seeds(size_t num_seeds); // its plan pass is one launch
+size_t khop0_plan_desc_words(size_t num_seeds); // descriptor words of the batch's scan area that launch uses itself
 int sample_khop0_impl(GraphView g, const uint32_t *input, size_t n_max, Count n, uint32_t fanout, uint32_t *out_src,
                       uint32_t *out_dst, uint64_t *num_out_dev, uint32_t *workspace, const uint32_t *seed_local,
-                      int src_local, hipStream_t s, ScanArea *shared_scan = nullptr, const DedupInsert *insert = nullptr);
+                      int src_local, hipStream_t s, ScanArea *shared_scan = nullptr, const DedupInsert *insert = nullptr,
+                      const SeedEnter *enter = nullptr);
 int sample_khop2_impl(const uint32_t *indptr, uint32_t *indices, size_t num_node, const uint32_t *input, size_t n_max,
                       Count n, uint32_t fanout, uint32_t *out_src, uint32_t *out_dst, uint64_t *num_out_dev,
                       uint32_t *states, uint32_t *workspace, const uint32_t *seed_local, int src_local, hipStream_t s,

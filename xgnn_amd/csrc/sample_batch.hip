@@ -132,6 +132,7 @@ static BatchLayout layout_of(int sample_type, size_t num_seeds, const size_t *fa
   // generic tile scans of the other samplers (<= kSinglePassTiles descriptors, else three launches)
   l.scan_tiles = std::max<size_t>({c.max_in_all / 128 + 2, owner_scan_tiles(l.dedup_items) + 2, kSinglePassTiles + 2});
   if (sample_type == GGMS_RANDOM_WALK) l.scan_tiles = std::max(l.scan_tiles, walk_scan_tiles(c.max_in_all));
+  if (sample_type == GGMS_KHOP0) l.scan_tiles = std::max<size_t>(l.scan_tiles, 2 * (kSinglePassTiles + 2)); // two sums per pass
   l.scan = w;
   w += up4(std::max(tile_scan_words(std::max(c.max_e_all, c.max_in_all)), 8 + 2 * l.scan_tiles + 4) + 16);
   // the chunked owner scan's 32-bit descriptors + one ticket set per ticketed sampler launch: a piece of their own,
@@ -232,13 +233,25 @@ int ggms_sample_batch(int sample_type, const ggms_graph_t *graph, const ggms_id_
   const bool distinct = extra && extra->seeds_distinct && ht->direct && num_seeds != 0;
   const bool fuse_seeds = distinct && sample_type == GGMS_KHOP3 && khop3_can_fuse_seeds(num_seeds) &&
                           c.max_edges[num_layer - 1] != 0;
+  // khop0: its plan pass (both running sums of the first layer) reads the seeds anyway and enters them on the way
+  const bool khop0_enters = distinct && sample_type == GGMS_KHOP0 && khop0_can_enter_seeds(num_seeds) &&
+                            c.max_input[num_layer - 1] != 0;
   FirstLayer first_layer{};
+  SeedEnter seed_enter{};
   int rc = GGMS_OK;
   if (distinct) {
     seed_local = nullptr;       // SrcMode: the first layer's `col` is the seed's position
     di.map.arr[0] = nullptr;    // IdxMap: segment 0 is the identity
     pro.items_are_seeds = 1;
-    if (fuse_seeds) {
+    if (khop0_enters) {
+      // as below: the prologue must leave alone the descriptors its own launch publishes (epoch-tagged; the rest of
+      // the area is zeroed as usual)
+      const size_t used = khop0_plan_desc_words(num_seeds);
+      pro.num_zero = 8;
+      pro.zero_words3 = pro.zero_words + 8 + used;
+      pro.num_zero3 = (uint32_t)(2 * lay.scan_tiles > used ? 2 * lay.scan_tiles - used : 0);
+      seed_enter = SeedEnter{(unsigned long long *)ht->o2n, ht->version, ht->n2o, pro};
+    } else if (fuse_seeds) {
       // the prologue rides on the first layer's launch and must leave alone the tile descriptors that launch uses
       // (words [8, 8 + 2 tiles) of the area; they are epoch-tagged like every descriptor shared inside a batch)
       const size_t tiles0 = (num_seeds + 127) / 128;
@@ -290,7 +303,8 @@ int ggms_sample_batch(int sample_type, const ggms_graph_t *graph, const ggms_id_
       inserted = ht->direct != 0 && e_max != 0; // khop0 enters its output where it produces it, too
       if (inserted) di.tag = next_dedup_tag();
       rc = sample_khop0_impl(g, input, n_max, n, (uint32_t)fanouts[i], col[i], tmp_dst, num_edge, samp_ws,
-                             first ? seed_local : nullptr, 1, s, &scan, inserted ? &di : nullptr);
+                             first ? seed_local : nullptr, 1, s, &scan, inserted ? &di : nullptr,
+                             first && khop0_enters ? &seed_enter : nullptr);
     } else if (sample_type == GGMS_KHOP2) {
       // no fused insert: even with the four seeds of a lane in lock-step and their atomics issued together, the
       // returning atomics sit in the draw loop's dependency chain (measured on products: 0.45 -> 0.62 ms per step;

@@ -394,14 +394,47 @@ __global__ __launch_bounds__(128 * (4 / GPW), 6) void k_khop3_fused(GraphView g,
 // wave per seed -- modulo, LDS atomicMax on the slot (highest position wins, the canonical reading of the racy
 // atomicExch of khop0.cu:144-148), output.  The buffer holds `cap` draws; a seed whose draws do not fit is
 // resolved in place by the generating lanes, the old way, so the capacity only affects speed.
-struct DrawCount { // draws a seed consumes: one per neighbour position beyond the first `fanout`
+// One pass over the seeds' list heads for both running sums of a khop0 layer (tile_scan2): a = edges the seed emits
+// (min(deg, fanout): its slice of the compact COO), b = draws it consumes (one per neighbour position beyond fanout).
+struct Khop0Count {
   GraphView g;
   const uint32_t *input;
   uint32_t fanout;
-  __device__ __forceinline__ uint32_t operator()(uint64_t i) const {
+  __device__ __forceinline__ U2 operator()(uint64_t i) const {
     uint32_t len;
     g.neighbours(input[i], len);
-    return len > fanout ? len - fanout : 0u;
+    return len > fanout ? U2{fanout, len - fanout} : U2{len, 0u};
+  }
+};
+// ... and what rides on that pass: the two prefix arrays and -- first layer of a batch with distinct seeds, direct
+// table -- the seeds themselves (k_seed_enter's work: table word {pending, i}, head of the unique list)
+struct Khop0Store {
+  uint32_t *offset, *draw_base;
+  unsigned long long *w; // NULL: the seeds are not entered here
+  uint32_t version;
+  const uint32_t *seeds;
+  uint32_t *n2o;
+  template <int CH>
+  __device__ __forceinline__ void one(uint64_t i, uint32_t, uint32_t excl) const {
+    (CH ? draw_base : offset)[i] = excl;
+  }
+  __device__ __forceinline__ void operator()(uint64_t i, uint32_t, uint32_t, uint32_t pa, uint32_t pb) const {
+    offset[i] = pa;
+    draw_base[i] = pb;
+    if (w) {
+      const uint32_t key = seeds[i];
+      n2o[i] = key;
+      atomicMin(w + key, make_w1(version, 1u, (uint32_t)i)); // not returning: nothing of this batch was entered before
+    }
+  }
+};
+struct Khop0Side { // workgroup 0 of the pass: the heavy list starts empty; the batch prologue where this is a batch's first kernel
+  uint32_t *heavy_count;
+  BatchPrologue pro;
+  uint32_t has_pro;
+  __device__ __forceinline__ void start(uint64_t n, uint32_t tid, uint32_t nthreads) const {
+    if (tid == 0) *heavy_count = 0u;
+    if (has_pro) pro.run(n, tid, nthreads);
   }
 };
 
@@ -427,6 +460,9 @@ __device__ __forceinline__ void slot_fence_wave() {
   __builtin_amdgcn_wave_barrier();
 }
 
+// A seed with more parked draws than this is resolved by a whole workgroup of the resolve kernel, not by one 16-lane group
+constexpr uint32_t kKhop0Heavy = 1024;
+
 template <bool BIG>
 __global__ __launch_bounds__(128) void k_khop0_generate(GraphView g, const uint32_t *__restrict__ input, Count n_arg,
                                                         uint32_t fanout, const uint32_t *__restrict__ offset,
@@ -434,13 +470,13 @@ __global__ __launch_bounds__(128) void k_khop0_generate(GraphView g, const uint3
                                                         uint32_t *__restrict__ raw, uint32_t cap,
                                                         uint32_t *__restrict__ out_src,
                                                         uint32_t *__restrict__ out_dst, SrcMode sm,
-                                                        uint32_t *__restrict__ heavy_count, DedupInsert di) {
+                                                        uint32_t *__restrict__ heavy_count,
+                                                        uint32_t *__restrict__ heavy_list, DedupInsert di) {
   extern __shared__ uint32_t slot_j[]; // [4][fanout]: winning position per reservoir slot (in-place seeds only)
   const uint64_t n = n_arg.get();
   const uint32_t x = threadIdx.x & 31, w = threadIdx.x >> 5;
   const uint32_t half = threadIdx.x & 32u; // first lane of my logical warp inside the wave64
   const uint64_t num_blocks = (n + 63) / 64;
-  if (blockIdx.x == 0 && threadIdx.x == 0) *heavy_count = 0u; // list filled by k_khop0_resolve
   uint32_t first_j = x;
   while (first_j < fanout) first_j += 32; // first position of this lane that is drawn for
   for (uint64_t b = blockIdx.x; b < num_blocks; b += gridDim.x) {
@@ -453,6 +489,19 @@ __global__ __launch_bounds__(128) void k_khop0_generate(GraphView g, const uint3
     if (x < 16 && my_index < n) {
       g.neighbours(input[my_index], my_len);
       my_base = draw_base[my_index];
+    }
+    { // the seeds whose parked draws one 16-lane group should not walk alone: listed here (the resolve kernel's
+      // workgroups take them first, a whole workgroup per seed).  One counter update per wave.
+      const bool heavy = x < 16 && my_index < n && my_len > fanout && my_len - fanout > kKhop0Heavy &&
+                         (uint64_t)my_base + (my_len - fanout) <= cap;
+      const uint64_t hm = __ballot(heavy);
+      if (hm) {
+        const uint32_t leader = (uint32_t)__builtin_ctzll(hm);
+        uint32_t at = 0;
+        if ((threadIdx.x & 63u) == leader) at = atomicAdd(heavy_count, (uint32_t)__popcll(hm));
+        at = __shfl(at, (int)leader, 64);
+        if (heavy) heavy_list[at + (uint32_t)__popcll(hm & ((1ull << (threadIdx.x & 63u)) - 1ull))] = (uint32_t)my_index;
+      }
     }
     for (uint32_t k = 0; k < 16; ++k) {
       const uint64_t index = 64 * b + w + 4 * (uint64_t)k;
@@ -490,9 +539,6 @@ __global__ __launch_bounds__(128) void k_khop0_generate(GraphView g, const uint3
   }
 }
 
-// A seed with more parked draws than this is left to k_khop0_resolve_heavy (one 1024-thread block per seed)
-constexpr uint32_t kKhop0Heavy = 1024;
-
 // the resolve step proper: lanes `lane`, `lane + stride`, ... of the draws of one seed into its LDS slots
 __device__ __forceinline__ void khop0_resolve_draws(const uint32_t *__restrict__ raw, uint32_t base, uint32_t extra,
                                                     uint32_t fanout, uint32_t lane, uint32_t stride,
@@ -514,9 +560,10 @@ __device__ __forceinline__ void khop0_resolve_draws(const uint32_t *__restrict__
   }
 }
 
-// 16 lanes per seed (4 seeds per wave, 16 per block): copy (deg <= fanout) or resolve the parked draws.  The
-// per-seed chain of dependent loads (id -> degree -> offsets -> draws -> neighbours) is what bounds this kernel,
-// so several seeds share a wave.
+// Resolve: the listed long lists first -- one whole workgroup per seed (k_khop0_generate listed them; the longest
+// tasks start first) -- then 16 lanes per seed (4 seeds per wave, 16 per block): copy (deg <= fanout) or resolve the
+// parked draws.  The per-seed chain of dependent loads (id -> degree -> offsets -> draws -> neighbours) is what bounds
+// this kernel, so several seeds share a wave.
 template <bool BIG>
 __global__ __launch_bounds__(kBlock) void k_khop0_resolve(GraphView g, const uint32_t *__restrict__ input, Count n_arg,
                                                           uint32_t fanout, const uint32_t *__restrict__ offset,
@@ -524,12 +571,37 @@ __global__ __launch_bounds__(kBlock) void k_khop0_resolve(GraphView g, const uin
                                                           const uint32_t *__restrict__ raw, uint32_t cap,
                                                           uint32_t *__restrict__ out_src,
                                                           uint32_t *__restrict__ out_dst, SrcMode sm,
-                                                          uint32_t *__restrict__ heavy_count,
-                                                          uint32_t *__restrict__ heavy_list, uint32_t groups,
+                                                          const uint32_t *__restrict__ heavy_count,
+                                                          const uint32_t *__restrict__ heavy_list, uint32_t groups,
                                                           DedupInsert di) {
-  extern __shared__ uint32_t slot_j[]; // [groups][fanout]
+  extern __shared__ uint32_t slot_j[]; // [groups][fanout]; the heavy pass uses the first [fanout]
   constexpr uint32_t G = 16;
   const uint64_t n = n_arg.get();
+  {
+    const uint32_t num_heavy = *heavy_count; // uniform
+    for (uint32_t h = blockIdx.x; h < num_heavy; h += gridDim.x) {
+      const uint32_t index = heavy_list[h];
+      const uint32_t rid = input[index];
+      uint32_t len;
+      const uint32_t *edges = g.neighbours(rid, len);
+      const uint32_t o = offset[index], base = draw_base[index];
+      const uint32_t sv = sm.value(rid, index);
+      uint32_t *const slots = BIG ? out_dst + o : slot_j;
+      for (uint32_t s0 = threadIdx.x; s0 < fanout; s0 += kBlock) slot_init<BIG>(&slots[s0], s0);
+      if constexpr (BIG) __threadfence();
+      __syncthreads();
+      khop0_resolve_draws(raw, base, len - fanout, fanout, threadIdx.x, kBlock, slots);
+      if constexpr (BIG) __threadfence();
+      __syncthreads();
+      for (uint32_t s0 = threadIdx.x; s0 < fanout; s0 += kBlock) {
+        const uint32_t nbr = edges[slot_read<BIG>(&slots[s0])];
+        out_src[o + s0] = sv;
+        out_dst[o + s0] = nbr;
+        if (di.w) di.enter(nbr, o + s0);
+      }
+      __syncthreads();
+    }
+  }
   const uint32_t lig = threadIdx.x & (G - 1), grp = threadIdx.x / G;
   if (grp >= groups) return; // wide fanouts: fewer seeds per block, the LDS slots decide
   const uint64_t stride = (uint64_t)gridDim.x * groups;
@@ -550,10 +622,7 @@ __global__ __launch_bounds__(kBlock) void k_khop0_resolve(GraphView g, const uin
     }
     const uint32_t base = draw_base[index], extra = len - fanout;
     if ((uint64_t)base + extra > cap) continue; // resolved in place by k_khop0_generate
-    if (extra > kKhop0Heavy) {                  // a whole block takes it
-      if (lig == 0) heavy_list[atomicAdd(heavy_count, 1u)] = (uint32_t)index;
-      continue;
-    }
+    if (extra > kKhop0Heavy) continue;          // listed: taken by a whole workgroup above
     uint32_t *const my_slots = BIG ? out_dst + o : slot_j + grp * fanout;
     for (uint32_t s0 = lig; s0 < fanout; s0 += G) slot_init<BIG>(&my_slots[s0], s0);
     slot_fence_wave<BIG>();
@@ -566,42 +635,6 @@ __global__ __launch_bounds__(kBlock) void k_khop0_resolve(GraphView g, const uin
       if (di.w) di.enter(nbr, o + s0);
     }
     __builtin_amdgcn_wave_barrier();
-  }
-}
-
-// the long neighbour lists: one 1024-thread block per listed seed
-template <bool BIG>
-__global__ __launch_bounds__(1024) void k_khop0_resolve_heavy(GraphView g, const uint32_t *__restrict__ input,
-                                                              uint32_t fanout, const uint32_t *__restrict__ offset,
-                                                              const uint32_t *__restrict__ draw_base,
-                                                              const uint32_t *__restrict__ raw,
-                                                              uint32_t *__restrict__ out_src,
-                                                              uint32_t *__restrict__ out_dst, SrcMode sm,
-                                                              const uint32_t *__restrict__ heavy_count,
-                                                              const uint32_t *__restrict__ heavy_list, DedupInsert di) {
-  extern __shared__ uint32_t slot_j[]; // [fanout]
-  const uint32_t num = *heavy_count;
-  for (uint32_t h = blockIdx.x; h < num; h += gridDim.x) {
-    const uint32_t index = heavy_list[h];
-    const uint32_t rid = input[index];
-    uint32_t len;
-    const uint32_t *edges = g.neighbours(rid, len);
-    const uint32_t o = offset[index], base = draw_base[index];
-    const uint32_t sv = sm.value(rid, index);
-    uint32_t *const slots = BIG ? out_dst + o : slot_j;
-    for (uint32_t s0 = threadIdx.x; s0 < fanout; s0 += 1024) slot_init<BIG>(&slots[s0], s0);
-    if constexpr (BIG) __threadfence();
-    __syncthreads();
-    khop0_resolve_draws(raw, base, len - fanout, fanout, threadIdx.x, 1024, slots);
-    if constexpr (BIG) __threadfence();
-    __syncthreads();
-    for (uint32_t s0 = threadIdx.x; s0 < fanout; s0 += 1024) {
-      const uint32_t nbr = edges[slot_read<BIG>(&slots[s0])];
-      out_src[o + s0] = sv;
-      out_dst[o + s0] = nbr;
-      if (di.w) di.enter(nbr, o + s0);
-    }
-    __syncthreads();
   }
 }
 
@@ -799,13 +832,22 @@ size_t khop0_draw_cap(size_t num_input, size_t fanout) {
   const unsigned long long want = 8ull * num_input * fanout;
   return (size_t)(want < 0x7fffffffull ? want : 0x7fffffffull);
 }
+bool khop0_can_enter_seeds(size_t num_seeds) { return scan2_single_launch(num_seeds); }
+size_t khop0_plan_desc_words(size_t num_seeds) { return scan2_desc_words(num_seeds); }
 size_t khop0_ws_words(size_t num_input, size_t fanout) {
   return 3 * num_input + tile_scan_words(num_input) + 48 + khop0_draw_cap(num_input, fanout);
 }
 
+// One layer = THREE launches: plan (both running sums in one pass, tile_scan2; the batch prologue and the distinct
+// seeds' table entries ride on it where this is a batch's first kernel), generate (draws parked, long lists listed),
+// resolve (listed lists by whole workgroups first, then 16 lanes per seed).  Rounds 1-4 took six (two scans, generate,
+// resolve, a 256 x 1024-thread launch for the long lists, + a seed-entry launch per batch): on a stream that runs
+// beside another batch's sampler and a gather every small launch is a chain of loaded round trips
+// (profiles/r05_khop0_chain.txt).
 int sample_khop0_impl(GraphView g, const uint32_t *input, size_t n_max, Count n, uint32_t fanout, uint32_t *out_src,
                       uint32_t *out_dst, uint64_t *num_out_dev, uint32_t *workspace, const uint32_t *seed_local,
-                      int src_local, hipStream_t s, ScanArea *shared_scan, const DedupInsert *insert) {
+                      int src_local, hipStream_t s, ScanArea *shared_scan, const DedupInsert *insert,
+                      const SeedEnter *enter) {
   const DedupInsert di = insert ? *insert : DedupInsert{}; // w == NULL: no table to enter the output into
   uint32_t *offset = workspace;
   uint32_t *draw_base = offset + n_max;
@@ -819,11 +861,28 @@ int sample_khop0_impl(GraphView g, const uint32_t *input, size_t n_max, Count n,
   const size_t full_cap = khop0_draw_cap(n_max, fanout);
   const uint32_t cap = (uint32_t)(forced_cap >= 0 && (size_t)forced_cap < full_cap ? (size_t)forced_cap : full_cap);
   const ScanArea sa = shared_scan ? *shared_scan : ScanArea{scan_scr, false};
-  int rc = tile_scan(SeedCount{g, input, fanout}, StoreOffset{offset}, n_max, n, sa, nullptr, nullptr,
-                     num_out_dev, s);
-  if (rc != GGMS_OK) return rc;
-  const ScanArea sb = shared_scan ? *shared_scan : ScanArea{scan_scr, true}; // control words re-armed by the first scan
-  rc = tile_scan(DrawCount{g, input, fanout}, StoreOffset{draw_base}, n_max, n, sb, nullptr, nullptr, nullptr, s);
+  const bool one_launch = scan2_single_launch(n_max);
+  if (enter && !one_launch) {
+    set_error("sample_khop0: seeds can only be entered by a one-launch plan pass");
+    return GGMS_ERR_INVALID;
+  }
+  Khop0Store store{offset, draw_base, nullptr, 0u, nullptr, nullptr};
+  Khop0Side side{heavy_count, BatchPrologue{nullptr, 0, nullptr, 0, nullptr, nullptr}, 0u};
+  if (enter) {
+    store.w = enter->w;
+    store.version = enter->version;
+    store.seeds = input;
+    store.n2o = enter->n2o;
+    side.pro = enter->pro;
+    side.has_pro = 1u;
+  }
+  int rc;
+  if (one_launch) {
+    rc = tile_scan2(Khop0Count{g, input, fanout}, store, side, n_max, n, sa, num_out_dev, s);
+  } else { // beyond kSinglePassTiles tiles: two plain scans, nobody to run `side`
+    GGMS_HIP(hipMemsetAsync(heavy_count, 0, sizeof(uint32_t), s));
+    rc = tile_scan2(Khop0Count{g, input, fanout}, store, NoSide{}, n_max, n, sa, num_out_dev, s);
+  }
   if (rc != GGMS_OK) return rc;
   const SrcMode sm{seed_local, src_local};
   const bool big = fanout > kKhop0LdsFanout; // slots in the output array instead of LDS
@@ -831,10 +890,10 @@ int sample_khop0_impl(GraphView g, const uint32_t *input, size_t n_max, Count n,
   const int grid_gen = grid_for((n_max + 63) / 64, 1);
   if (big)
     hipLaunchKernelGGL(k_khop0_generate<true>, dim3(grid_gen), dim3(128), lds, s, g, input, n, fanout, offset, draw_base,
-                       raw, cap, out_src, out_dst, sm, heavy_count, di);
+                       raw, cap, out_src, out_dst, sm, heavy_count, heavy_list, di);
   else
     hipLaunchKernelGGL(k_khop0_generate<false>, dim3(grid_gen), dim3(128), lds, s, g, input, n, fanout, offset,
-                       draw_base, raw, cap, out_src, out_dst, sm, heavy_count, di);
+                       draw_base, raw, cap, out_src, out_dst, sm, heavy_count, heavy_list, di);
   GGMS_LAUNCH_CHECK();
   // seeds per 256-thread block of the resolve kernel: 16 lanes each, as many as 48 KB of LDS slots allow
   const uint32_t groups = big ? 16u : std::max<uint32_t>(1, std::min<uint32_t>(16, (48u << 10) / (4u * fanout)));
@@ -845,14 +904,6 @@ int sample_khop0_impl(GraphView g, const uint32_t *input, size_t n_max, Count n,
     hipLaunchKernelGGL(k_khop0_resolve<false>, dim3(grid_for(n_max, groups)), dim3(kBlock),
                        groups * fanout * sizeof(uint32_t), s, g, input, n, fanout, offset, draw_base, raw, cap, out_src,
                        out_dst, sm, heavy_count, heavy_list, groups, di);
-  GGMS_LAUNCH_CHECK();
-  // the few neighbour lists with more than kKhop0Heavy parked draws (none on most batches: the kernel then exits at once)
-  if (big)
-    hipLaunchKernelGGL(k_khop0_resolve_heavy<true>, dim3(256), dim3(1024), 0, s, g, input, fanout, offset, draw_base, raw,
-                       out_src, out_dst, sm, heavy_count, heavy_list, di);
-  else
-    hipLaunchKernelGGL(k_khop0_resolve_heavy<false>, dim3(256), dim3(1024), fanout * sizeof(uint32_t), s, g, input,
-                       fanout, offset, draw_base, raw, out_src, out_dst, sm, heavy_count, heavy_list, di);
   GGMS_LAUNCH_CHECK();
   return GGMS_OK;
 }

@@ -470,4 +470,165 @@ inline int tile_scan(ValueF value, EmitF emit, size_t n_max, Count n, ScanArea a
   return GGMS_OK;
 }
 
+// ---- two sums over one input, one pass ---------------------------------------------------------------------------
+// Some samplers need two running sums of the same per-seed read (khop0: output offsets = sum of min(deg, fanout), draw
+// bases = sum of the neighbour positions beyond fanout).  Two scans are two launches, two passes over the seeds' list
+// heads and two look-back chains on a stream whose small kernels are latency chains; this form carries both sums
+// through ONE launch: value(i) -> {a, b}, emit(i, a, b, prefix_a, prefix_b).  Channel A's descriptors sit at
+// desc[0, tiles), channel B's right behind them at desc[tiles, 2 tiles) (tiles = the launch's upper bound), so a
+// launch uses ONE contiguous range of the area.  side.start(n) runs once, on workgroup 0 (a batch prologue, a counter
+// reset, ...).  Inputs beyond kSinglePassTiles take two plain scans (tile_scan2 below).
+struct U2 {
+  uint32_t a, b;
+};
+template <typename ValueF2, int CH>
+struct PickChannel { // by value: it is also handed to kernels (the two-launch fallback)
+  ValueF2 v;
+  __device__ __forceinline__ uint32_t operator()(uint64_t i) const {
+    const U2 x = v(i);
+    return CH ? x.b : x.a;
+  }
+};
+struct NoSide {
+  __device__ __forceinline__ void start(uint64_t, uint32_t, uint32_t) const {}
+};
+
+template <typename ValueF2, typename EmitF2, typename Side>
+__global__ __launch_bounds__(kBlock) void k_tile_scan2(ValueF2 value, EmitF2 emit, Side side, Count n_arg,
+                                                       unsigned long long *desc, uint32_t b_off, uint32_t epoch,
+                                                       uint64_t *total_a_out, uint32_t *err, uint32_t patience) {
+  constexpr uint32_t ROUNDS = kTile / kBlock, FLAG_A = 1, FLAG_P = 2;
+  __shared__ uint32_t smem[kBlock / kWave];
+  __shared__ uint32_t s_prefix[2];
+  const uint64_t n = n_arg.get();
+  const uint64_t num_tiles = (n + kTile - 1) / kTile;
+  if (blockIdx.x == 0) side.start(n, threadIdx.x, kBlock);
+  unsigned long long *const desc_b = desc + b_off;
+  for (uint64_t round = 0;; ++round) {
+    const uint64_t tile = (uint64_t)blockIdx.x + round * gridDim.x;
+    if (tile >= num_tiles) break;
+    U2 v[ROUNDS];
+    uint32_t ea[ROUNDS], eb[ROUNDS];
+    uint32_t run_a = 0, run_b = 0;
+#pragma unroll
+    for (uint32_t r = 0; r < ROUNDS; ++r) {
+      const uint64_t i = tile * kTile + r * kBlock + threadIdx.x;
+      v[r] = (i < n) ? value(i) : U2{0u, 0u};
+      uint32_t ta, tb;
+      ea[r] = run_a + block_exclusive_scan(v[r].a, smem, ta);
+      eb[r] = run_b + block_exclusive_scan(v[r].b, smem, tb);
+      run_a += ta;
+      run_b += tb;
+    }
+    if (threadIdx.x < kWave) { // wave 0 publishes both sums and looks back for both
+      const uint32_t lane = threadIdx.x;
+      uint32_t pa = 0, pb = 0;
+      if (tile == 0) {
+        if (lane == 0) {
+          __hip_atomic_store(&desc[0], scan_desc(epoch, FLAG_P, run_a), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(&desc_b[0], scan_desc(epoch, FLAG_P, run_b), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      } else {
+        if (lane == 0) {
+          __hip_atomic_store(&desc[tile], scan_desc(epoch, FLAG_A, run_a), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(&desc_b[tile], scan_desc(epoch, FLAG_A, run_b), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        const PickChannel<ValueF2, 0> va{value};
+        const PickChannel<ValueF2, 1> vb{value};
+        pa = scan_lookback(desc, tile, epoch, err, patience, TileSumHelp<PickChannel<ValueF2, 0>>{va, n, 0u});
+        pb = scan_lookback(desc_b, tile, epoch, err, patience, TileSumHelp<PickChannel<ValueF2, 1>>{vb, n, 0u});
+        if (lane == 0) {
+          __hip_atomic_store(&desc[tile], scan_desc(epoch, FLAG_P, pa + run_a), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(&desc_b[tile], scan_desc(epoch, FLAG_P, pb + run_b), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+      if (lane == 0) {
+        s_prefix[0] = pa;
+        s_prefix[1] = pb;
+        if (tile + 1 == num_tiles && total_a_out) *total_a_out = (uint64_t)(pa + run_a);
+      }
+    }
+    __syncthreads();
+    const uint32_t pa = s_prefix[0], pb = s_prefix[1];
+#pragma unroll
+    for (uint32_t r = 0; r < ROUNDS; ++r) {
+      const uint64_t i = tile * kTile + r * kBlock + threadIdx.x;
+      if (i < n) emit(i, v[r].a, v[r].b, pa + ea[r], pb + eb[r]);
+    }
+    __syncthreads(); // s_prefix is rewritten next iteration
+  }
+  if (threadIdx.x == 0 && num_tiles == 0 && blockIdx.x == 0 && total_a_out) *total_a_out = 0;
+}
+
+template <typename ValueF2, typename EmitF2, typename Side>
+__global__ __launch_bounds__(1024) void k_small_scan2(ValueF2 value, EmitF2 emit, Side side, Count n_arg,
+                                                      uint64_t *total_a_out) {
+  __shared__ uint32_t wsum[2][16];
+  const uint64_t n = n_arg.get();
+  side.start(n, threadIdx.x, 1024);
+  const uint32_t w = threadIdx.x >> 6;
+  const uint64_t i = threadIdx.x;
+  const U2 v = (i < n) ? value(i) : U2{0u, 0u};
+  const uint32_t ia = wave_inclusive_scan(v.a), ib = wave_inclusive_scan(v.b);
+  if (lane_id() == 63) {
+    wsum[0][w] = ia;
+    wsum[1][w] = ib;
+  }
+  __syncthreads();
+  uint32_t ba = 0, bb = 0, ta = 0;
+#pragma unroll
+  for (uint32_t k = 0; k < 16; ++k) {
+    const uint32_t sa = wsum[0][k], sb = wsum[1][k];
+    if (k < w) {
+      ba += sa;
+      bb += sb;
+    }
+    ta += sa;
+  }
+  if (i < n) emit(i, v.a, v.b, ba + ia - v.a, bb + ib - v.b);
+  if (threadIdx.x == 0 && total_a_out) *total_a_out = (uint64_t)ta;
+}
+
+// whether tile_scan2 over n_max items is ONE launch (the caller may then hang a batch prologue on it)
+inline bool scan2_single_launch(size_t n_max) { return n_max <= kSmallScan || scan_single_pass(n_max); }
+// descriptor words (behind the 8 control words) a one-launch tile_scan2 over n_max items uses
+inline size_t scan2_desc_words(size_t n_max) { return n_max <= kSmallScan ? 0 : 4 * num_tiles_for(n_max); }
+
+// emit adapters for the two-launch fallback: the pair's other half is recomputed by the second scan
+template <typename EmitF2, int CH>
+struct EmitChannel {
+  EmitF2 emit;
+  __device__ __forceinline__ void operator()(uint64_t i, uint32_t v, uint32_t excl) const { emit.template one<CH>(i, v, excl); }
+};
+
+// area: control words + >= 4 (tiles + 1) descriptor words (single pass), `cleared` as for tile_scan.  side must be
+// NoSide unless scan2_single_launch(n_max).
+template <typename ValueF2, typename EmitF2, typename Side>
+inline int tile_scan2(ValueF2 value, EmitF2 emit, Side side, size_t n_max, Count n, ScanArea area, uint64_t *total_a_out,
+                      hipStream_t stream) {
+  if (n_max <= kSmallScan) {
+    hipLaunchKernelGGL((k_small_scan2<ValueF2, EmitF2, Side>), dim3(1), dim3(1024), 0, stream, value, emit, side, n, total_a_out);
+    GGMS_LAUNCH_CHECK();
+    return GGMS_OK;
+  }
+  const size_t nt = num_tiles_for(n_max);
+  uint32_t *ctl = scan_align(area.words);
+  unsigned long long *desc = reinterpret_cast<unsigned long long *>(ctl + 8);
+  if (scan_single_pass(n_max)) {
+    if (!area.cleared) GGMS_HIP(hipMemsetAsync(ctl, 0, (8 + 4 * (nt + 1)) * sizeof(uint32_t), stream));
+    hipLaunchKernelGGL((k_tile_scan2<ValueF2, EmitF2, Side>), dim3(grid_for(nt, 1)), dim3(kBlock), 0, stream, value, emit,
+                       side, n, desc, (uint32_t)nt, next_scan_epoch(), total_a_out, area.status_word(), scan_patience());
+    GGMS_LAUNCH_CHECK();
+    return GGMS_OK;
+  }
+  // large inputs: two plain scans (three launches each; no inter-workgroup wait), each emitting its own half
+  int rc = tile_scan(PickChannel<ValueF2, 0>{value}, EmitChannel<EmitF2, 0>{emit}, n_max, n, area, nullptr, nullptr,
+                     total_a_out, stream);
+  if (rc != GGMS_OK) return rc;
+  ScanArea again = area;
+  again.cleared = true;
+  return tile_scan(PickChannel<ValueF2, 1>{value}, EmitChannel<EmitF2, 1>{emit}, n_max, n, again, nullptr, nullptr,
+                   nullptr, stream);
+}
+
 } // namespace ggms

@@ -22,6 +22,17 @@ import threading
 import numpy as np
 import torch
 
+MAX_PARTS = 8  # GGMS_MAX_PARTS (include/ggms.h): shard base pointers travel in the kernels' arguments
+
+
+def check_num_parts(num_part, what):
+    """Refuse a group larger than the kernels carry BEFORE anything is allocated, exported or mapped (the reference's
+    DeviceDistGraph / DeviceDistFeature take any num_part through a device pointer table, dist_graph.h:114-212; here
+    the pointers are kernel arguments and the first gather of a larger group would return GGMS_ERR_INVALID)."""
+    if int(num_part) > MAX_PARTS:
+        raise ValueError(f"{what}: {num_part} shards, but the kernels carry at most GGMS_MAX_PARTS = {MAX_PARTS} shard "
+                         "pointers (include/ggms.h); use the all-to-all store or a smaller group")
+
 
 def ipc_timeout_s():
     """Deadline of every wait on a peer while the shards are connected (GGMS_IPC_TIMEOUT_S, default 120 s)."""
@@ -141,6 +152,140 @@ def connect_shared(shared_shard, world, rank, dist, group=None, what="shard"):
     return ptrs
 
 
+# ---- which GPUs reach which, and how fast (PartitionSolver::DetectTopo, cuda/dist_graph.cu:684-884) -----------------
+class HipProbeLeaf:
+    """What the link probe needs of the device, on HIP (include/ggms.h, "Link / topology probe")."""
+
+    def __init__(self, device):
+        import ctypes as C
+        from . import ops
+        from ._lib import check, lib
+        self.C, self.ops, self.check, self.lib, self.device = C, ops, check, lib, torch.device(device)
+
+    def peer_access(self, dev, peer):
+        v = self.C.c_int(0)
+        self.check(self.lib().ggms_peer_access(int(dev), int(peer), self.C.byref(v)), "ggms_peer_access")
+        return int(v.value)
+
+    def shard(self, rows, row_words, fill):
+        h = self.ops.SharedShard((rows, row_words), torch.int32, self.device)
+        h.tensor.fill_(fill)
+        return h
+
+    def scratch(self, nbytes):
+        return torch.empty(max(4, nbytes) // 4, dtype=torch.int32, device=self.device)
+
+    def copy_rate(self, dst, src_ptr, nbytes, reps):
+        C, g = self.C, self.C.c_double(0)
+        self.check(self.lib().ggms_link_probe_copy(C.c_void_p(dst.data_ptr()), C.c_void_p(src_ptr), nbytes, reps, C.byref(g),
+                                                   C.c_void_p(torch.cuda.current_stream().cuda_stream)), "ggms_link_probe_copy")
+        return g.value
+
+    def gather_rate(self, out, part_ptrs, rows_per_part, row_bytes, num_rows, seed, reps, index_ws):
+        C, g = self.C, self.C.c_double(0)
+        tab = self.ops.PartTable(part_ptrs)
+        self.check(self.lib().ggms_link_probe_gather(C.c_void_p(out.data_ptr()), tab.ptr(), len(part_ptrs), rows_per_part,
+                                                     row_bytes, num_rows, seed, reps, C.c_void_p(index_ws.data_ptr()),
+                                                     C.byref(g), C.c_void_p(torch.cuda.current_stream().cuda_stream)),
+                   "ggms_link_probe_gather")
+        return g.value
+
+    def first_word(self, t):
+        return int(t[0].item())
+
+
+def peer_access_preflight(world, rank, dist, device_index, leaf, group=None):
+    """hipDeviceCanAccessPeer for every pair of the group's GPUs (cudaDeviceCanAccessPeer, dist_graph.cu:812-818),
+    BEFORE any shard is built: rank r asks for its own row, the rows are gathered, every rank holds the same matrix
+    and takes the same turn.  Ranks that share a device (one-GPU rehearsal) reach each other by definition.
+    -> {"devices": [device index per rank], "can_access": [[0/1]], "refused": [[reader, owner], ...]}"""
+    devs = [None] * world
+    if world > 1:
+        with_deadline(lambda: dist.all_gather_object(devs, int(device_index), group=group),
+                      f"rank {rank} of {world} exchanging device indices for the peer-access preflight")
+    else:
+        devs = [int(device_index)]
+    row = [1 if devs[r] == devs[rank] else leaf.peer_access(devs[rank], devs[r]) for r in range(world)]
+    rows = [None] * world
+    if world > 1:
+        with_deadline(lambda: dist.all_gather_object(rows, row, group=group),
+                      f"rank {rank} of {world} exchanging the peer-access rows")
+    else:
+        rows = [row]
+    refused = [[i, j] for i in range(world) for j in range(world) if i != j and not rows[i][j]]
+    return {"devices": devs, "can_access": rows, "refused": refused}
+
+
+def link_probe(world, rank, dist, leaf, probe_bytes=128 << 20, row_bytes=512, reps=3, group=None):
+    """What a rank's xGMI links carry, measured the way the product uses them (one process per GPU, peers read in place
+    through hipIpc mappings) -- the one-process-per-GPU form of DetectTopo_child's timed 128-MiB peer copies
+    (dist_graph.cu:822-848).  Every rank publishes a probe_bytes buffer and maps its peers'; then
+      per pair, ALONE on the node (everybody else waits at a barrier): a timed copy out of the mapping
+        (hipMemcpyAsync, the copy engines) and the feature store's own gather kernel reading random row_bytes rows
+        of it (ggms_link_probe_gather);
+      all ranks at once, each from ALL its peers (slots modulo the peers, what the `peer` / `hybrid` stores do every
+        batch): the rate a GPU's inbound links sustain together while its outbound links serve the others.
+    Matrices are [reader][owner]; the diagonal is the reader's own HBM through the same code.  Returns the same dict
+    on every rank.  A refused mapping raises PeerConnectError on every rank (connect_shared)."""
+    import time
+    t0 = time.perf_counter()
+    rows_per_part = probe_bytes // row_bytes
+    nbytes = rows_per_part * row_bytes
+    holder = leaf.shard(rows_per_part, row_bytes // 4, rank + 1)
+    try:
+        ptrs = connect_shared(holder, world, rank, dist, group, what="link-probe buffer")
+        dst = leaf.scratch(nbytes)
+        num_rows = 2 * rows_per_part  # rows gathered per launch: twice the buffer's rows, drawn at random
+        out = leaf.scratch(num_rows * row_bytes)
+        index_ws = leaf.scratch(num_rows * 4)
+
+        def barrier():
+            if world > 1:
+                dist.barrier(group=group)
+
+        copy_row, gather_row, wrong = [0.0] * world, [0.0] * world, []
+        barrier()
+        for reader in range(world):
+            for owner in range(world):
+                if reader == rank:
+                    copy_row[owner] = leaf.copy_rate(dst, ptrs[owner], nbytes, reps)
+                    if leaf.first_word(dst) != owner + 1:  # the mapping reads the owner's memory, not somebody else's
+                        wrong.append(owner)
+                    gather_row[owner] = leaf.gather_rate(out, [ptrs[owner]], rows_per_part, row_bytes, num_rows,
+                                                         17 * reader + owner, reps, index_ws)
+                barrier()
+        peers = [ptrs[p] for p in range(world) if p != rank]
+        inbound = leaf.gather_rate(out, peers, rows_per_part, row_bytes, num_rows, 1000 + rank, reps, index_ws) if peers else 0.0
+        barrier()  # nobody unmaps a buffer a peer may still be reading
+        mine = {"copy": copy_row, "gather": gather_row, "inbound": inbound, "wrong": wrong}
+        rows = [None] * world
+        if world > 1:
+            with_deadline(lambda: dist.all_gather_object(rows, mine, group=group),
+                          f"rank {rank} of {world} collecting the link-probe rows")
+        else:
+            rows = [mine]
+    finally:
+        holder.close()
+    bad = [[r, o] for r in range(world) for o in rows[r]["wrong"]]
+    if bad:
+        raise PeerConnectError(f"link probe: mappings that do not show their owner's memory [reader, owner]: {bad}")
+    remote = [rows[r]["gather"][o] for r in range(world) for o in range(world) if o != r]
+    return {
+        "method": "one rank per GPU; every rank publishes a buffer (hipIpc) and maps its peers'; per pair alone on the "
+                  "node: hipMemcpyAsync out of the mapping, and the feature store's gather kernel "
+                  "(ggms_gather_scatter_partition, 16-B nt loads) on random rows of it; then all ranks at once, each from "
+                  "all its peers (slots modulo the peers); matrices are [reader][owner], the diagonal is local HBM",
+        "probe_bytes": nbytes, "row_bytes": row_bytes, "rows_per_launch": num_rows, "reps": reps,
+        "per_pair_copy_GBps": [r["copy"] for r in rows],
+        "per_pair_gather_GBps": [r["gather"] for r in rows],
+        "inbound_all_peers_gather_GBps": [r["inbound"] for r in rows],
+        "inbound_all_peers_min_GBps": min((r["inbound"] for r in rows), default=0.0) if world > 1 else None,
+        "per_pair_gather_min_GBps": min(remote) if remote else None,
+        "per_pair_gather_max_GBps": max(remote) if remote else None,
+        "seconds": round(time.perf_counter() - t0, 2),
+    }
+
+
 class HipLeaf:
     """The device operators the store needs, on HIP (xgnn_amd.ops)."""
 
@@ -209,6 +354,8 @@ class FeatureShards:
         slots -- slot s < R is read from it, slot s >= R from shard (s - R) % world at row (s - R) // world."""
         assert mode in ("peer", "a2a")
         assert replica is None or mode == "peer", "hot-row replication rides on the peer gather"
+        if mode == "peer":
+            check_num_parts(world, "FeatureShards(peer)")
         self.shard, self.table, self.world, self.rank, self.mode = shard, table, world, rank, mode
         self.dist, self.group, self.host_feat, self.replica = dist, group, host_feat, replica
         if mode == "peer" and host_feat is None and table is not None:
@@ -350,36 +497,44 @@ def num_cache_node_for(indptr, fraction):
     return int(np.searchsorted(indptr[:-1], cache_edge, side="left"))
 
 
-def topology_shards(indptr, indices, num_part, num_cache_node, rows_per_step=1 << 24, only=None):
+def topology_shards(indptr, indices, num_part, num_cache_node, edges_per_step=1 << 26, only=None):
     """_DatasetPartition (dist_graph.cu:228-272) on the GPU: shard p = the CSR of the nodes v = p (mod num_part),
     v < num_cache_node, at rows v // num_part.  indptr / indices: int32 device tensors holding the uint32 CSR.
     Returns (part_indptr, part_indices): two lists of int32 device tensors -- the shards of every worker (one process
-    that plays all of them: logical shards), or with only=p just worker p's own."""
+    that plays all of them: logical shards), or with only=p just worker p's own.
+    Scratch is bounded by EDGES, not rows: a block moves at most about edges_per_step neighbour ids (20 B of
+    temporaries each: 1.3 GB at the default) whatever the degrees are, and a shard costs two host syncs in all."""
     dev = indptr.device
     P = int(num_part)
     pip, pix = [], []
     for p in (range(P) if only is None else [int(only)]):
-        nodes = torch.arange(p, num_cache_node, P, dtype=torch.int64, device=dev)
+        nodes = torch.arange(p, max(p, int(num_cache_node)), P, dtype=torch.int64, device=dev)
+        n = nodes.numel()
         start = indptr[nodes].to(torch.int64) & 0xFFFFFFFF
-        end = indptr[nodes + 1].to(torch.int64) & 0xFFFFFFFF
-        deg = end - start
-        ip = torch.zeros(nodes.numel() + 1, dtype=torch.int64, device=dev)
-        torch.cumsum(deg, 0, out=ip[1:])
-        total = int(ip[-1].item())
+        ip = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+        if n:
+            torch.cumsum((indptr[nodes + 1].to(torch.int64) & 0xFFFFFFFF) - start, 0, out=ip[1:])
+        del nodes
+        total = int(ip[-1].item())  # host sync 1: the shard's edge count sizes its allocation
         ix = torch.empty(max(total, 1), dtype=torch.int32, device=dev)
-        # rows in blocks: the (row -> edge slots) expansion needs 8-byte temporaries per edge
-        for lo in range(0, nodes.numel(), rows_per_step):
-            hi = min(nodes.numel(), lo + rows_per_step)
-            d = deg[lo:hi]
-            n_e = int((ip[hi] - ip[lo]).item())
-            if n_e == 0:
-                continue
-            # source slot of shard edge k of row j: start[j] + (k - ip[j])
-            shift = torch.repeat_interleave(start[lo:hi] - ip[lo:hi], d)
-            src = torch.arange(int(ip[lo].item()), int(ip[lo].item()) + n_e, dtype=torch.int64, device=dev) + shift
-            ix[int(ip[lo].item()):int(ip[lo].item()) + n_e] = indices[src]
-            del shift, src
+        if total:
+            # block boundaries: the first row whose list starts at or beyond each multiple of edges_per_step
+            targets = torch.arange(1, (total - 1) // edges_per_step + 1, dtype=torch.int64, device=dev) * edges_per_step
+            cuts = torch.unique(torch.cat([torch.zeros(1, dtype=torch.int64, device=dev),
+                                           torch.searchsorted(ip, targets), torch.full((1,), n, dtype=torch.int64, device=dev)]))
+            rows = cuts.tolist()          # host sync 2
+            offs = ip[cuts].tolist()
+            for (lo, hi), (e_lo, e_hi) in zip(zip(rows[:-1], rows[1:]), zip(offs[:-1], offs[1:])):
+                if e_hi == e_lo:
+                    continue
+                # source slot of shard edge k of row j: start[j] + (k - ip[j])
+                src = torch.repeat_interleave(start[lo:hi] - ip[lo:hi], ip[lo + 1:hi + 1] - ip[lo:hi], output_size=e_hi - e_lo)
+                src += torch.arange(e_lo, e_hi, dtype=torch.int64, device=dev)
+                ix[e_lo:e_hi] = indices[src]
+                del src
+        del start
         pip.append(ip.to(torch.int32))  # values < 2^32 kept bit for bit (uint32 in an int32 tensor)
+        del ip
         pix.append(ix)
     return pip, pix
 
@@ -388,21 +543,47 @@ class TopologyShards:
     """This rank's view of the sharded topology (DistGraph, cuda/dist_graph.cu:228-385): it builds shard `rank` of the
     leading num_cache_node nodes, publishes it (two hipIpc allocations: indptr, indices), maps every peer's, and hands
     out a DeviceGraph whose kernels read a peer's list heads and neighbour lists in place over xGMI.  slot: (indptr,
-    indices) tensors of the whole CSR for the nodes beyond num_cache_node (device or registered host memory)."""
+    indices) tensors of the whole CSR for the nodes beyond num_cache_node (device or registered host memory).
 
-    def __init__(self, indptr, indices, world, rank, num_cache_node, dist, slot, group=None):
-        from . import ops
-        pip, pix = topology_shards(indptr, indices, world, num_cache_node, only=rank)
+    Every failure is a verdict of the whole group: a rank that cannot build or allocate its shard (out of memory)
+    still walks through the handle exchange as a FailedShard, so that EVERY rank raises PeerConnectError together
+    instead of the others sitting out a deadline in all_gather_object; whatever this rank did allocate or map before
+    the verdict is released before the exception leaves.  shard_alloc (tests): stands in for ops.SharedShard."""
+
+    def __init__(self, indptr, indices, world, rank, num_cache_node, dist, slot, group=None, shard_alloc=None,
+                 build=None):
+        check_num_parts(world, "TopologyShards")  # before anything is allocated, exported or mapped
+        if shard_alloc is None:
+            from . import ops
+            shard_alloc = ops.SharedShard
         self.holders = []
-        tabs = []
-        for name, t in (("topology indptr shard", pip[0]), ("topology indices shard", pix[0])):
-            h = ops.SharedShard((max(1, t.numel()),), torch.int32, t.device)
-            h.tensor[:t.numel()].copy_(t)
-            self.holders.append(h)
-            tabs.append(connect_shared(h, world, rank, dist, group, what=name))
-        del pip, pix
         self.num_cache_node, self.world, self.rank = int(num_cache_node), world, rank
         self._slot = slot
+        names = ("topology indptr shard", "topology indices shard")
+        failure = None
+        try:
+            pip, pix = (build or topology_shards)(indptr, indices, world, num_cache_node, only=rank)
+            for t in (pip[0], pix[0]):
+                h = shard_alloc((max(1, t.numel()),), torch.int32, t.device)
+                self.holders.append(h)
+                h.tensor[:t.numel()].copy_(t)
+            del pip, pix, t
+        except (RuntimeError, MemoryError) as e:  # torch.cuda.OutOfMemoryError, GgmsError (ggms_device_alloc), ...
+            failure = f"{type(e).__name__}: {str(e)[:200]}"
+            self.close()
+            pip = pix = None
+            if torch.cuda.is_available() and torch.cuda.is_initialized():
+                torch.cuda.empty_cache()
+        tabs = []
+        try:
+            for i, name in enumerate(names):
+                # a failed build takes part in the FIRST exchange with its reason: that exchange raises on every rank
+                shard = FailedShard(failure) if failure is not None else self.holders[i]
+                tabs.append(connect_shared(shard, world, rank, dist, group, what=name))
+        except BaseException:
+            self.close()  # the indptr holder and its peer mappings when the second exchange is the one that failed
+            raise
+        from . import ops
         self.graph = ops.DeviceGraph(None, None, part_indptr=[_Addr(a) for a in tabs[0]] + [slot[0]],
                                      part_indices=[_Addr(a) for a in tabs[1]] + [slot[1]], num_cache_node=num_cache_node)
 

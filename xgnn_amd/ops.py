@@ -323,6 +323,9 @@ class PartTable:
     hand the pointers to their kernels by value, at most GGMS_MAX_PARTS = 8 shards."""
 
     def __init__(self, ptrs, keep=None):
+        if len(ptrs) > 9:  # GGMS_MAX_PARTS shards + the topology's host slot
+            raise ValueError(f"PartTable: {len(ptrs)} pointers, the kernels carry at most GGMS_MAX_PARTS = 8 shards "
+                             "(+ the host slot of a graph view)")
         self.n = len(ptrs)
         self.arr = (C.c_void_p * max(1, self.n))(*[int(p) for p in ptrs])
         self._keep = keep
