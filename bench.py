@@ -442,6 +442,16 @@ def main():
         if preflight["refused"] and args.dist_graph is not None:
             raise SystemExit(f"bench.py: --dist-graph needs P2P access between every pair of GPUs; refused [reader, owner]: "
                              f"{preflight['refused']}")
+    # ---- N > 1: what the xGMI links carry, measured the way the stores use them (ggms_store.link_probe: per pair alone,
+    # then every rank from all its peers at once) -- BEFORE the store is placed: the planned placement sizes its sharded
+    # tail by it (ggms_store.plan_with_links, the role of the reference's PartitionSolver), and the line quotes every
+    # store's xGMI bytes against it.  A few seconds; a refused mapping is a verdict of every rank.
+    xgmi = None
+    if world > 1 and not args.no_xgmi_probe and not preflight["refused"]:
+        try:
+            xgmi = ggms_store.link_probe(world, rank, dist, ggms_store.HipProbeLeaf(dev))
+        except (RuntimeError, MemoryError) as e:  # PeerConnectError: raised on every rank alike
+            xgmi = {"error": f"{type(e).__name__}: {str(e)[:300]}"}
 
     t_start = time.perf_counter()
     if os.environ.get("GGMS_BENCH_VERBOSE"):  # where is a stuck rank?  Python stacks every 2 minutes
@@ -563,8 +573,9 @@ def main():
             keep.update(cache=cache, table=table, ptab=ptab)
 
             def extract(nodes, num_max, out, num_dev, counters):
+                # (a full cache has no misses to count: no counter, no memset node in front of every gather)
                 ops.extract_cached(out, nodes, table, ptab, 0, host_feat, num=num_max, num_dev=num_dev,
-                                   num_miss=counters[0:1])
+                                   num_miss=None if table is None else counters[0:1])
             return extract, keep
         # sharded kinds.  Everything cached and nothing replicated: slot = node id, no table (as on one GPU).
         # Otherwise slots in degree-rank order (hot first); hybrid replicates the first R of them on every GPU.
@@ -572,9 +583,20 @@ def main():
         if kind == "hybrid":
             R = (ggms_store.plan_replication(num_cached, row_bytes, world, int(args.hbm_budget_gb * 1e9))
                  if args.replicate_frac == "auto" else int(num_cached * float(args.replicate_frac)))
+            link_plan = None
+            if args.replicate_frac == "auto" and xgmi and "error" not in xgmi:
+                # the probe's rates: what this GPU's inbound links sustained with every rank pulling from all its peers,
+                # and the same gather kernel on local HBM (the diagonal); capacity: what every GPU can really hold
+                free_b = [None] * world
+                dist.all_gather_object(free_b, int(torch.cuda.mem_get_info(dev)[0]))
+                local = min(xgmi["per_pair_gather_GBps"][r][r] for r in range(world))
+                R, link_plan = ggms_store.plan_with_links(num_cached, row_bytes, world, R, xgmi["inbound_all_peers_min_GBps"],
+                                                          local, int(0.6 * min(free_b)))
             R = min(R, num_cached - world)  # keep a sharded tail
             hybrid_plan.update(replicated_rows=int(R), replicated_fraction=R / max(1, num_cached),
-                               hbm_budget_gb=args.hbm_budget_gb if args.replicate_frac == "auto" else None)
+                               hbm_budget_gb=args.hbm_budget_gb if args.replicate_frac == "auto" else None,
+                               hbm_spent_gb=(R + (num_cached - R + world - 1) // world) * row_bytes / 1e9,
+                               **({"link_plan": link_plan} if link_plan else {}))
         if full and R == 0:
             order, table = torch.arange(N, dtype=torch.int64, device=dev), None
         else:
@@ -638,6 +660,9 @@ def main():
     L = len(fanouts)
     s_samples = [torch.cuda.Stream(device=dev) for _ in range(K)]
     s_extract = s_samples[0] if args.no_overlap else torch.cuda.Stream(device=dev)
+    # the label gather needs the seeds and nothing else of the batch: on a stream of its own it runs beside the sampler
+    # instead of as a small launch between two gathers on the stream that bounds the step (as the engine does)
+    s_label = s_samples[0] if args.no_overlap else torch.cuda.Stream(device=dev)
     slot_free = [None] * NSLOT  # event: the slot's previous extract has finished
 
     # DistAlignedShuffler semantics (dist_shuffler_aligned.cc:37-146): pad to a multiple of world,
@@ -668,13 +693,20 @@ def main():
     host_t = [0.0] * 6
     last_gather = [None]  # completion event of the most recent feature gather (--heavy-after-gather)
 
-    def make_step(extract_fn, counters, acc, seeds_of):
-        """One step of the hot path: sample on the batch's pipeline stream, gather + labels on the extract stream."""
+    def make_step(extract_fn, counters, accs, seeds_of):
+        """One step of the hot path: sample on the batch's pipeline stream (the batch's counts are added to that pipeline's
+        totals there), labels on the label stream, the feature gather -- and nothing else -- on the extract stream."""
         def run_step(step, ev4=None):
             seeds, distinct = seeds_of(step)
             slot = step % NSLOT
             s_sample = s_samples[step % K]
             h0 = time.perf_counter()
+            with torch.cuda.stream(s_label):
+                if slot_free[slot] is not None:
+                    s_label.wait_event(slot_free[slot])
+                ops.extract(labels, seeds, out=out_label[slot][:seeds.numel()])
+                labelled = torch.cuda.Event()
+                labelled.record(s_label)
             with torch.cuda.stream(s_sample):
                 if slot_free[slot] is not None:
                     s_sample.wait_event(slot_free[slot])
@@ -688,6 +720,7 @@ def main():
                 sampled.record(s_sample)
                 if ev4 is not None:
                     ev4[1].record(s_sample)
+                accs[step % K].add_(sampler.counts_slots[slot])  # behind the batch on ITS stream: off the extract stream
             h3 = time.perf_counter()
             with torch.cuda.stream(s_extract):
                 s_extract.wait_event(sampled)
@@ -701,9 +734,8 @@ def main():
                     last_gather[0] = torch.cuda.Event()
                     last_gather[0].record(s_extract)
                 h4 = time.perf_counter()
-                ops.extract(labels, seeds, out=out_label[slot][:seeds.numel()])
+                s_extract.wait_event(labelled)  # the slot is free again when its rows AND its labels are out
                 h5 = time.perf_counter()
-                acc.add_(counts)
                 done = torch.cuda.Event()
                 done.record(s_extract)
                 slot_free[slot] = done
@@ -720,20 +752,22 @@ def main():
         seeds_all = [(s, seeds_distinct(s)) for s in seeds_all]
         # rows by tier: [host misses, remote-shard rows, local-shard rows, replica rows]
         counters = torch.zeros(4, dtype=torch.int64, device=dev)
-        acc = torch.zeros(3 * L + 2, dtype=torch.int64, device=dev)
-        run_step = make_step(extract_fn, counters, acc, lambda s: seeds_all[s])
+        accs = [torch.zeros(3 * L + 2, dtype=torch.int64, device=dev) for _ in range(K)]  # one per sampling pipeline
+        run_step = make_step(extract_fn, counters, accs, lambda s: seeds_all[s])
         log(f"measure: {warmup} warm-up + {repeats} x {steps} steps")
         for s in range(warmup):
             run_step(s)
         barrier()
-        if warmup and int(acc[3 * L + 1].item()):  # the warm-up batches' status words (acc is zeroed before each timed block)
-            raise SystemExit(f"device status {int(acc[3 * L + 1].item())} during warm-up")
+        warm_status = int(sum(a[3 * L + 1] for a in accs).item())  # the warm-up batches' status words (zeroed before each timed block)
+        if warmup and warm_status:
+            raise SystemExit(f"device status {warm_status} during warm-up")
         log("warm-up done")
         blocks = []
         for r in range(repeats):
             ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(steps)]
             barrier()
-            acc.zero_()
+            for a in accs:
+                a.zero_()
             counters.zero_()
             barrier()
             t0 = time.perf_counter()
@@ -741,7 +775,7 @@ def main():
                 run_step(warmup + r * steps + k, ev[k])
             barrier()
             elapsed = time.perf_counter() - t0
-            c = acc.cpu().tolist()
+            c = torch.stack(accs).sum(0).cpu().tolist()
             if c[3 * L + 1]:
                 ops.check_device_status("bench")
                 raise SystemExit(f"device status {c[3 * L + 1]} after a timed block")
@@ -794,7 +828,7 @@ def main():
     elapsed, edges_all = blk["elapsed"], blk["edges_all"]
     edges, rows = blk["edges"], blk["rows"]
     if args.host_profile and rank == 0:
-        names = ["ev0", "sample", "ev1", "extract", "ev2+label", "acc"]
+        names = ["label", "sample", "ev1+acc", "extract", "wait-label", "done"]
         n_all = args.warmup + args.steps * repeats
         print("host enqueue ms/step:", {n: round(1e3 * t / n_all, 4) for n, t in zip(names, host_t)}, file=sys.stderr)
 
@@ -913,11 +947,16 @@ def main():
                             f"seeds DP over {world} GPU(s), feature store: {main_store}"
                             + (f" ({main_plan.get('replicated_fraction', 0):.2f} of the cached rows on every GPU"
                                + (f" under a {args.hbm_budget_gb:g}-GB per-GPU budget" if args.replicate_frac == "auto" else "")
+                               + (" raised by the link probe's bound (xGMI rows arrive while the local rows stream: "
+                                  f"{main_plan['hbm_spent_gb']:.1f} GB spent)"
+                                  if (main_plan.get("link_plan") or {}).get("replicated_rows_chosen", 0)
+                                  > (main_plan.get("link_plan") or {}).get("replicated_rows_budget_plan", 0) else "")
                                + f", the rest sharded over the {world} GPUs)" if main_store == "hybrid" and world > 1 else ""),
                 "global_batch": args.batch * world,
                 "parallelism": f"dp{world}",
                 "streams": "1 (serial)" if args.no_overlap else
-                           f"{K} sampling pipeline(s) (batches in flight, RNG pool consumed in batch order) + 1 extract stream",
+                           f"{K} sampling pipeline(s) (batches in flight, RNG pool consumed in batch order) + 1 extract stream "
+                           "(the feature gather alone) + 1 label stream",
                 "neighbour_skew": args.neighbour_skew,
                 "seeds_distinct_promise": not args.no_distinct_seeds,
                 **({"topology": topo_record} if topo_record else {}),
@@ -962,6 +1001,8 @@ def main():
             "value_over_box": (edges_all / elapsed) / box["d2d_over_guide"] if box and box["d2d_over_guide"] else None,
             "budget": {"budget_s": args.budget_s, "headline_at_s": round(time.perf_counter() - T0, 1)},
         }
+        if xgmi is not None:
+            res["xgmi"] = xgmi
         if preflight is not None:
             res["peer_access"] = {"devices": preflight["devices"], "can_access": preflight["can_access"],
                                   "refused": preflight["refused"],
@@ -990,17 +1031,8 @@ def main():
         log(f"sub-record {name}: {'runs' if ok[0] else 'skipped (budget)'}, {left():.0f} s left")
         return ok[0]
 
-    # ---- N > 1: what the xGMI links carry, measured the way the stores use them (ggms_store.link_probe) ---------------
-    # and next to every sharded store's xgmi bytes the remote time they predict: bytes per GPU and step / inbound rate
-    xgmi = None
-    if world > 1 and not args.no_xgmi_probe and fits("xgmi", 6 + 0.15 * world * world):
-        try:
-            xgmi = ggms_store.link_probe(world, rank, dist, ggms_store.HipProbeLeaf(dev))
-        except (RuntimeError, MemoryError) as e:  # PeerConnectError: raised on every rank alike
-            xgmi = {"error": f"{type(e).__name__}: {str(e)[:300]}"}
-        if res is not None:
-            res["xgmi"] = xgmi
-
+    # ---- N > 1: next to every sharded store's xGMI bytes the remote time they predict: bytes per GPU and step over the
+    # inbound rate the probe measured
     def predict_remote(rec):
         """stores.<kind> + the probe: xgmi bytes one GPU pulls per step over the rate its inbound links sustained when every
         rank pulled from all its peers at once -> the time the remote rows alone need (they overlap the local rows

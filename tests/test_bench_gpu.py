@@ -171,6 +171,28 @@ def test_two_ranks_default_is_the_planned_placement():
     x = d["xgnn_mode"]
     assert "error" not in x, x
     assert x["use_dist_graph"] == 1.0 and x["edges_per_s"] > 0 and 0.2 < x["vs_main_edges_per_s"] < 2.0
+    # the line explains its own xGMI side.  Preflight (hipDeviceCanAccessPeer per pair, before anything
+    # was placed) and the link probe (before the placement was planned: it sizes the sharded tail) in the early headline
+    # already; next to every sharded store the remote time its xgmi bytes predict.  (Two ranks on ONE GPU: the rates are HBM rates, the plumbing is what is tested.)
+    early = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    for line in (early, d):
+        pa = line["peer_access"]
+        assert pa["devices"] == [0, 0] and pa["can_access"] == [[1, 1], [1, 1]] and pa["refused"] == []
+        assert line["box"]["d2d_copy_GBps"] > 500 and line["value_over_box"] > 0
+    assert "error" not in early["xgmi"]  # measured before the store was placed: the early headline carries it already
+    xg = d["xgmi"]
+    assert "error" not in xg, xg
+    for key in ("per_pair_copy_GBps", "per_pair_gather_GBps"):
+        m = xg[key]
+        assert len(m) == 2 and all(len(row) == 2 and all(v > 1.0 for v in row) for row in m), (key, m)
+    assert len(xg["inbound_all_peers_gather_GBps"]) == 2 and xg["inbound_all_peers_min_GBps"] > 1.0
+    assert xg["probe_bytes"] == 128 << 20 and xg["row_bytes"] == 512 and xg["seconds"] < 30
+    for kind in ("peer", "hybrid"):
+        rec = st[kind]
+        assert rec["xgmi_bytes_per_step_per_gpu"] == rec["xgmi_bytes_per_step"] / 2
+        want = rec["xgmi_bytes_per_step_per_gpu"] / (xg["inbound_all_peers_min_GBps"] * 1e9) * 1e3
+        assert abs(rec["predicted_remote_ms_per_step"] - want) <= 1e-9 + 1e-6 * want
+    assert st["replica"]["predicted_remote_ms_per_step"] == 0
 
 
 _BROKEN_IPC = """

@@ -243,11 +243,37 @@ def test_batches_through_topology_shards(ops, P, stype):
 
 
 def test_more_shards_than_the_kernels_carry_is_refused(ops):
-    """GGMS_MAX_PARTS = 8 shard pointers travel in the kernel arguments; nine are an argument error, not a fault."""
+    """GGMS_MAX_PARTS = 8 shard pointers travel in the kernel arguments; nine are an argument error, not a fault -- in the
+    Python wrapper before anything is built (ops.PartTable), and in the library for a caller that has no wrapper."""
     ip, ix = powerlaw_csr(2000, mean_deg=8, seed=5)
     t_ip, t_ix = P_dev(ip), P_dev(ix)
     parts = [oracle.partition_graph(ip, ix, r, 9, 900) for r in range(9)]
-    g = ops.DeviceGraph(None, None, part_indptr=[P_dev(p[0]) for p in parts] + [t_ip],
+    with pytest.raises(ValueError, match="GGMS_MAX_PARTS"):
+        ops.DeviceGraph(None, None, part_indptr=[P_dev(p[0]) for p in parts] + [t_ip],
                         part_indices=[P_dev(p[1]) for p in parts] + [t_ix], num_cache_node=900)
+    g = ops.DeviceGraph(None, None, part_indptr=[P_dev(p[0]) for p in parts[:8]] + [t_ip],
+                        part_indices=[P_dev(p[1]) for p in parts[:8]] + [t_ix], num_cache_node=900)
+    g.c.num_part = 9  # what a C caller could hand over: refused before any table entry is read
     with pytest.raises(RuntimeError, match="at most 8"):
         ops.sample_khop3(g, P_dev(np.arange(10, dtype=np.uint32)), 3, ops.random_states(256, 1))
+
+
+def test_a_device_pointer_table_is_an_argument_error(ops):
+    """the shard pointer tables became HOST arrays with ABI 3; a caller still passing a device array must get
+    GGMS_ERR_INVALID, not a host dereference of device memory."""
+    import ctypes as C
+    import torch
+    from xgnn_amd import _lib
+    dev = torch.device("cuda", 0)
+    src = torch.arange(64 * 8, dtype=torch.float32, device=dev).reshape(64, 8)
+    dev_table = torch.tensor([src.data_ptr()], dtype=torch.int64, device=dev)  # the pre-ABI-3 form
+    idx = torch.arange(16, dtype=torch.int32, device=dev)
+    out = torch.zeros((16, 8), dtype=torch.float32, device=dev)
+    rc = _lib.lib().ggms_gather_scatter_partition(C.c_void_p(out.data_ptr()), C.c_void_p(dev_table.data_ptr()), 1,
+                                                  C.c_void_p(idx.data_ptr()), None, 16, None, 8, 0, None)
+    assert rc == -1 and b"HOST arrays" in _lib.lib().ggms_last_error()
+    tab = ops.PartTable([src.data_ptr()])
+    assert _lib.lib().ggms_gather_scatter_partition(C.c_void_p(out.data_ptr()), tab.ptr(), 1, C.c_void_p(idx.data_ptr()), None,
+                                                    16, None, 8, 0, None) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(out, src[:16])

@@ -244,3 +244,25 @@ def test_topology_shards_blocks_are_bounded_by_edges():
                                else np.zeros(0, np.int32))
                     assert np.array_equal(pip[p].numpy(), want_ip.astype(np.int32)), (P, ncn, step, p)
                     assert np.array_equal(pix[p].numpy()[:want_ip[-1]], want_ix), (P, ncn, step, p)
+
+
+def test_plan_with_links_keeps_xgmi_off_the_critical_path():
+    """The placement after the link probe (PartitionSolver's role): the sharded tail is sized so that a batch's remote
+    rows arrive while its local rows stream; never less replication than the budget plan, never more than fits."""
+    from xgnn_amd.ggms_store import plan_replication, plan_with_links
+    n, rb, P = 111_059_956, 512, 8
+    budget = plan_replication(n, rb, P, int(48e9))
+    r, rec = plan_with_links(n, rb, P, budget, inbound_GBps=400.0, local_GBps=2500.0, capacity_bytes=int(200e9))
+    f = 0.8 * 400 / 2900
+    assert abs(rec["remote_row_share_the_links_hide"] - f) < 1e-12 and r == rec["replicated_rows_chosen"] >= budget
+    tail = (n - r) / n
+    assert tail * (P - 1) / P <= f + 1e-7 and tail * (P - 1) / P > f - 1e-3  # the bound binds: links slower than the budget plan assumes
+    # fast links: the budget plan already hides the remote rows -- nothing changes
+    r2, rec2 = plan_with_links(n, rb, P, budget, inbound_GBps=2000.0, local_GBps=2500.0, capacity_bytes=int(200e9))
+    assert r2 == budget and rec2["replicated_rows_link_plan"] < budget
+    # capacity binds: no more replica than the GPU holds beside its share of the tail
+    r3, rec3 = plan_with_links(n, rb, P, budget, inbound_GBps=50.0, local_GBps=2500.0, capacity_bytes=int(50e9))
+    assert r3 == rec3["replicated_rows_capacity"] == plan_replication(n, rb, P, int(50e9)) < rec3["replicated_rows_link_plan"]
+    # no probe (or one GPU): the budget plan
+    assert plan_with_links(n, rb, P, budget, None, None, int(200e9)) == (budget, None)
+    assert plan_with_links(n, rb, 1, n, 400.0, 2500.0, int(200e9)) == (n, None)

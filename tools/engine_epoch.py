@@ -110,9 +110,11 @@ def main_staged_host(a):
            "batch_size": a.batch_size, "num_epoch": 1, "_cache_policy": sam.cache_policies["degree"],
            "cache_percentage": a.cache_percentage, "max_sampling_jobs": 10, "max_copying_jobs": 1, "omp_thread_num": threads,
            "num_layer": len(a.fanout), "num_hidden": 256, "lr": 0.003, "dropout": 0.5, "num_fanout": len(a.fanout),
-           "fanout": a.fanout, "num_worker": 1, "seed": a.seed, "staged_serial_steps": warm + n_serial,
-           # batches are enqueued exactly when asked for: a stretch's wall clock then covers its own batches only
-           "lookahead": 0}
+           "fanout": a.fanout, "num_worker": 1, "seed": a.seed,
+           # the engine counts the batches it ENQUEUES: with the default look-ahead (2 batches beyond the one asked for) the
+           # serial stretch's per-phase items are still exactly its own, and the overlapped stretch is measured in steady
+           # state (its wall clock enqueues as many batches as it hands out)
+           "staged_serial_steps": warm + n_serial}
     t0 = time.perf_counter()
     sam.config(cfg)
     sam.data_init()
@@ -121,6 +123,7 @@ def main_staged_host(a):
     t_init = time.perf_counter() - t0
     steps = sam.num_local_step()
     assert steps >= 2 * warm + n_serial + n_over, "train set too small for the staged-host stretches"
+    warm2 = warm + 2 if steps >= 2 * warm + n_serial + n_over + 2 else warm  # past the batches enqueued ahead in serial mode
     out = {"arch": "arch6, 1 worker, gpu_extract off", "cache_percentage": a.cache_percentage, "host_threads": threads,
            "init_s": t_init}
 
@@ -144,7 +147,7 @@ def main_staged_host(a):
                      "effective_GBps": miss / (g + c + m) / 1e9 if g + c + m else None,
                      "phase_ms_per_step": {"cpu_gather": g / n_serial * 1e3, "h2d": c / n_serial * 1e3,
                                            "combine_miss": m / n_serial * 1e3, "combine_cache": h / n_serial * 1e3}}
-    stretch(warm)
+    stretch(warm2)
     wall, item = stretch(n_over)
     miss, g = item(sam.kLogL1MissBytes), item(46)
     out["overlapped"] = {"steps": n_over, "ms_per_step": wall / n_over * 1e3, "miss_MB_per_step": miss / n_over / 1e6,
@@ -173,9 +176,12 @@ def main_arch6(a):
         cfg["replicate_percentage"] = a.replicate_percentage
     if a.use_dist_graph > 0:
         cfg["use_dist_graph"] = a.use_dist_graph
+    out_dir = tempfile.mkdtemp(prefix="ggms_engine_")
+    # data_init probes the node's topology in a forked child (P2P reachability + a timed 128-MiB copy per GPU pair,
+    # engine.cc:DetectTopo <- PartitionSolver::DetectTopo): keep its file where this script can read it back
+    os.environ.setdefault("SAMGRAPH_TOPO_FILE", os.path.join(out_dir, "detect_topo"))
     sam.config(cfg)
     sam.data_init()  # host only: the GPUs are first touched in the workers
-    out_dir = tempfile.mkdtemp(prefix="ggms_engine_")
     pids = []
     for w in range(W):
         pid = os.fork()
@@ -219,7 +225,25 @@ def main_arch6(a):
            "sample_edges_per_s": sum(r["edges"] / r["sample_s"] for r in recs if r["sample_s"]),
            "feature_GBps": sum(r["feature_bytes"] / r["copy_s"] / 1e9 for r in recs if r["copy_s"]),
            "feature_bytes": sum(r["feature_bytes"] for r in recs), "init_s": max(r["init_s"] for r in recs)}
+    out["topology"] = read_topology(os.environ["SAMGRAPH_TOPO_FILE"], W)
     print(json.dumps(out), flush=True)
+
+
+def read_topology(path, workers):
+    """The engine's probe file (the reference's format) -> {"p2p": [[0/1]], "copy_GBps": [[..]]} over the workers' GPUs,
+    [reader][owner]; None when the engine did not probe (one worker, the one-GPU rehearsal hook, a failed probe)."""
+    import ctypes as C
+    from xgnn_amd import _lib
+    if not os.path.exists(path):
+        return None
+    t = _lib.Topology()
+    if _lib.lib().ggms_topology_read_host(C.byref(t), path.encode()) != 0:
+        return None
+    n = min(workers, t.num_device)
+    return {"p2p": [[int(t.can_access[i][j]) for j in range(n)] for i in range(n)],
+            "copy_GBps": [[round(float(t.copy_GBps[i][j]), 1) for j in range(n)] for i in range(n)],
+            "what": "engine.cc:DetectTopo (forked probe child at data_init): hipDeviceCanAccessPeer and a timed 128-MiB "
+                    "hipMemcpyAsync INTO row FROM column; the diagonal is a local copy counted read + write"}
 
 
 if __name__ == "__main__":

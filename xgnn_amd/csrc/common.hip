@@ -59,6 +59,27 @@ int raise_dynamic_lds(const void *func, size_t bytes, const char *who) {
   return GGMS_OK;
 }
 
+bool host_readable_table(const void *table, const char *what) {
+  static thread_local const void *last_ok[2] = {nullptr, nullptr}; // the hot loop hands over the same tables every batch
+  if (table == last_ok[0] || table == last_ok[1]) return true;
+  struct Remember {
+    const void *t;
+    bool ok = true;
+    ~Remember() { if (ok) { last_ok[1] = last_ok[0]; last_ok[0] = t; } }
+  } remember{table};
+  hipPointerAttribute_t a;
+  if (hipPointerGetAttributes(&a, table) != hipSuccess) { // an ordinary host pointer the runtime has never seen
+    (void)hipGetLastError();
+    return true;
+  }
+  if (a.type == hipMemoryTypeDevice) {
+    set_error("%s is a DEVICE pointer: since ABI 3 the shard pointer tables are HOST arrays (include/ggms.h)", what);
+    remember.ok = false;
+    return false;
+  }
+  return true;
+}
+
 std::atomic<long long> &debug_knob_word(int knob) {
   static std::atomic<long long> v[GGMS_DEBUG_NUM_KNOBS] = {{-1}, {-1}, {-1}};
   return v[knob];

@@ -557,6 +557,7 @@ bool Engine::ShufflerNext(Batch *b, hipStream_t copy_stream) {
   static const bool sanity = getenv("SAMGRAPH_SANITY_CHECK") != nullptr; // run_config.cc:126-128
   if (sanity && cfg.arch == kArch1) SanityCheckBatch(shuf_host_.data() + global_data_offset_ + offset, size);
   SAM_HIP(hipMemcpyAsync(b->output_nodes, shuf_dev_ + offset, size * 4, hipMemcpyDeviceToDevice, copy_stream)); // Copy1D
+  SAM_HIP(hipEventRecord(b->ev_seeds, copy_stream)); // the label gather needs the seeds and nothing else of the batch
   return true;
 }
 
@@ -651,6 +652,7 @@ void Engine::SampleInit(int worker_id, const std::string &ctx) {
   SAM_HIP(hipSetDevice(device_));
   SAM_HIP(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
   SAM_HIP(hipStreamCreateWithFlags(&stream_extract_, hipStreamNonBlocking));
+  SAM_HIP(hipStreamCreateWithFlags(&stream_label_, hipStreamNonBlocking));
   UploadGraph();
   ShufflerInit();
   const uint32_t L = (uint32_t)cfg.fanout.size();
@@ -928,6 +930,7 @@ void Engine::TrainInit(int worker_id, const std::string &ctx) {
     SAM_HIP(hipHostMalloc((void **)&b->counts, (3 * L + 8) * 8));
     std::memset(b->counts, 0, (3 * L + 8) * 8);
     SAM_HIP(hipEventCreateWithFlags(&b->ev_seeds, hipEventDisableTiming));
+    SAM_HIP(hipEventCreateWithFlags(&b->ev_label, hipEventDisableTiming));
     SAM_HIP(hipEventCreate(&b->ev_start));
     SAM_HIP(hipEventCreate(&b->ev_sampled));
     SAM_HIP(hipEventCreate(&b->ev_xstart));
@@ -960,6 +963,7 @@ void Engine::Shutdown() {
     if (P.stream) (void)hipStreamSynchronize(P.stream);
   if (stream_) (void)hipStreamSynchronize(stream_);
   if (stream_extract_) (void)hipStreamSynchronize(stream_extract_);
+  if (stream_label_) (void)hipStreamSynchronize(stream_label_);
 }
 
 // ------------------------------------------------------------------ hot loop
@@ -1041,8 +1045,13 @@ bool Engine::EnqueueOne(bool background) {
   SAM_HIP(hipStreamWaitEvent(xs, b->ev_sampled, 0));
   SAM_HIP(hipEventRecord(b->ev_xstart, xs)); // the extract's own start: behind the previous batch's extract on xs
   const bool mock = ds.feat_mask != 0xffffffffu; // SAMGRAPH_EMPTY_FEAT: host rows are node & mask
+  // DoGPULabelExtract (dist_loops.cc:938-974) depends on the seeds only: on a stream of its own it runs while the batch
+  // is still being sampled, instead of as a small launch between two gathers of the stream that bounds the step
+  SAM_HIP(hipStreamWaitEvent(stream_label_, b->ev_seeds, 0));
+  SAM_GGMS(ggms_extract(b->label, label_src_, b->output_nodes, b->num_seeds, 1, GGMS_I64, stream_label_));
+  SAM_HIP(hipEventRecord(b->ev_label, stream_label_));
   if (StagedHostTier()) {
-    StagedExtract(b, xs);
+    StagedExtract(b, ss, xs);
   } else if (cfg.UseGPUCache() && (mock || num_replica_)) { // every tier in one gather; rows per tier counted
     SAM_HIP(hipMemsetAsync(n_miss, 0, 4 * 8, xs)); // {host, remote shard, local shard, replica} = counts[3L+2 .. 3L+5]
     ggms_feature_tiers_t tiers{};
@@ -1070,8 +1079,7 @@ bool Engine::EnqueueOne(bool background) {
   }
   if (node_access_dev_) // Profiler::LogNodeAccess (profiler.cc:570-575): visits per node, counted on the device
     SAM_GGMS(ggms_count_nodes(node_access_dev_, b->input_nodes, max_unique_, n_in, xs));
-  // DoGPULabelExtract, dist_loops.cc:938-974
-  SAM_GGMS(ggms_extract(b->label, label_src_, b->output_nodes, b->num_seeds, 1, GGMS_I64, xs));
+  SAM_HIP(hipStreamWaitEvent(xs, b->ev_label, 0)); // the batch is complete when its labels are, too
   SAM_HIP(hipMemcpyAsync(b->counts, b->counts_dev, (3 * L + 8) * 8, hipMemcpyDeviceToHost, xs));
   SAM_HIP(hipEventRecord(b->ev_done, xs));
   {
@@ -1135,7 +1143,7 @@ void Engine::HostGatherRows(char *rows, const uint32_t *ids, size_t first, size_
   });
 }
 
-void Engine::StagedExtract(Batch *b, hipStream_t xs) {
+void Engine::StagedExtract(Batch *b, hipStream_t ss, hipStream_t xs) {
   const uint32_t L = (uint32_t)cfg.fanout.size();
   const size_t row_bytes = ds.feat_dim * ggms_dtype_bytes(ds.feat_dtype);
   if (!host_team_) {
@@ -1151,18 +1159,19 @@ void Engine::StagedExtract(Batch *b, hipStream_t xs) {
   auto since = [](clk::time_point t) { return std::chrono::duration<double>(clk::now() - t).count(); };
   double t_index = 0, t_ids = 0, t_gather = 0, t_copy = 0, t_comb_miss = 0, t_comb_hit = 0;
   auto t0 = clk::now();
-  // 0. split (GetMissCacheIndex) behind the sampler, sizes to the host: wait 1
+  // 0. split (GetMissCacheIndex) behind the sampler ON THE BATCH'S SAMPLING STREAM, sizes to the host: wait 1.  The
+  // extract stream may still be copying the previous batch's last chunks down -- the cores must not wait for that
   if (have_cache)
     SAM_GGMS(ggms_get_miss_cache_index_dev(cache_table_, b->input_nodes, max_unique_, n_in, b->miss_src, b->miss_dst, n_miss,
                                            b->hit_src, b->hit_dst, n_hit, b->idx_ws,
-                                           ggms_cache_index_workspace_bytes(max_unique_), xs));
-  SAM_HIP(hipMemcpyAsync(b->counts, b->counts_dev, (3 * L + 8) * 8, hipMemcpyDeviceToHost, xs));
-  SAM_HIP(hipStreamSynchronize(xs));
+                                           ggms_cache_index_workspace_bytes(max_unique_), ss));
+  SAM_HIP(hipMemcpyAsync(b->counts, b->counts_dev, (3 * L + 8) * 8, hipMemcpyDeviceToHost, ss));
+  SAM_HIP(hipStreamSynchronize(ss));
   const size_t num_input = b->counts[3 * L];
   size_t num_miss = have_cache ? b->counts[3 * L + 2] : num_input, num_hit = have_cache ? b->counts[3 * L + 3] : 0;
   if (!have_cache) { // every row comes from the host tier: the counters say so too
     b->counts[3 * L + 2] = num_input;
-    SAM_HIP(hipMemcpyAsync(n_miss, b->counts + 3 * L + 2, 8, hipMemcpyHostToDevice, xs));
+    SAM_HIP(hipMemcpyAsync(n_miss, b->counts + 3 * L + 2, 8, hipMemcpyHostToDevice, ss));
   }
   SAM_CHECK(num_miss + num_hit == num_input, "CHECK_EQ(num_miss + num_cache, num_input), dist_loops.cc:1047");
   t_index = since(t0);
@@ -1170,8 +1179,9 @@ void Engine::StagedExtract(Batch *b, hipStream_t xs) {
   // 1. miss ids to the host (DoCacheIdCopyToCPU / DoIdCopy): wait 2 -- the hit rows are combined meanwhile
   const uint32_t *ids_dev = have_cache ? b->miss_src : b->input_nodes;
   t0 = clk::now();
-  if (num_miss) SAM_HIP(hipMemcpyAsync(b->miss_ids_host, ids_dev, num_miss * 4, hipMemcpyDeviceToHost, xs));
-  SAM_HIP(hipEventRecord(b->ev_ids, xs));
+  if (num_miss) SAM_HIP(hipMemcpyAsync(b->miss_ids_host, ids_dev, num_miss * 4, hipMemcpyDeviceToHost, ss));
+  SAM_HIP(hipEventRecord(b->ev_ids, ss));
+  SAM_HIP(hipStreamWaitEvent(xs, b->ev_ids, 0)); // the extract stream's work of this batch starts behind the split
   auto combine_hits = [&] { // CombineCacheData
     if (!num_hit) return;
     if (num_cache_part_ == 0)

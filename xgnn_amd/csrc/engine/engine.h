@@ -152,6 +152,7 @@ struct Batch {
   void *miss_rows_host = nullptr;   // hipHostMalloc (pinned): CPU-gathered miss rows, copied down chunk by chunk
   uint32_t *miss_ids_host = nullptr; // hipHostMalloc
   hipEvent_t ev_ids = nullptr;       // the miss ids have reached the host
+  hipEvent_t ev_label = nullptr;     // the labels of the batch are gathered
 };
 
 class Engine {
@@ -206,7 +207,7 @@ class Engine {
   // `gpu_extract` off (SGNN mode of arch6): miss ids -> host, CPU gather into pinned memory, async H2D, combine
   // (a partial cache: its table exists; no cache at all: every row is a miss.  A FULL cache has no table and no misses.)
   bool StagedHostTier() const { return cfg.arch == kArch6 && !cfg.gpu_extract && (cache_table_ != nullptr || !cfg.UseGPUCache()); }
-  void StagedExtract(Batch *b, hipStream_t xs);
+  void StagedExtract(Batch *b, hipStream_t ss, hipStream_t xs);
   void HostGatherRows(char *rows, const uint32_t *ids, size_t first, size_t count); // ExtractMissData on the host team
   std::unique_ptr<class Team> host_team_;
   size_t staged_batches_ = 0;
@@ -227,7 +228,8 @@ class Engine {
   bool data_ready_ = false, sample_ready_ = false, train_ready_ = false, shutdown_ = false;
   int worker_id_ = 0, device_ = 0;
   hipStream_t stream_ = nullptr;         // shuffle + sampling (latency-bound)
-  hipStream_t stream_extract_ = nullptr; // feature / label gather (HBM-bound): overlaps the next batch's sampling
+  hipStream_t stream_extract_ = nullptr; // feature gather (HBM-bound): overlaps the next batch's sampling
+  hipStream_t stream_label_ = nullptr;   // label gather: needs the seeds only, runs beside the sampler
   // device graph
   uint32_t *d_indptr_ = nullptr, *d_indices_ = nullptr;
   std::vector<void *> part_indptr_, part_indices_; // P+1 entries (slot P = host CSR)

@@ -153,6 +153,7 @@ static inline bool part_ptrs(const void *const *parts, uint32_t num_part, PartPt
     set_error("extract: num_part %u (at most %u shards; `parts` is a HOST array of num_part device pointers)", num_part, kMaxParts);
     return false;
   }
+  if (!host_readable_table(parts, "`parts`")) return false;
   for (uint32_t p = 0; p < n; ++p) out.p[p] = (const char *)parts[p];
   return true;
 }

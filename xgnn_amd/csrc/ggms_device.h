@@ -144,6 +144,11 @@ struct GraphView {
   }
 };
 
+// The shard pointer tables of the ABI are HOST arrays since ABI 3 (they were device arrays before): a caller that still
+// hands over a device array would have this library dereference device memory on the host.  One attribute query per
+// call (host side) turns that into an argument error.  common.hip
+bool host_readable_table(const void *table, const char *what);
+
 // host side: NULL + an error message if the graph has more shards than the kernels carry
 inline bool view_of(const ggms_graph_t *g, GraphView &v) {
   v = GraphView{};
@@ -158,6 +163,9 @@ inline bool view_of(const ggms_graph_t *g, GraphView &v) {
               g->num_part, kMaxParts);
     return false;
   }
+  if (!host_readable_table(g->part_indptr, "ggms_graph_t.part_indptr") ||
+      !host_readable_table(g->part_indices, "ggms_graph_t.part_indices"))
+    return false;
   for (uint32_t p = 0; p < g->num_part; ++p) {
     v.pip.p[p] = g->part_indptr[p];
     v.pix.p[p] = g->part_indices[p];

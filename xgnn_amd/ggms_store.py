@@ -470,6 +470,31 @@ def plan_replication(num_cached, row_bytes, world, hbm_budget_bytes):
     return int(max(0, min(num_cached, r)))
 
 
+def plan_with_links(num_cached, row_bytes, world, r_budget, inbound_GBps, local_GBps, capacity_bytes, margin=0.8):
+    """The placement once the links have been MEASURED (ggms_store.link_probe) -- what the reference's PartitionSolver
+    does with its bandwidth matrix (dist_graph.cu:40-222: replicas until no GPU fetches more than its links carry).
+    One gather kernel streams a batch's local rows from HBM and its remote rows over xGMI at the same time; the remote
+    part stays off the critical path while  remote_bytes / inbound <= local_bytes / local,  i.e. while the share of a
+    batch's rows that is remote stays below  f = inbound / (inbound + local)  (`margin` of it is used).  With the sharded
+    tail holding a fraction t of the (uniformly requested) slots, (world - 1) / world of its requests are remote:
+    t <= f * world / (world - 1).  The replica is the LARGER of the budget plan's (r_budget, plan_replication) and the
+    one this bound asks for, capped by what the GPU can really hold (capacity_bytes).
+    -> (R, record)"""
+    if world <= 1 or not inbound_GBps or not local_GBps:
+        return int(r_budget), None
+    f = margin * inbound_GBps / (inbound_GBps + local_GBps)
+    tail = min(1.0, f * world / (world - 1))
+    r_link = min(int(num_cached), int(np.ceil(num_cached * (1.0 - tail))))
+    r_cap = plan_replication(num_cached, row_bytes, world, int(capacity_bytes))
+    r = int(min(max(int(r_budget), r_link), r_cap))
+    return r, {"inbound_GBps": inbound_GBps, "local_gather_GBps": local_GBps, "margin": margin,
+               "remote_row_share_the_links_hide": f, "sharded_tail_max_fraction": tail,
+               "replicated_rows_budget_plan": int(r_budget), "replicated_rows_link_plan": r_link,
+               "replicated_rows_capacity": int(r_cap), "replicated_rows_chosen": r,
+               "rule": "remote share <= margin * inbound / (inbound + local): the remote rows of a batch arrive while its "
+                       "local rows stream; R = min(max(budget plan, link plan), capacity)"}
+
+
 def shard_rows(feat_rows_fn, rank_list, num_cached, world, rank, dim, dtype, device, shared=False):
     """Build this rank's shard: row k = feature of node rank_list[rank + k * world] (partition_feature).
     feat_rows_fn(node_ids, out) fills `out` with the rows of `node_ids`.  shared=True allocates an
