@@ -660,9 +660,6 @@ def main():
     L = len(fanouts)
     s_samples = [torch.cuda.Stream(device=dev) for _ in range(K)]
     s_extract = s_samples[0] if args.no_overlap else torch.cuda.Stream(device=dev)
-    # the label gather needs the seeds and nothing else of the batch: on a stream of its own it runs beside the sampler
-    # instead of as a small launch between two gathers on the stream that bounds the step (as the engine does)
-    s_label = s_samples[0] if args.no_overlap else torch.cuda.Stream(device=dev)
     slot_free = [None] * NSLOT  # event: the slot's previous extract has finished
 
     # DistAlignedShuffler semantics (dist_shuffler_aligned.cc:37-146): pad to a multiple of world,
@@ -694,19 +691,13 @@ def main():
     last_gather = [None]  # completion event of the most recent feature gather (--heavy-after-gather)
 
     def make_step(extract_fn, counters, accs, seeds_of):
-        """One step of the hot path: sample on the batch's pipeline stream (the batch's counts are added to that pipeline's
-        totals there), labels on the label stream, the feature gather -- and nothing else -- on the extract stream."""
+        """One step of the hot path: sample on the batch's pipeline stream (label gather and count totals behind it, same
+        stream), the feature gather -- and nothing else -- on the extract stream."""
         def run_step(step, ev4=None):
             seeds, distinct = seeds_of(step)
             slot = step % NSLOT
             s_sample = s_samples[step % K]
             h0 = time.perf_counter()
-            with torch.cuda.stream(s_label):
-                if slot_free[slot] is not None:
-                    s_label.wait_event(slot_free[slot])
-                ops.extract(labels, seeds, out=out_label[slot][:seeds.numel()])
-                labelled = torch.cuda.Event()
-                labelled.record(s_label)
             with torch.cuda.stream(s_sample):
                 if slot_free[slot] is not None:
                     s_sample.wait_event(slot_free[slot])
@@ -720,7 +711,13 @@ def main():
                 sampled.record(s_sample)
                 if ev4 is not None:
                     ev4[1].record(s_sample)
-                accs[step % K].add_(sampler.counts_slots[slot])  # behind the batch on ITS stream: off the extract stream
+                # The label gather (needs the seeds only) and the batch's counts ride BEHIND the batch on its sampling stream,
+                # not between two gathers on the extract stream, which bounds the step.  (Not on a stream of their own: HIP
+                # streams share 4 hardware queues -- a fifth stream serialised the two khop0 pipelines, 0.36 -> 0.42 ms.)
+                ops.extract(labels, seeds, out=out_label[slot][:seeds.numel()])
+                accs[step % K].add_(sampler.counts_slots[slot])
+                labelled = torch.cuda.Event()
+                labelled.record(s_sample)
             h3 = time.perf_counter()
             with torch.cuda.stream(s_extract):
                 s_extract.wait_event(sampled)
@@ -828,7 +825,7 @@ def main():
     elapsed, edges_all = blk["elapsed"], blk["edges_all"]
     edges, rows = blk["edges"], blk["rows"]
     if args.host_profile and rank == 0:
-        names = ["label", "sample", "ev1+acc", "extract", "wait-label", "done"]
+        names = ["ev0", "sample", "label+acc", "extract", "wait-label", "done"]
         n_all = args.warmup + args.steps * repeats
         print("host enqueue ms/step:", {n: round(1e3 * t / n_all, 4) for n, t in zip(names, host_t)}, file=sys.stderr)
 
@@ -896,19 +893,24 @@ def main():
         a_buf = torch.empty(n_copy, dtype=torch.uint8, device=dev)
         b_buf = torch.zeros(n_copy, dtype=torch.uint8, device=dev)
         rate = C.c_double(0)
-        rc = _lib().ggms_link_probe_copy(C.c_void_p(a_buf.data_ptr()), C.c_void_p(b_buf.data_ptr()), n_copy, 5, C.byref(rate),
-                                         C.c_void_p(torch.cuda.current_stream().cuda_stream))
-        d2d = 2.0 * rate.value if rc == 0 else None
+        cur = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        d2d = None
+        for wg_per_cu in (1, 2, 4, 8):  # the copy ceiling of the box = the best grid of the streaming kernel
+            rc = _lib().ggms_link_probe_copy(C.c_void_p(a_buf.data_ptr()), C.c_void_p(b_buf.data_ptr()), n_copy, 5, wg_per_cu,
+                                             C.byref(rate), cur)
+            if rc == 0:
+                d2d = max(d2d or 0.0, 2.0 * rate.value)
+        rc = _lib().ggms_link_probe_copy(C.c_void_p(a_buf.data_ptr()), C.c_void_p(b_buf.data_ptr()), n_copy, 5, 0, C.byref(rate), cur)
+        d2d_memcpy = 2.0 * rate.value if rc == 0 else None
         n_pin = 256 << 20
         h_buf = torch.empty(n_pin, dtype=torch.uint8, pin_memory=True)
-        rc = _lib().ggms_link_probe_copy(C.c_void_p(a_buf.data_ptr()), C.c_void_p(h_buf.data_ptr()), n_pin, 3, C.byref(rate),
-                                         C.c_void_p(torch.cuda.current_stream().cuda_stream))
+        rc = _lib().ggms_link_probe_copy(C.c_void_p(a_buf.data_ptr()), C.c_void_p(h_buf.data_ptr()), n_pin, 3, 0, C.byref(rate), cur)
         h2d = rate.value if rc == 0 else None
         del a_buf, b_buf, h_buf
-        box = {"d2d_copy_GBps": d2d, "pinned_h2d_GBps": h2d,
-               "what": "hipMemcpyAsync of 1 GiB device to device (bytes read + written per second; the guide's MI355X figure "
-                       "is 6290) and of 256 MiB from hipHostMalloc memory; atomics_per_s / loads_per_s are added by the "
-                       "sampler roofline's probe",
+        box = {"d2d_copy_GBps": d2d, "d2d_memcpy_GBps": d2d_memcpy, "pinned_h2d_GBps": h2d,
+               "what": "1 GiB device to device, bytes read + written per second: a 16-B-per-lane streaming copy kernel (the "
+                       "guide's MI355X figure is 6290) and hipMemcpyAsync; 256 MiB from hipHostMalloc memory; atomics_per_s "
+                       "/ loads_per_s are added by the sampler roofline's probe",
                "d2d_over_guide": d2d / 6290.0 if d2d else None}
     res = None
     if rank == 0:
@@ -955,8 +957,8 @@ def main():
                 "global_batch": args.batch * world,
                 "parallelism": f"dp{world}",
                 "streams": "1 (serial)" if args.no_overlap else
-                           f"{K} sampling pipeline(s) (batches in flight, RNG pool consumed in batch order) + 1 extract stream "
-                           "(the feature gather alone) + 1 label stream",
+                           f"{K} sampling pipeline(s) (batches in flight, RNG pool consumed in batch order; label gather behind the "
+                           "batch) + 1 extract stream (the feature gather alone)",
                 "neighbour_skew": args.neighbour_skew,
                 "seeds_distinct_promise": not args.no_distinct_seeds,
                 **({"topology": topo_record} if topo_record else {}),

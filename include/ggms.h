@@ -534,8 +534,10 @@ int ggms_peer_access(int device, int peer, int *can_access);
 int ggms_detect_topology(ggms_topology_t *topo, size_t probe_bytes /* 0 = 128 MiB */, int reps);
 int ggms_topology_write_host(const ggms_topology_t *topo, const char *path, const char *device_order);
 int ggms_topology_read_host(ggms_topology_t *topo, const char *path);
-int ggms_link_probe_copy(void *dst, const void *src, size_t bytes, int reps, double *GBps_host,
-                         ggms_stream_t stream);
+/* with_kernel 0: hipMemcpyAsync; k = 1 .. 16: a plain 16-B-per-lane streaming copy kernel, k workgroups per CU (bytes,
+ * dst, src multiples of 16) */
+int ggms_link_probe_copy(void *dst, const void *src, size_t bytes, int reps, int with_kernel,
+                         double *GBps_host, ggms_stream_t stream);
 /* out: num_rows x row_bytes; parts: HOST array of num_part (<= GGMS_MAX_PARTS) base pointers, each holding
  * rows_per_part rows; index_ws: num_rows ids of device scratch; row_bytes a multiple of 4. */
 int ggms_link_probe_gather(void *out, const void *const *parts, uint32_t num_part, size_t rows_per_part,

@@ -182,7 +182,7 @@ def test_two_ranks_default_is_the_planned_placement():
     assert "error" not in early["xgmi"]  # measured before the store was placed: the early headline carries it already
     xg = d["xgmi"]
     assert "error" not in xg, xg
-    for key in ("per_pair_copy_GBps", "per_pair_gather_GBps"):
+    for key in ("per_pair_copy_GBps", "per_pair_stream_kernel_GBps", "per_pair_gather_GBps"):
         m = xg[key]
         assert len(m) == 2 and all(len(row) == 2 and all(v > 1.0 for v in row) for row in m), (key, m)
     assert len(xg["inbound_all_peers_gather_GBps"]) == 2 and xg["inbound_all_peers_min_GBps"] > 1.0

@@ -60,8 +60,11 @@ def test_link_probe_on_local_buffers():
         part, row = int(idx[i]) % 2, int(idx[i]) // 2
         assert got[i, 0] == (part << 28) + row * (row_bytes // 4) and got[i, -1] == got[i, 0] + row_bytes // 4 - 1
     dst = torch.empty(rows_per_part * row_bytes, dtype=torch.uint8, device=dev)
-    assert h.ggms_link_probe_copy(C.c_void_p(dst.data_ptr()), C.c_void_p(parts[1].data_ptr()), dst.numel(), 2, C.byref(rate), s) == 0
-    assert rate.value > 50 and torch.equal(dst.view(torch.int32).reshape(rows_per_part, -1), parts[1])
+    for with_kernel in (0, 1):
+        dst.zero_()
+        assert h.ggms_link_probe_copy(C.c_void_p(dst.data_ptr()), C.c_void_p(parts[1].data_ptr()), dst.numel(), 2, with_kernel,
+                                      C.byref(rate), s) == 0
+        assert rate.value > 50 and torch.equal(dst.view(torch.int32).reshape(rows_per_part, -1), parts[1])
     can = C.c_int(0)
     assert h.ggms_peer_access(0, 0, C.byref(can)) == 0 and can.value == 1
 

@@ -322,7 +322,7 @@ class Leaf:  # what link_probe / peer_access_preflight need of the device, on th
     def peer_access(self, dev, peer): return 0 if (mode == "refused" and dev == 1 and peer == 0) else 1
     def shard(self, rows, words, fill): return Holder(fill)
     def scratch(self, nbytes): return [0]
-    def copy_rate(self, dst, src_ptr, nbytes, reps): dst[0] = src_ptr - 1000; return 100.0 * rank + (src_ptr - 1000)
+    def copy_rate(self, dst, src_ptr, nbytes, reps, with_kernel=0): dst[0] = src_ptr - 1000; return 100.0 * rank + (src_ptr - 1000)
     def gather_rate(self, out, ptrs, rpp, rb, n, seed, reps, ws): return 10.0 * rank + sum(p - 1000 for p in ptrs)
     def first_word(self, t): return t[0]
 

@@ -115,7 +115,7 @@ SYMBOLS = {
     "ggms_detect_topology": (_i, [C.POINTER(Topology), _sz, _i]),
     "ggms_topology_write_host": (_i, [C.POINTER(Topology), C.c_char_p, C.c_char_p]),
     "ggms_topology_read_host": (_i, [C.POINTER(Topology), C.c_char_p]),
-    "ggms_link_probe_copy": (_i, [_vp, _vp, _sz, _i, C.POINTER(C.c_double), _vp]),
+    "ggms_link_probe_copy": (_i, [_vp, _vp, _sz, _i, _i, C.POINTER(C.c_double), _vp]),
     "ggms_link_probe_gather": (_i, [_vp, _vp, _u32, _sz, _sz, _sz, _u32, _i, _vp, C.POINTER(C.c_double), _vp]),
 }
 

@@ -557,7 +557,6 @@ bool Engine::ShufflerNext(Batch *b, hipStream_t copy_stream) {
   static const bool sanity = getenv("SAMGRAPH_SANITY_CHECK") != nullptr; // run_config.cc:126-128
   if (sanity && cfg.arch == kArch1) SanityCheckBatch(shuf_host_.data() + global_data_offset_ + offset, size);
   SAM_HIP(hipMemcpyAsync(b->output_nodes, shuf_dev_ + offset, size * 4, hipMemcpyDeviceToDevice, copy_stream)); // Copy1D
-  SAM_HIP(hipEventRecord(b->ev_seeds, copy_stream)); // the label gather needs the seeds and nothing else of the batch
   return true;
 }
 
@@ -652,7 +651,6 @@ void Engine::SampleInit(int worker_id, const std::string &ctx) {
   SAM_HIP(hipSetDevice(device_));
   SAM_HIP(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
   SAM_HIP(hipStreamCreateWithFlags(&stream_extract_, hipStreamNonBlocking));
-  SAM_HIP(hipStreamCreateWithFlags(&stream_label_, hipStreamNonBlocking));
   UploadGraph();
   ShufflerInit();
   const uint32_t L = (uint32_t)cfg.fanout.size();
@@ -963,7 +961,6 @@ void Engine::Shutdown() {
     if (P.stream) (void)hipStreamSynchronize(P.stream);
   if (stream_) (void)hipStreamSynchronize(stream_);
   if (stream_extract_) (void)hipStreamSynchronize(stream_extract_);
-  if (stream_label_) (void)hipStreamSynchronize(stream_label_);
 }
 
 // ------------------------------------------------------------------ hot loop
@@ -1039,17 +1036,17 @@ bool Engine::EnqueueOne(bool background) {
   uint64_t *n_in = b->counts_dev + 3 * L, *n_miss = b->counts_dev + 3 * L + 2; // [3L + 1] = the batch's status word
   SAM_HIP(hipMemsetAsync(n_miss, 0, 8, ss));
   SAM_HIP(hipEventRecord(b->ev_sampled, ss));
+  // DoGPULabelExtract (dist_loops.cc:938-974) needs the seeds only: it rides behind the batch on its sampling stream, not
+  // between two gathers on the extract stream, which bounds the step.  (Not on a stream of its own: HIP streams share 4
+  // hardware queues, and a fifth stream serialises streams that have nothing to do with each other.)
+  SAM_GGMS(ggms_extract(b->label, label_src_, b->output_nodes, b->num_seeds, 1, GGMS_I64, ss));
+  SAM_HIP(hipEventRecord(b->ev_label, ss));
   // The gather is HBM-bound, the sampler latency-bound: they run on separate streams so that batch k's
   // extract overlaps batch k+1's sampling (the reference serialises them, dist_loops_arch6.cc:248-251)
   hipStream_t xs = stream_extract_;
   SAM_HIP(hipStreamWaitEvent(xs, b->ev_sampled, 0));
   SAM_HIP(hipEventRecord(b->ev_xstart, xs)); // the extract's own start: behind the previous batch's extract on xs
   const bool mock = ds.feat_mask != 0xffffffffu; // SAMGRAPH_EMPTY_FEAT: host rows are node & mask
-  // DoGPULabelExtract (dist_loops.cc:938-974) depends on the seeds only: on a stream of its own it runs while the batch
-  // is still being sampled, instead of as a small launch between two gathers of the stream that bounds the step
-  SAM_HIP(hipStreamWaitEvent(stream_label_, b->ev_seeds, 0));
-  SAM_GGMS(ggms_extract(b->label, label_src_, b->output_nodes, b->num_seeds, 1, GGMS_I64, stream_label_));
-  SAM_HIP(hipEventRecord(b->ev_label, stream_label_));
   if (StagedHostTier()) {
     StagedExtract(b, ss, xs);
   } else if (cfg.UseGPUCache() && (mock || num_replica_)) { // every tier in one gather; rows per tier counted
@@ -1220,17 +1217,54 @@ void Engine::StagedExtract(Batch *b, hipStream_t ss, hipStream_t xs) {
     static const size_t chunk_mb = [] { const char *e = getenv("SAMGRAPH_STAGED_CHUNK_MB"); const long v = e ? atol(e) : 0; return (size_t)(v > 0 ? v : 16); }();
     static const size_t chunk_rows = [] { const char *e = getenv("SAMGRAPH_STAGED_CHUNK_ROWS"); const long v = e ? atol(e) : 0; return (size_t)(v > 0 ? v : 0); }(); // test hook
     const size_t chunk = chunk_rows ? chunk_rows : std::max<size_t>(1024, (chunk_mb << 20) / row_bytes);
-    for (size_t lo = 0; lo < num_miss; lo += chunk) {
-      const size_t m = std::min(chunk, num_miss - lo);
-      t0 = clk::now();
-      HostGatherRows(rows, b->miss_ids_host, lo, m);
-      t_gather += since(t0);
-      // chunk lo of the pinned buffer is complete: copy engine + combine kernel take it from here, the cores go on
-      SAM_HIP(hipMemcpyAsync(land + lo * row_bytes, rows + lo * row_bytes, m * row_bytes, hipMemcpyHostToDevice, xs));
-      if (have_cache)
-        SAM_GGMS(ggms_gather_scatter(b->feat, (char *)b->miss_rows_dev + lo * row_bytes, nullptr, b->miss_dst + lo, m, nullptr,
-                                     ds.feat_dim, ds.feat_dtype, xs)); // CombineMissData of this chunk
-    }
+    // ONE dispatch of the host team per batch: every thread walks the chunks itself (its slice of chunk 0, of chunk 1,
+    // ...) and ticks the chunk's counter; the calling thread -- thread 0 of the team, the only one that talks to HIP --
+    // hands every chunk whose counter is full to the copy engine between two of its own slices.  (One dispatch per
+    // chunk was 34 wake-ups of 15 sleeping threads per batch: a millisecond of an 11-ms step.)
+    const size_t nchunks = (num_miss + chunk - 1) / chunk;
+    const int T = host_team_->size();
+    std::vector<std::atomic<int>> ticks(nchunks);
+    for (auto &t : ticks) t.store(0, std::memory_order_relaxed);
+    size_t flushed = 0;
+    auto flush_ready = [&](bool all) {
+      while (flushed < nchunks) {
+        if (ticks[flushed].load(std::memory_order_acquire) != T) {
+          if (!all) return;
+          std::this_thread::yield();
+          continue;
+        }
+        const size_t lo = flushed * chunk, m = std::min(chunk, num_miss - lo);
+        SAM_HIP(hipMemcpyAsync(land + lo * row_bytes, rows + lo * row_bytes, m * row_bytes, hipMemcpyHostToDevice, xs));
+        if (have_cache)
+          SAM_GGMS(ggms_gather_scatter(b->feat, (char *)b->miss_rows_dev + lo * row_bytes, nullptr, b->miss_dst + lo, m, nullptr,
+                                       ds.feat_dim, ds.feat_dtype, xs)); // CombineMissData of this chunk
+        ++flushed;
+      }
+    };
+    t0 = clk::now();
+    const char *feat = (const char *)ds.feat.ptr;
+    const uint32_t *ids = b->miss_ids_host;
+    const uint32_t mask = ds.feat_mask;
+    host_team_->ParallelFor((size_t)T, [&](size_t tid, size_t, int) { // one iteration per thread: iteration == thread
+      constexpr size_t kAhead = 8;
+      for (size_t c = 0; c < nchunks; ++c) {
+        const size_t base = c * chunk, m = std::min(chunk, num_miss - base);
+        const size_t q = m / T, r = m % T;
+        const size_t lo = base + tid * q + std::min<size_t>(tid, r), hi = lo + q + (tid < r ? 1 : 0);
+        for (size_t i = lo; i < hi; ++i) {
+          if (i + kAhead < hi) {
+            const char *nx = feat + (size_t)(ids[i + kAhead] & mask) * row_bytes;
+            for (size_t o = 0; o < row_bytes; o += 64) __builtin_prefetch(nx + o, 0, 0);
+          }
+          copy_row_stream(rows + i * row_bytes, feat + (size_t)(ids[i] & mask) * row_bytes, row_bytes);
+        }
+        store_fence();
+        ticks[c].fetch_add(1, std::memory_order_release);
+        if (tid == 0) flush_ready(false);
+      }
+    });
+    t_gather = since(t0);
+    flush_ready(true);
   }
   // the reference's step items (profiler.h:111-116: 44 .. 49); overlapped mode: the host's own busy time per phase
   prof.LogStep(b->key, 44, t_index);

@@ -229,7 +229,6 @@ class Engine {
   int worker_id_ = 0, device_ = 0;
   hipStream_t stream_ = nullptr;         // shuffle + sampling (latency-bound)
   hipStream_t stream_extract_ = nullptr; // feature gather (HBM-bound): overlaps the next batch's sampling
-  hipStream_t stream_label_ = nullptr;   // label gather: needs the seeds only, runs beside the sampler
   // device graph
   uint32_t *d_indptr_ = nullptr, *d_indices_ = nullptr;
   std::vector<void *> part_indptr_, part_indices_; // P+1 entries (slot P = host CSR)

@@ -32,6 +32,24 @@ __global__ __launch_bounds__(kBlock) void k_probe_index(uint32_t *__restrict__ i
   }
 }
 
+// a plain streaming copy, 16 B per lane and 8 chunks in flight per lane (every load instruction of a wave covers one
+// contiguous KiB): the kind of kernel behind the guide's device-to-device copy ceiling
+typedef uint32_t u32x4_probe __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(kBlock) void k_probe_copy16(u32x4_probe *__restrict__ dst, const u32x4_probe *__restrict__ src,
+                                                         uint64_t n) {
+  constexpr int U = 8;
+  const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+  uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+  for (; i + (U - 1) * stride < n; i += U * stride) {
+    u32x4_probe v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) v[u] = __builtin_nontemporal_load(src + i + u * stride);
+#pragma unroll
+    for (int u = 0; u < U; ++u) __builtin_nontemporal_store(v[u], dst + i + u * stride);
+  }
+  for (; i < n; i += stride) __builtin_nontemporal_store(__builtin_nontemporal_load(src + i), dst + i);
+}
+
 static int timed(hipStream_t s, int reps, const std::function<int()> &enqueue, double *seconds) {
   hipEvent_t e0, e1;
   GGMS_HIP(hipEventCreate(&e0));
@@ -214,13 +232,24 @@ int ggms_topology_read_host(ggms_topology_t *topo, const char *path) {
 }
 
 // A rank's own measurement on a mapping it holds: copy `bytes` from src (local HBM, a hipIpc-mapped peer, mapped
-// host memory) into dst (local HBM), `reps` times after one warm-up copy.  Synchronises `stream`.
-int ggms_link_probe_copy(void *dst, const void *src, size_t bytes, int reps, double *GBps, ggms_stream_t stream) {
+// host memory) into dst (local HBM), `reps` times after one warm-up copy -- with hipMemcpyAsync (the copy engines / the
+// runtime's blit kernel), or with_kernel != 0: a plain 16-B-per-lane streaming kernel (in-kernel loads over the link;
+// locally: the device's copy ceiling).  Synchronises `stream`.
+int ggms_link_probe_copy(void *dst, const void *src, size_t bytes, int reps, int with_kernel, double *GBps,
+                         ggms_stream_t stream) {
   GGMS_CHECK_ARG(dst && src && bytes && GBps);
+  GGMS_CHECK_ARG(!with_kernel || (bytes % 16 == 0 && (((uintptr_t)dst | (uintptr_t)src) & 15) == 0));
   if (reps < 1) reps = 1;
   hipStream_t s = to_stream(stream);
   double sec = 0;
   const int rc = timed(s, reps, [&]() -> int {
+    if (with_kernel) {
+      // with_kernel = workgroups per CU (256 CUs): 1 .. 16
+      hipLaunchKernelGGL(k_probe_copy16, dim3(256 * (with_kernel > 16 ? 16 : with_kernel)), dim3(kBlock), 0, s,
+                         (u32x4_probe *)dst, (const u32x4_probe *)src, (uint64_t)(bytes / 16));
+      GGMS_LAUNCH_CHECK();
+      return GGMS_OK;
+    }
     if (hipMemcpyAsync(dst, src, bytes, hipMemcpyDefault, s) != hipSuccess) {
       set_error("ggms_link_probe_copy: %s", hipGetErrorString(hipGetLastError()));
       return GGMS_ERR_HIP;

@@ -175,10 +175,11 @@ class HipProbeLeaf:
     def scratch(self, nbytes):
         return torch.empty(max(4, nbytes) // 4, dtype=torch.int32, device=self.device)
 
-    def copy_rate(self, dst, src_ptr, nbytes, reps):
+    def copy_rate(self, dst, src_ptr, nbytes, reps, with_kernel=0):
         C, g = self.C, self.C.c_double(0)
-        self.check(self.lib().ggms_link_probe_copy(C.c_void_p(dst.data_ptr()), C.c_void_p(src_ptr), nbytes, reps, C.byref(g),
-                                                   C.c_void_p(torch.cuda.current_stream().cuda_stream)), "ggms_link_probe_copy")
+        self.check(self.lib().ggms_link_probe_copy(C.c_void_p(dst.data_ptr()), C.c_void_p(src_ptr), nbytes, reps, with_kernel,
+                                                   C.byref(g), C.c_void_p(torch.cuda.current_stream().cuda_stream)),
+                   "ggms_link_probe_copy")
         return g.value
 
     def gather_rate(self, out, part_ptrs, rows_per_part, row_bytes, num_rows, seed, reps, index_ws):
@@ -221,8 +222,9 @@ def link_probe(world, rank, dist, leaf, probe_bytes=128 << 20, row_bytes=512, re
     through hipIpc mappings) -- the one-process-per-GPU form of DetectTopo_child's timed 128-MiB peer copies
     (dist_graph.cu:822-848).  Every rank publishes a probe_bytes buffer and maps its peers'; then
       per pair, ALONE on the node (everybody else waits at a barrier): a timed copy out of the mapping
-        (hipMemcpyAsync, the copy engines) and the feature store's own gather kernel reading random row_bytes rows
-        of it (ggms_link_probe_gather);
+        (hipMemcpyAsync, the copy engines), a streaming copy kernel reading it in place (what in-kernel loads over
+        the link can reach at best) and the feature store's own gather kernel reading random row_bytes rows of it
+        (ggms_link_probe_gather);
       all ranks at once, each from ALL its peers (slots modulo the peers, what the `peer` / `hybrid` stores do every
         batch): the rate a GPU's inbound links sustain together while its outbound links serve the others.
     Matrices are [reader][owner]; the diagonal is the reader's own HBM through the same code.  Returns the same dict
@@ -243,7 +245,7 @@ def link_probe(world, rank, dist, leaf, probe_bytes=128 << 20, row_bytes=512, re
             if world > 1:
                 dist.barrier(group=group)
 
-        copy_row, gather_row, wrong = [0.0] * world, [0.0] * world, []
+        copy_row, stream_row, gather_row, wrong = [0.0] * world, [0.0] * world, [0.0] * world, []
         barrier()
         for reader in range(world):
             for owner in range(world):
@@ -251,13 +253,14 @@ def link_probe(world, rank, dist, leaf, probe_bytes=128 << 20, row_bytes=512, re
                     copy_row[owner] = leaf.copy_rate(dst, ptrs[owner], nbytes, reps)
                     if leaf.first_word(dst) != owner + 1:  # the mapping reads the owner's memory, not somebody else's
                         wrong.append(owner)
+                    stream_row[owner] = leaf.copy_rate(dst, ptrs[owner], nbytes, reps, 4)
                     gather_row[owner] = leaf.gather_rate(out, [ptrs[owner]], rows_per_part, row_bytes, num_rows,
                                                          17 * reader + owner, reps, index_ws)
                 barrier()
         peers = [ptrs[p] for p in range(world) if p != rank]
         inbound = leaf.gather_rate(out, peers, rows_per_part, row_bytes, num_rows, 1000 + rank, reps, index_ws) if peers else 0.0
         barrier()  # nobody unmaps a buffer a peer may still be reading
-        mine = {"copy": copy_row, "gather": gather_row, "inbound": inbound, "wrong": wrong}
+        mine = {"copy": copy_row, "stream": stream_row, "gather": gather_row, "inbound": inbound, "wrong": wrong}
         rows = [None] * world
         if world > 1:
             with_deadline(lambda: dist.all_gather_object(rows, mine, group=group),
@@ -272,11 +275,13 @@ def link_probe(world, rank, dist, leaf, probe_bytes=128 << 20, row_bytes=512, re
     remote = [rows[r]["gather"][o] for r in range(world) for o in range(world) if o != r]
     return {
         "method": "one rank per GPU; every rank publishes a buffer (hipIpc) and maps its peers'; per pair alone on the "
-                  "node: hipMemcpyAsync out of the mapping, and the feature store's gather kernel "
-                  "(ggms_gather_scatter_partition, 16-B nt loads) on random rows of it; then all ranks at once, each from "
+                  "node: hipMemcpyAsync out of the mapping, a 16-B-per-lane streaming copy kernel reading it in place, and the "
+                  "feature store's gather kernel (ggms_gather_scatter_partition, 16-B nt loads) on random rows of it; then all "
+                  "ranks at once, each from "
                   "all its peers (slots modulo the peers); matrices are [reader][owner], the diagonal is local HBM",
         "probe_bytes": nbytes, "row_bytes": row_bytes, "rows_per_launch": num_rows, "reps": reps,
         "per_pair_copy_GBps": [r["copy"] for r in rows],
+        "per_pair_stream_kernel_GBps": [r["stream"] for r in rows],
         "per_pair_gather_GBps": [r["gather"] for r in rows],
         "inbound_all_peers_gather_GBps": [r["inbound"] for r in rows],
         "inbound_all_peers_min_GBps": min((r["inbound"] for r in rows), default=0.0) if world > 1 else None,
