@@ -895,7 +895,7 @@ def main():
         rate = C.c_double(0)
         cur = C.c_void_p(torch.cuda.current_stream().cuda_stream)
         d2d = None
-        for wg_per_cu in (1, 2, 4, 8):  # the copy ceiling of the box = the best grid of the streaming kernel
+        for wg_per_cu in (1, 2, 3, 4):  # the copy ceiling of the box = the best grid of the streaming kernel (profiles/r05_copy_grid.txt)
             rc = _lib().ggms_link_probe_copy(C.c_void_p(a_buf.data_ptr()), C.c_void_p(b_buf.data_ptr()), n_copy, 5, wg_per_cu,
                                              C.byref(rate), cur)
             if rc == 0:

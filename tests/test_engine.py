@@ -57,6 +57,37 @@ sam.config({{'dataset_path': '/nonexistent', '_arch': 1}})
     assert "missing config key" in out.stderr
 
 
+def test_arch6_refuses_workers_whose_gpus_cannot_reach_each_other(tmp_path):
+    """PartitionSolver's P2P matrix (cuda/dist_graph.cu:812-818) as the engine uses it: data_init reads the topology
+    file (here a hand-written one in the reference's format: two GPUs, GPU 0 cannot access GPU 1) and aborts naming the
+    pair BEFORE any worker is forked or any shard built -- host only, no GPU touched.  A fully connected file passes."""
+    d = make_dataset(tmp_path / "ds")
+    body = "GPU Count 2\nDevice Order test\nGPU [0] gfx950\nGPU [1] gfx950\n\n\nP2P Matrix\n   1    {a} \n   1    1 \n\n\n" \
+           "Bandwidth Matrix\n 5000.00    48.10 \n   47.90  5000.00 \n"
+    code = f"""
+import sys; sys.path.insert(0, {ROOT!r})
+import samgraph.torch as sam
+sam.config({{'dataset_path': {d['path']!r}, '_arch': 6, '_sample_type': 7, 'batch_size': 64, 'num_epoch': 1,
+  '_cache_policy': 0, 'cache_percentage': 0.3, 'max_sampling_jobs': 1, 'max_copying_jobs': 1, 'omp_thread_num': 1,
+  'num_layer': 2, 'num_hidden': 8, 'lr': 0.1, 'dropout': 0.5, 'num_worker': 2, 'num_fanout': 2, 'fanout': [5, 4],
+  'part_cache': 'True', 'gpu_extract': 'True'}})
+sam.data_init()
+print('placed')
+"""
+    env = {k: v for k, v in os.environ.items() if k != "SAMGRAPH_FORCE_DEVICE"}
+    for a, ok in (("0", False), ("1", True)):
+        topo = tmp_path / f"topo_{a}"
+        topo.write_text(body.format(a=a))
+        out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300,
+                             env=dict(env, SAMGRAPH_TOPO_FILE=str(topo), SAMGRAPH_LOG_LEVEL="info"))
+        if ok:
+            assert out.returncode == 0 and "placed" in out.stdout, out.stderr[-1500:]
+            assert "GB/s INTO row FROM column" in out.stderr and "48.1" in out.stderr  # the matrix is logged (info level)
+        else:
+            assert out.returncode < 0 and "placed" not in out.stdout  # SIGABRT, like a failed CHECK of the reference
+            assert "GPU 0 cannot access GPU 1" in out.stderr and "hipDeviceCanAccessPeer" in out.stderr
+
+
 def _replay_arch0(d, batch_size, num_epoch, fanouts, seed, sample_type, sampler, extract):
     """CPUEngine semantics (cpu_loops.cc:41-228): CPUShuffler (no padding, shuffled in place epoch after epoch), then
     per batch the CPU sampler + first-occurrence dedup/remap + CPUExtract.  `sampler` / `extract` are the leaves under

@@ -540,18 +540,21 @@ __global__ __launch_bounds__(128) void k_khop0_generate(GraphView g, const uint3
 }
 
 // the resolve step proper: lanes `lane`, `lane + stride`, ... of the draws of one seed into its LDS slots
+// U independent loads in flight per lane: 8 for a 16-lane group (at most kKhop0Heavy draws: 8 rounds), 32 for the
+// workgroup that takes a listed long list alone -- its rounds are latency, and a 300 K-neighbour hub is the kernel's tail
+template <uint32_t U = 8>
 __device__ __forceinline__ void khop0_resolve_draws(const uint32_t *__restrict__ raw, uint32_t base, uint32_t extra,
                                                     uint32_t fanout, uint32_t lane, uint32_t stride,
                                                     uint32_t *slots) {
-  for (uint32_t d0 = 0; d0 < extra; d0 += stride * 8) { // 8 independent loads in flight per lane
-    uint32_t xs[8];
+  for (uint32_t d0 = 0; d0 < extra; d0 += stride * U) {
+    uint32_t xs[U];
 #pragma unroll
-    for (uint32_t u = 0; u < 8; ++u) {
+    for (uint32_t u = 0; u < U; ++u) {
       const uint32_t d = d0 + u * stride + lane;
       xs[u] = d < extra ? raw[base + d] : 0u;
     }
 #pragma unroll
-    for (uint32_t u = 0; u < 8; ++u) {
+    for (uint32_t u = 0; u < U; ++u) {
       const uint32_t d = d0 + u * stride + lane;
       const uint32_t j = fanout + d;
       const uint32_t kk = xs[u] % (j + 1);
@@ -590,7 +593,7 @@ __global__ __launch_bounds__(kBlock) void k_khop0_resolve(GraphView g, const uin
       for (uint32_t s0 = threadIdx.x; s0 < fanout; s0 += kBlock) slot_init<BIG>(&slots[s0], s0);
       if constexpr (BIG) __threadfence();
       __syncthreads();
-      khop0_resolve_draws(raw, base, len - fanout, fanout, threadIdx.x, kBlock, slots);
+      khop0_resolve_draws<32>(raw, base, len - fanout, fanout, threadIdx.x, kBlock, slots);
       if constexpr (BIG) __threadfence();
       __syncthreads();
       for (uint32_t s0 = threadIdx.x; s0 < fanout; s0 += kBlock) {

@@ -253,7 +253,7 @@ def link_probe(world, rank, dist, leaf, probe_bytes=128 << 20, row_bytes=512, re
                     copy_row[owner] = leaf.copy_rate(dst, ptrs[owner], nbytes, reps)
                     if leaf.first_word(dst) != owner + 1:  # the mapping reads the owner's memory, not somebody else's
                         wrong.append(owner)
-                    stream_row[owner] = leaf.copy_rate(dst, ptrs[owner], nbytes, reps, 4)
+                    stream_row[owner] = leaf.copy_rate(dst, ptrs[owner], nbytes, reps, 1)
                     gather_row[owner] = leaf.gather_rate(out, [ptrs[owner]], rows_per_part, row_bytes, num_rows,
                                                          17 * reader + owner, reps, index_ws)
                 barrier()
