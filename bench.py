@@ -630,6 +630,7 @@ def main():
 
         def extract(nodes, num_max, out, num_dev, counters):
             st.extract(nodes, num_max, out, num_dev=num_dev, counters=counters)
+        extract.single_launch = kind != "a2a"  # a2a: several gathers and two collectives per batch -- timed with an event pair
         return extract, keep
 
     code = {"khop3": ops.KHOP3, "khop0": ops.KHOP0, "khop2": ops.KHOP2, "khop1": ops.KHOP1,
@@ -693,14 +694,17 @@ def main():
     def make_step(extract_fn, counters, accs, seeds_of):
         """One step of the hot path: sample on the batch's pipeline stream (label gather and count totals behind it, same
         stream), the feature gather -- and nothing else -- on the extract stream."""
-        def run_step(step, ev4=None):
+        def run_step(step, ev4=None, tm=None):
             seeds, distinct = seeds_of(step)
             slot = step % NSLOT
             s_sample = s_samples[step % K]
             h0 = time.perf_counter()
             with torch.cuda.stream(s_sample):
-                if slot_free[slot] is not None:
-                    s_sample.wait_event(slot_free[slot])
+                for e in slot_free[slot] or ():  # the slot's previous rows are out (extract stream) and its labels too
+                    if isinstance(e, ops.LaunchTimer):
+                        e.wait(s_sample)
+                    else:
+                        s_sample.wait_event(e)
                 if ev4 is not None:
                     ev4[0].record(s_sample)
                 h1 = time.perf_counter()
@@ -722,24 +726,34 @@ def main():
             with torch.cuda.stream(s_extract):
                 s_extract.wait_event(sampled)
                 counts = sampler.counts_slots[slot]
-                if ev4 is not None:
-                    ev4[2].record(s_extract)
-                extract_fn(sampler.input_nodes[slot], sampler.max_unique, out[slot], counts[3 * L:3 * L + 1], counters)
-                if ev4 is not None:
-                    ev4[3].record(s_extract)
+                # The extract stream carries the gather and as little else as possible: every event record / wait is a
+                # barrier packet the command processor works through between two gathers (profiles/r05_ab_extract_stream.txt:
+                # 28 us of dead time per step with five of them).  The slot's labels are waited for by the NEXT user of the
+                # slot on its sampling stream, which has the slack -- not here.  The gather's timing and its "rows are out"
+                # event ride on the kernel's own dispatch packet (ggms_launch_timer_t, include/ggms.h); the event-pair form
+                # is kept for the store whose extract is several launches (a2a) and as an A/B (GGMS_BENCH_GATHER_TIMING=events).
+                if tm is not None:
+                    tm.arm()
+                    extract_fn(sampler.input_nodes[slot], sampler.max_unique, out[slot], counts[3 * L:3 * L + 1], counters)
+                    done = tm
+                else:
+                    if ev4 is not None:
+                        ev4[2].record(s_extract)
+                    extract_fn(sampler.input_nodes[slot], sampler.max_unique, out[slot], counts[3 * L:3 * L + 1], counters)
+                    done = ev4[3] if ev4 is not None else torch.cuda.Event()
+                    done.record(s_extract)
                 if args.heavy_after_gather:
                     last_gather[0] = torch.cuda.Event()
                     last_gather[0].record(s_extract)
-                h4 = time.perf_counter()
-                s_extract.wait_event(labelled)  # the slot is free again when its rows AND its labels are out
-                h5 = time.perf_counter()
-                done = torch.cuda.Event()
-                done.record(s_extract)
-                slot_free[slot] = done
+                h4 = h5 = time.perf_counter()
+                slot_free[slot] = (done, labelled)
             h6 = time.perf_counter()
             for i, (a, b) in enumerate([(h0, h1), (h1, h2), (h2, h3), (h3, h4), (h4, h5), (h5, h6)]):
                 host_t[i] += b - a
         return run_step
+
+    step_events = os.environ.get("GGMS_BENCH_STEP_EVENTS", "1") != "0"    # A/B hook: no per-step timing at all
+    gather_timing = os.environ.get("GGMS_BENCH_GATHER_TIMING", "timer")   # "events": HIP event pair around the launch (A/B)
 
     def measure(extract_fn, steps, warmup, repeats, first_step=0):
         """warmup untimed steps, then `repeats` blocks of `steps` timed steps, each bracketed by barrier + synchronize.
@@ -752,8 +766,11 @@ def main():
         accs = [torch.zeros(3 * L + 2, dtype=torch.int64, device=dev) for _ in range(K)]  # one per sampling pipeline
         run_step = make_step(extract_fn, counters, accs, lambda s: seeds_all[s])
         log(f"measure: {warmup} warm-up + {repeats} x {steps} steps")
+        timed = gather_timing == "timer" and getattr(extract_fn, "single_launch", True)
+        slot_tm = [ops.LaunchTimer() for _ in range(NSLOT)] if timed else None
+        step_tm = [ops.LaunchTimer() for _ in range(steps)] if timed else None
         for s in range(warmup):
-            run_step(s)
+            run_step(s, None, slot_tm[s % NSLOT] if timed else None)
         barrier()
         warm_status = int(sum(a[3 * L + 1] for a in accs).item())  # the warm-up batches' status words (zeroed before each timed block)
         if warmup and warm_status:
@@ -769,9 +786,15 @@ def main():
             barrier()
             t0 = time.perf_counter()
             for k in range(steps):
-                run_step(warmup + r * steps + k, ev[k])
+                run_step(warmup + r * steps + k, ev[k] if step_events else None,
+                         (step_tm[k] if step_events else slot_tm[k % NSLOT]) if timed else None)
             barrier()
             elapsed = time.perf_counter() - t0
+            if not step_events:  # A/B hook: what the per-step timing costs the step (the per-stream figures are then bounds)
+                for e in ev:
+                    for x in e:
+                        x.record()
+                torch.cuda.synchronize()
             c = torch.stack(accs).sum(0).cpu().tolist()
             if c[3 * L + 1]:
                 ops.check_device_status("bench")
@@ -779,7 +802,12 @@ def main():
             edges, rows = sum(c[3 * i] for i in range(L)), c[3 * L]
             inputs = sum(c[3 * i + 2] for i in range(L))  # sampler inputs (seeds of every layer)
             t_sample_ms = sum(e[0].elapsed_time(e[1]) for e in ev)   # on the sampling stream
-            t_extract_ms = sum(e[2].elapsed_time(e[3]) for e in ev)  # HIP events on the stream the gather is launched on
+            if timed and step_events:  # HIP events on the gather's own dispatch packet, on the stream it is launched on
+                t_extract_ms = sum(t.elapsed_us() for t in step_tm) / 1e3
+            else:                      # HIP event pair around the launch on that stream
+                t_extract_ms = sum(e[2].elapsed_time(e[3]) for e in ev)
+            if not step_events:
+                t_sample_ms = t_extract_ms = elapsed * 1e3
             stats = torch.tensor([elapsed, float(edges), float(rows), t_sample_ms, t_extract_ms,
                                   rows * row_bytes / (t_extract_ms / 1e3) / 1e9]
                                  + [float(x) for x in counters.cpu().tolist()], dtype=torch.float64, device=dev)

@@ -486,6 +486,27 @@ int ggms_extract_tiered(void *out, const ggms_id_t *nodes, size_t num_nodes,
 
 
 /* ---------------------------------------------------------------------------
+ * Launch timer: a row gather's OWN start / end timestamps, with no packet of their own on the stream.
+ * The reference times its extract with a host timer around a stream sync (dist_loops.cc:1276-1281,
+ * kLogL1CopyTime); a pipelined caller has to use events instead, and every hipEventRecord / hipStreamWaitEvent
+ * is a barrier packet the command processor works through between two kernels of the stream -- 6-7 us each on
+ * MI355X, all of it dead time on the stream that bounds the step (profiles/r05_ab_extract_stream.txt).  A timer's
+ * two events ride ON the dispatch packet of the next row-gather launch (hipExtLaunchKernel): the kernel's own
+ * start and end timestamps, and its end event is what another stream waits for ("the slot's rows are out").
+ *   arm(t):      the next launch of ggms_extract* / ggms_gather_scatter* / ggms_mock_extract issued by THIS thread
+ *                carries the timer (thread-local, consumed by that one launch; a call that launches nothing --
+ *                zero rows -- leaves it armed)
+ *   wait(t, s):  stream s waits for the timed launch (no-op if the timer never rode a launch)
+ *   elapsed_us:  blocks until the launch has finished; GGMS_ERR_INVALID if the timer never rode a launch
+ * ------------------------------------------------------------------------- */
+typedef struct ggms_launch_timer ggms_launch_timer_t;
+int ggms_launch_timer_create(ggms_launch_timer_t **timer);
+int ggms_launch_timer_destroy(ggms_launch_timer_t *timer);
+int ggms_launch_timer_arm(ggms_launch_timer_t *timer);
+int ggms_launch_timer_wait(ggms_launch_timer_t *timer, ggms_stream_t stream);
+int ggms_launch_timer_elapsed_us(ggms_launch_timer_t *timer, double *us);
+
+/* ---------------------------------------------------------------------------
  * GGMS shards across processes (one process per GPU).
  *
  * Publishing a shard: DistGraph::_Barrier/IPC exchange, cuda/dist_graph.cu:228-272

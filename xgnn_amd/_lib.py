@@ -117,6 +117,11 @@ SYMBOLS = {
     "ggms_topology_read_host": (_i, [C.POINTER(Topology), C.c_char_p]),
     "ggms_link_probe_copy": (_i, [_vp, _vp, _sz, _i, _i, C.POINTER(C.c_double), _vp]),
     "ggms_link_probe_gather": (_i, [_vp, _vp, _u32, _sz, _sz, _sz, _u32, _i, _vp, C.POINTER(C.c_double), _vp]),
+    "ggms_launch_timer_create": (_i, [C.POINTER(C.c_void_p)]),
+    "ggms_launch_timer_destroy": (_i, [_vp]),
+    "ggms_launch_timer_arm": (_i, [_vp]),
+    "ggms_launch_timer_wait": (_i, [_vp, _vp]),
+    "ggms_launch_timer_elapsed_us": (_i, [_vp, C.POINTER(C.c_double)]),
 }
 
 ABI_VERSION = 3  # include/ggms.h as this binding declares it (struct layouts, host / device pointer conventions)

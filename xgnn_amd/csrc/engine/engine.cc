@@ -933,6 +933,7 @@ void Engine::TrainInit(int worker_id, const std::string &ctx) {
     SAM_HIP(hipEventCreate(&b->ev_sampled));
     SAM_HIP(hipEventCreate(&b->ev_xstart));
     SAM_HIP(hipEventCreate(&b->ev_done));
+    SAM_GGMS(ggms_launch_timer_create(&b->gather_timer));
     slots_.push_back(std::move(b));
   }
   train_ready_ = true;
@@ -1040,13 +1041,28 @@ bool Engine::EnqueueOne(bool background) {
   // between two gathers on the extract stream, which bounds the step.  (Not on a stream of its own: HIP streams share 4
   // hardware queues, and a fifth stream serialises streams that have nothing to do with each other.)
   SAM_GGMS(ggms_extract(b->label, label_src_, b->output_nodes, b->num_seeds, 1, GGMS_I64, ss));
-  SAM_HIP(hipEventRecord(b->ev_label, ss));
+  const bool mock = ds.feat_mask != 0xffffffffu; // SAMGRAPH_EMPTY_FEAT: host rows are node & mask
+  // The extract stream bounds the step, and every event record / wait / small copy on it is a packet the command
+  // processor works through between two gathers -- 28 us of dead time per 0.7-ms step with six of them
+  // (profiles/r05_ab_extract_stream.txt).  LEAN batch: the gather writes nothing the host reads (no miss / tier
+  // counters, no visit counts), so the batch's counts go to the host behind the label gather on the SAMPLING stream,
+  // which has the slack, and the extract stream carries one wait and the gather -- whose start / end timestamps and
+  // "rows are out" event ride on its own dispatch packet (b->gather_timer).  Otherwise the sequence the counters need.
+  const bool gather_counts = cfg.UseGPUCache() && (mock || num_replica_ || cache_table_);
+  static const bool lean_off = [] { const char *e = getenv("SAMGRAPH_LEAN_EXTRACT"); return e && e[0] == '0'; }(); // A/B hook
+  b->lean = !lean_off && !StagedHostTier() && !gather_counts && !node_access_dev_;
+  if (b->lean) {
+    SAM_HIP(hipMemcpyAsync(b->counts, b->counts_dev, (3 * L + 8) * 8, hipMemcpyDeviceToHost, ss));
+    SAM_HIP(hipEventRecord(b->ev_done, ss)); // labels and counts are out; the rows: gather_timer
+  } else {
+    SAM_HIP(hipEventRecord(b->ev_label, ss));
+  }
   // The gather is HBM-bound, the sampler latency-bound: they run on separate streams so that batch k's
   // extract overlaps batch k+1's sampling (the reference serialises them, dist_loops_arch6.cc:248-251)
   hipStream_t xs = stream_extract_;
   SAM_HIP(hipStreamWaitEvent(xs, b->ev_sampled, 0));
-  SAM_HIP(hipEventRecord(b->ev_xstart, xs)); // the extract's own start: behind the previous batch's extract on xs
-  const bool mock = ds.feat_mask != 0xffffffffu; // SAMGRAPH_EMPTY_FEAT: host rows are node & mask
+  if (b->lean) SAM_GGMS(ggms_launch_timer_arm(b->gather_timer));
+  else SAM_HIP(hipEventRecord(b->ev_xstart, xs)); // the extract's own start: behind the previous batch's extract on xs
   if (StagedHostTier()) {
     StagedExtract(b, ss, xs);
   } else if (cfg.UseGPUCache() && (mock || num_replica_)) { // every tier in one gather; rows per tier counted
@@ -1062,10 +1078,11 @@ bool Engine::EnqueueOne(bool background) {
     tiers.host_row_mask = mock ? ds.feat_mask : 0;
     SAM_GGMS(ggms_extract_tiered(b->feat, b->input_nodes, max_unique_, n_in, &tiers, ds.feat_dim, ds.feat_dtype, n_miss, xs));
   } else if (cfg.UseGPUCache()) {
-    // DoArch6GetCacheMissIndex + DoArch6GPUCacheFeatureCopy (dist_loops.cc:1015-1285) in one pass
+    // DoArch6GetCacheMissIndex + DoArch6GPUCacheFeatureCopy (dist_loops.cc:1015-1285) in one pass; everything cached in
+    // node order (no table): no row can miss, the count stays the zero the sampling stream wrote
     SAM_GGMS(ggms_extract_cached(b->feat, b->input_nodes, max_unique_, n_in, cache_table_,
                                  (const void *const *)cache_parts_.data(), num_cache_part_, feat_src_, ds.feat_dim,
-                                 ds.feat_dtype, n_miss, xs));
+                                 ds.feat_dtype, cache_table_ ? n_miss : nullptr, xs));
   } else if (mock) { // GPUMockExtract, cuda_loops.cc:692-700 / dist_loops.cc:608-616
     SAM_GGMS(ggms_gather_scatter_masked(b->feat, feat_src_, b->input_nodes, nullptr, max_unique_, n_in, ds.feat_dim,
                                         ds.feat_dtype, ds.feat_mask, xs));
@@ -1074,11 +1091,13 @@ bool Engine::EnqueueOne(bool background) {
     SAM_GGMS(ggms_gather_scatter(b->feat, feat_src_, b->input_nodes, nullptr, max_unique_, n_in, ds.feat_dim,
                                  ds.feat_dtype, xs));
   }
-  if (node_access_dev_) // Profiler::LogNodeAccess (profiler.cc:570-575): visits per node, counted on the device
-    SAM_GGMS(ggms_count_nodes(node_access_dev_, b->input_nodes, max_unique_, n_in, xs));
-  SAM_HIP(hipStreamWaitEvent(xs, b->ev_label, 0)); // the batch is complete when its labels are, too
-  SAM_HIP(hipMemcpyAsync(b->counts, b->counts_dev, (3 * L + 8) * 8, hipMemcpyDeviceToHost, xs));
-  SAM_HIP(hipEventRecord(b->ev_done, xs));
+  if (!b->lean) {
+    if (node_access_dev_) // Profiler::LogNodeAccess (profiler.cc:570-575): visits per node, counted on the device
+      SAM_GGMS(ggms_count_nodes(node_access_dev_, b->input_nodes, max_unique_, n_in, xs));
+    SAM_HIP(hipStreamWaitEvent(xs, b->ev_label, 0)); // the batch is complete when its labels are, too
+    SAM_HIP(hipMemcpyAsync(b->counts, b->counts_dev, (3 * L + 8) * 8, hipMemcpyDeviceToHost, xs));
+    SAM_HIP(hipEventRecord(b->ev_done, xs));
+  }
   {
     std::lock_guard<std::mutex> lk(pool_mu_);
     pool_.push_back(b); // graph_pool->Submit
@@ -1283,6 +1302,8 @@ void Engine::StagedExtract(Batch *b, hipStream_t ss, hipStream_t xs) {
 void Engine::Finish(Batch *b) {
   if (cfg.arch == kArch0) return; // complete (and logged) when it was enqueued
   SAM_HIP(hipEventSynchronize(b->ev_done));
+  double us_gather = 0; // a lean batch's rows: complete when its gather is (the timer's end event)
+  if (b->lean) SAM_GGMS(ggms_launch_timer_elapsed_us(b->gather_timer, &us_gather));
   const uint32_t L = (uint32_t)cfg.fanout.size();
   b->num_input = b->counts[3 * L];
   b->num_miss = b->counts[3 * L + 2];
@@ -1297,7 +1318,8 @@ void Engine::Finish(Batch *b) {
   }
   float ms_sample = 0, ms_copy = 0;
   (void)hipEventElapsedTime(&ms_sample, b->ev_start, b->ev_sampled);
-  (void)hipEventElapsedTime(&ms_copy, b->ev_xstart, b->ev_done); // not from ev_sampled: that would add the queueing behind the previous extract
+  if (b->lean) ms_copy = (float)(us_gather * 1e-3); // the gather kernel's own time
+  else (void)hipEventElapsedTime(&ms_copy, b->ev_xstart, b->ev_done); // not from ev_sampled: that would add the queueing behind the previous extract
   uint64_t edges = 0;
   for (uint32_t i = 0; i < L; ++i) edges += b->counts[3 * i];
   const double row_bytes = (double)ds.feat_dim * ggms_dtype_bytes(ds.feat_dtype);

@@ -153,6 +153,10 @@ struct Batch {
   uint32_t *miss_ids_host = nullptr; // hipHostMalloc
   hipEvent_t ev_ids = nullptr;       // the miss ids have reached the host
   hipEvent_t ev_label = nullptr;     // the labels of the batch are gathered
+  // the feature gather's own start / end timestamps, riding on its dispatch packet (include/ggms.h, launch timer);
+  // lean: this batch's extract stream carried the gather and nothing else (EnqueueOne)
+  ggms_launch_timer_t *gather_timer = nullptr;
+  bool lean = false;
 };
 
 class Engine {

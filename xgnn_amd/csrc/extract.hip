@@ -20,6 +20,8 @@
 // Algorithmic bytes per row: 4 (index) + 2 * row_bytes.
 #include <cstdlib>
 
+#include <hip/hip_ext.h>
+
 #include "ggms_device.h"
 
 namespace ggms {
@@ -307,6 +309,32 @@ static inline int pick_chunk(size_t row_bytes, uintptr_t align_bits) {
   return 1;
 }
 
+} // namespace ggms
+
+// ---- launch timer (include/ggms.h): a pair of events that ride on the next gather's own dispatch packet ------------
+struct ggms_launch_timer {
+  hipEvent_t start = nullptr, stop = nullptr;
+  bool launched = false; // the pair has been attached to a launch (its timestamps mean something)
+};
+
+namespace ggms {
+
+static thread_local ggms_launch_timer *tl_armed_timer = nullptr;
+
+// One row-gather launch: with a timer armed on this thread the kernel goes out through hipExtLaunchKernel carrying
+// the timer's events (start = the dispatch's own begin timestamp, stop = its completion signal) -- no marker packet
+// before or behind it; otherwise the plain launch.
+template <typename F, typename... Args>
+static inline void launch_rows(F kernel, int grid, hipStream_t stream, Args... args) {
+  if (ggms_launch_timer *t = tl_armed_timer) {
+    tl_armed_timer = nullptr;
+    t->launched = true;
+    hipExtLaunchKernelGGL(kernel, dim3(grid), dim3(kBlock), 0, stream, t->start, t->stop, 0, args...);
+  } else {
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlock), 0, stream, args...);
+  }
+}
+
 template <typename Rows>
 static int launch_gather(char *out, Rows rows, const uint32_t *dst_index, size_t n_max, Count n,
                          size_t row_bytes, int cb, uint64_t *miss_count, hipStream_t stream) {
@@ -319,11 +347,11 @@ static int launch_gather(char *out, Rows rows, const uint32_t *dst_index, size_t
   if (rc >= 8192) {
     const int g = grid_for(n_max, 1);
     switch (cb) {
-      case 16: hipLaunchKernelGGL((k_gather_long_rows<16, Rows>), dim3(g), dim3(kBlock), 0, stream, out, rows, dst_index, n, rc, miss_count); break;
-      case 8: hipLaunchKernelGGL((k_gather_long_rows<8, Rows>), dim3(g), dim3(kBlock), 0, stream, out, rows, dst_index, n, rc, miss_count); break;
-      case 4: hipLaunchKernelGGL((k_gather_long_rows<4, Rows>), dim3(g), dim3(kBlock), 0, stream, out, rows, dst_index, n, rc, miss_count); break;
-      case 2: hipLaunchKernelGGL((k_gather_long_rows<2, Rows>), dim3(g), dim3(kBlock), 0, stream, out, rows, dst_index, n, rc, miss_count); break;
-      default: hipLaunchKernelGGL((k_gather_long_rows<1, Rows>), dim3(g), dim3(kBlock), 0, stream, out, rows, dst_index, n, rc, miss_count); break;
+      case 16: launch_rows(k_gather_long_rows<16, Rows>, g, stream, out, rows, dst_index, n, rc, miss_count); break;
+      case 8: launch_rows(k_gather_long_rows<8, Rows>, g, stream, out, rows, dst_index, n, rc, miss_count); break;
+      case 4: launch_rows(k_gather_long_rows<4, Rows>, g, stream, out, rows, dst_index, n, rc, miss_count); break;
+      case 2: launch_rows(k_gather_long_rows<2, Rows>, g, stream, out, rows, dst_index, n, rc, miss_count); break;
+      default: launch_rows(k_gather_long_rows<1, Rows>, g, stream, out, rows, dst_index, n, rc, miss_count); break;
     }
     GGMS_LAUNCH_CHECK();
     return GGMS_OK;
@@ -343,11 +371,9 @@ static int launch_gather(char *out, Rows rows, const uint32_t *dst_index, size_t
 #define GGMS_LAUNCH(CB, ID)                                                                                          \
   do {                                                                                                               \
     if (deep)                                                                                                        \
-      hipLaunchKernelGGL((k_gather_rows<CB, Rows, ID, 16>), dim3(grid), dim3(kBlock), 0, stream, out, rows, dst_index, n, \
-                         (uint32_t)rc, magic, miss_count);                                                           \
+      launch_rows(k_gather_rows<CB, Rows, ID, 16>, grid, stream, out, rows, dst_index, n, (uint32_t)rc, magic, miss_count); \
     else                                                                                                             \
-      hipLaunchKernelGGL((k_gather_rows<CB, Rows, ID, 8>), dim3(grid), dim3(kBlock), 0, stream, out, rows, dst_index, n, \
-                         (uint32_t)rc, magic, miss_count);                                                           \
+      launch_rows(k_gather_rows<CB, Rows, ID, 8>, grid, stream, out, rows, dst_index, n, (uint32_t)rc, magic, miss_count); \
   } while (0)
 #define GGMS_CASE(CB)                                        \
   case CB:                                                   \
@@ -394,8 +420,8 @@ int ggms_gather_scatter(void *out, const void *src, const ggms_id_t *src_index, 
   GGMS_CHECK_ARG(out && src);
   const size_t row_bytes = dim * es;
   if (!src_index && !dst_index && row_bytes % 4 == 0 && (((uintptr_t)out | (uintptr_t)src) & 3) == 0) {
-    hipLaunchKernelGGL(k_copy_words, dim3(grid_for(num * (row_bytes / 4), kBlock * 4)), dim3(kBlock), 0, to_stream(stream),
-                       (uint32_t *)out, (const uint32_t *)src, count_of(num, num_dev), (uint32_t)(row_bytes / 4));
+    launch_rows(k_copy_words, grid_for(num * (row_bytes / 4), kBlock * 4), to_stream(stream), (uint32_t *)out,
+                (const uint32_t *)src, count_of(num, num_dev), (uint32_t)(row_bytes / 4));
     GGMS_LAUNCH_CHECK();
     return GGMS_OK;
   }
@@ -488,6 +514,58 @@ int ggms_extract_tiered(void *out, const ggms_id_t *nodes, size_t num_nodes, con
                   tiers->my_part, tiers->host_row_mask ? tiers->host_row_mask : 0xffffffffu};
   return launch_gather((char *)out, rows, nullptr, num_nodes, count_of(num_nodes, num_nodes_dev), row_bytes, cb,
                        tier_rows_dev, to_stream(stream));
+}
+
+// ---- launch timer ---------------------------------------------------------------------------------------------------
+int ggms_launch_timer_create(ggms_launch_timer_t **timer) {
+  GGMS_CHECK_ARG(timer);
+  ggms_launch_timer *t = new ggms_launch_timer();
+  hipError_t e = hipEventCreate(&t->start);
+  if (e == hipSuccess) e = hipEventCreate(&t->stop);
+  if (e != hipSuccess) {
+    if (t->start) (void)hipEventDestroy(t->start);
+    delete t;
+    set_error("ggms_launch_timer_create: hipEventCreate -> %s", hipGetErrorString(e));
+    return GGMS_ERR_HIP;
+  }
+  *timer = t;
+  return GGMS_OK;
+}
+
+int ggms_launch_timer_destroy(ggms_launch_timer_t *timer) {
+  if (!timer) return GGMS_OK;
+  if (tl_armed_timer == timer) tl_armed_timer = nullptr;
+  const hipError_t e0 = hipEventDestroy(timer->start), e1 = hipEventDestroy(timer->stop);
+  delete timer;
+  GGMS_HIP(e0);
+  GGMS_HIP(e1);
+  return GGMS_OK;
+}
+
+int ggms_launch_timer_arm(ggms_launch_timer_t *timer) {
+  GGMS_CHECK_ARG(timer);
+  timer->launched = false;
+  tl_armed_timer = timer;
+  return GGMS_OK;
+}
+
+int ggms_launch_timer_wait(ggms_launch_timer_t *timer, ggms_stream_t stream) {
+  GGMS_CHECK_ARG(timer);
+  if (timer->launched) GGMS_HIP(hipStreamWaitEvent(to_stream(stream), timer->stop, 0));
+  return GGMS_OK;
+}
+
+int ggms_launch_timer_elapsed_us(ggms_launch_timer_t *timer, double *us) {
+  GGMS_CHECK_ARG(timer && us);
+  if (!timer->launched) {
+    set_error("ggms_launch_timer_elapsed_us: the timer never rode a launch (armed on another thread, or the call had no rows)");
+    return GGMS_ERR_INVALID;
+  }
+  GGMS_HIP(hipEventSynchronize(timer->stop));
+  float ms = 0.f;
+  GGMS_HIP(hipEventElapsedTime(&ms, timer->start, timer->stop));
+  *us = (double)ms * 1e3;
+  return GGMS_OK;
 }
 
 } // extern "C"

@@ -382,6 +382,40 @@ def extract_tiered(out, nodes, table, replica, parts_table, num_part, my_part, h
     return out
 
 
+class LaunchTimer:
+    """ggms_launch_timer_t (include/ggms.h): the next row gather issued by this thread carries the timer's two events ON
+    its dispatch packet -- the kernel's own start / end timestamps, no marker packet on the stream.  `wait(stream)` makes
+    another stream wait for that launch; `elapsed_us()` blocks until it has finished."""
+
+    def __init__(self):
+        self._h = C.c_void_p()
+        check(lib().ggms_launch_timer_create(C.byref(self._h)), "ggms_launch_timer_create")
+
+    def arm(self):
+        check(lib().ggms_launch_timer_arm(self._h), "ggms_launch_timer_arm")
+        return self
+
+    def wait(self, stream=None):
+        s = _stream() if stream is None else C.c_void_p(stream.cuda_stream)
+        check(lib().ggms_launch_timer_wait(self._h, s), "ggms_launch_timer_wait")
+
+    def elapsed_us(self):
+        us = C.c_double(0)
+        check(lib().ggms_launch_timer_elapsed_us(self._h, C.byref(us)), "ggms_launch_timer_elapsed_us")
+        return us.value
+
+    def close(self):
+        if self._h:
+            lib().ggms_launch_timer_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001 -- interpreter shutdown
+            pass
+
+
 def owner_histogram(table, nodes, num_part, slots_out, counts, num=None, num_dev=None):
     """slots_out[i] = table[nodes[i]]; counts[p] += rows of the batch owned by shard p (p = num_part: host tier)."""
     _require_gpu(nodes)
