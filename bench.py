@@ -659,8 +659,10 @@ def main():
     out = [torch.empty((sampler.max_unique, dim), dtype=torch.float32, device=dev) for _ in range(NSLOT)]
     out_label = [torch.empty(sampler.max_seeds, dtype=torch.int64, device=dev) for _ in range(NSLOT)]
     L = len(fanouts)
-    s_samples = [torch.cuda.Stream(device=dev) for _ in range(K)]
-    s_extract = s_samples[0] if args.no_overlap else torch.cuda.Stream(device=dev)
+    # A/B hook: HIP stream priorities ("sample" / "extract" = that side's streams at high priority); default: none
+    prio = os.environ.get("GGMS_BENCH_STREAM_PRIORITY", "")
+    s_samples = [torch.cuda.Stream(device=dev, priority=-1 if prio == "sample" else 0) for _ in range(K)]
+    s_extract = s_samples[0] if args.no_overlap else torch.cuda.Stream(device=dev, priority=-1 if prio == "extract" else 0)
     slot_free = [None] * NSLOT  # event: the slot's previous extract has finished
 
     # DistAlignedShuffler semantics (dist_shuffler_aligned.cc:37-146): pad to a multiple of world,
