@@ -87,10 +87,11 @@ def parse():
     ap.add_argument("--host-steps", type=int, default=10, help="timed steps of the host-tier sub-record")
     ap.add_argument("--host-profile", action="store_true", help="print host enqueue time per section to stderr")
     ap.add_argument("--pipelines", type=int, default=None,
-                    help="sampling batches in flight (each on its own stream with its own dedup table).  Default 1; 2 for "
+                    help="sampling batches in flight (each on its own stream with its own dedup table).  Default: 2 for "
                          "khop0, whose generator is re-seeded per launch -- its batches do not have to consume a shared "
                          "generator pool in order, so a second one in flight fills the first one's latency chains "
-                         "(profiles/r03_ab_pipelines_products.txt)")
+                         "(profiles/r03_ab_pipelines_products.txt); every other sampler: 1 or 2, whichever a 10-step trial "
+                         "before the timed region finds faster (config.pipelines_trial)")
     ap.add_argument("--slots", type=int, default=0,
                     help="batch slots (a batch's outputs stay valid until its extract is done); default pipelines + 1")
     ap.add_argument("--heavy-after-gather", action="store_true",
@@ -650,8 +651,13 @@ def main():
         extra_kw = dict(random_walk_length=3, random_walk_restart_prob=0.5, num_random_walk=4)
     # batches in flight: K sampling pipelines (own stream, dedup table, workspace; RNG pool consumed in batch
     # order) + the extract stream; outputs live in batch slots, as in the engine
+    # Default (no --pipelines / --slots): khop0 runs two; every other sampler is TRIED with one and with two before the
+    # timed region (10 steps each, outside it) and runs with two only where that is at least 5 % faster -- two chains
+    # fill each other's latency gaps on small frontiers (papers100M [25,10]: 0.19 -> 0.165 ms/step) and only add
+    # memory-side contention on large ones (default workload + 3 %, products + 7 %: profiles/r05_ab_pipelines.txt).
+    auto_pipes = args.pipelines is None and not args.slots and args.sample_type != "khop0" and not args.no_overlap
     if args.pipelines is None:
-        args.pipelines = 2 if args.sample_type == "khop0" else 1
+        args.pipelines = 2 if (args.sample_type == "khop0" or auto_pipes) else 1
     K = 1 if args.no_overlap else max(1, args.pipelines)
     NSLOT = args.slots if args.slots else K + 1
     sampler = ops.BatchSampler(g, fanouts, args.batch, sample_type=code, seed=0x5EED + rank, device=dev,
@@ -849,7 +855,24 @@ def main():
         main_store = "replica"
         extract_main, keep_main = build_store(main_store)
     main_plan = dict(hybrid_plan) if main_store == "hybrid" else {}
-    blocks, next_step = measure(extract_main, args.steps, args.warmup, repeats)
+    pipes_trial, first_main = None, 0
+    if auto_pipes:
+        # every rank sees the same (max-over-ranks) times and takes the same turn
+        trial_steps, per_k = 10, {}
+        for k in (1, 2):
+            K, NSLOT = k, k + 1
+            sampler.use_pipelines(k)
+            slot_free[:] = [None] * len(slot_free)
+            tb, first_main = measure(extract_main, trial_steps, 3, 1, first_step=first_main)
+            per_k[k] = tb[0]["elapsed"] / trial_steps * 1e3
+        K = 2 if per_k[2] < 0.95 * per_k[1] else 1
+        NSLOT = K + 1
+        sampler.use_pipelines(K)
+        slot_free[:] = [None] * len(slot_free)
+        pipes_trial = {"ms_per_step_with_1": per_k[1], "ms_per_step_with_2": per_k[2], "chosen": K,
+                       "rule": "10 steps each before the timed region; two pipelines only if at least 5 % faster"}
+        log(f"pipelines trial: {per_k} -> {K}")
+    blocks, next_step = measure(extract_main, args.steps, args.warmup, repeats, first_step=first_main)
     log("main region done")
     blk = median_block(blocks)
     elapsed, edges_all = blk["elapsed"], blk["edges_all"]
@@ -989,6 +1012,7 @@ def main():
                 "streams": "1 (serial)" if args.no_overlap else
                            f"{K} sampling pipeline(s) (batches in flight, RNG pool consumed in batch order; label gather behind the "
                            "batch) + 1 extract stream (the feature gather alone)",
+                **({"pipelines_trial": pipes_trial} if pipes_trial else {}),
                 "neighbour_skew": args.neighbour_skew,
                 "seeds_distinct_promise": not args.no_distinct_seeds,
                 **({"topology": topo_record} if topo_record else {}),
@@ -1301,7 +1325,8 @@ def main():
                      "feature_extract_GBps": r["feature_extract_GBps"], "gather_frac": rf["frac"],
                      "gather_frac_alone": rf["frac_alone"], "rows_verified": r["rows_verified"],
                      "edges_per_step": r["per_gpu"]["edges_per_step"], "rows_per_step": r["per_gpu"]["rows_per_step"],
-                     "spread": r["repeats"]["spread"]}
+                     "spread": r["repeats"]["spread"], "streams": r["config"]["streams"],
+                     "pipelines_trial": r["config"].get("pipelines_trial")}
             res["configs"][name] = r
         log("configs sub-record done")
 

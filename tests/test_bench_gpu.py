@@ -34,6 +34,10 @@ def test_single_gpu_line():
     assert KEYS <= set(d) and "cpu_baseline" in d and "host_tier" in d
     assert d["n_gpus"] == 1 and d["value"] > 0 and d["roofline"]["bound"] == "hbm" and d["config"]["workload"]
     assert d["rows_verified"] and d["repeats"]["blocks"] == 3 and 0 < d["roofline"]["hbm_read_frac"] < 0.5
+    # one or two sampling pipelines: tried before the timed region, the line says what was chosen and why
+    pt = d["config"]["pipelines_trial"]
+    assert pt["chosen"] in (1, 2) and pt["ms_per_step_with_1"] > 0 and pt["ms_per_step_with_2"] > 0
+    assert d["config"]["streams"].startswith(f"{pt['chosen']} sampling pipeline")
     assert d["host_tier"]["feature_extract_GBps"] > 0 and d["host_tier"]["pinned_h2d_copy_GBps"] > 0
     cb = d["cpu_baseline"]
     assert cb["cores"] >= 1 and cb["value"] > 0 and set(cb["seconds"]) == {"sample", "remap", "extract", "total"}

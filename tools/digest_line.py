@@ -15,6 +15,10 @@ def main():
               f"{b['pinned_h2d_GBps']:.1f} GB/s, atomics {b.get('atomics_per_s', 0) / 1e9:.1f} G/s, random 4-B loads "
               f"{b.get('loads_per_s', 0) / 1e9:.1f} G/s | headline {d['value']:.4g} edges/s, {d['ms_per_step']:.4f} ms/step, "
               f"value_over_box {d['value_over_box']:.4g}")
+        pt = d.get("config", {}).get("pipelines_trial")
+        if pt:
+            print(f"sampling pipelines: {pt['chosen']} (trial before the timed region: {pt['ms_per_step_with_1']:.4f} / "
+                  f"{pt['ms_per_step_with_2']:.4f} ms/step with one / two)")
         r = d["roofline"]
         print(f"gather: {r['frac']:.3f} of 8 TB/s in the pipeline, {r['frac_alone']:.3f} alone; hbm_read_frac {r['hbm_read_frac']:.3f} "
               f"(target {r['hbm_read_frac_target']}, ceiling for a copy on this box {r['hbm_read_frac_ceiling_for_a_copy']:.3f})")
@@ -25,7 +29,9 @@ def main():
                 continue
             print(f"configs.{k}: {c['ms_per_step']:.4f} ms/step, {c['edges_per_s']:.4g} edges/s, feature {c['feature_extract_GBps']:.0f} GB/s, "
                   f"gather {c['gather_frac']:.3f} in the pipeline / {c['gather_frac_alone']:.3f} alone, {c['edges_per_step']:.0f} edges and "
-                  f"{c['rows_per_step']:.0f} rows per step")
+                  f"{c['rows_per_step']:.0f} rows per step"
+                  + (f"; sampling pipelines {c['pipelines_trial']['chosen']} (trial: {c['pipelines_trial']['ms_per_step_with_1']:.4f} / "
+                     f"{c['pipelines_trial']['ms_per_step_with_2']:.4f} ms with one / two)" if c.get("pipelines_trial") else ""))
     st = (d.get("host_tier") or {}).get("staged") or d.get("host_tier_staged")
     if what in ("staged", "all") and st:
         h = d.get("host_tier") or {}

@@ -582,6 +582,14 @@ class BatchSampler:
                 check(lib().ggms_event_create(C.byref(e)), "ggms_event_create")
                 self._events.append(e)
         self._batch_no = 0
+        self.active_pipelines = num_pipelines
+
+    def use_pipelines(self, k):
+        """Run the following batches on the first k of the allocated pipelines (1 <= k <= num_pipelines).  The caller
+        has drained the device (nothing of an earlier batch is in flight): the batch order on the RNG pool starts anew."""
+        assert 1 <= k <= self.num_pipelines
+        self.active_pipelines = k
+        self._batch_no = 0
 
     def __del__(self):
         try:
@@ -599,7 +607,7 @@ class BatchSampler:
         _i32(seeds)
         n = seeds.numel()
         assert n <= self.max_seeds
-        b, K = self._batch_no, self.num_pipelines
+        b, K = self._batch_no, self.active_pipelines
         self._batch_no += 1
         pipe = b % K
         self.ht = self.hts[pipe]
@@ -609,9 +617,11 @@ class BatchSampler:
         if self.datas is not None:
             ex.data = C.cast(self._datas[slot], C.c_void_p)
             self.data = self.datas[slot]
-        if self._events:
+        if self._events and K > 1:
             ex.rng_wait = self._events[(b - 1) % K] if b > 0 else None
             ex.rng_done = self._events[pipe]
+        else:
+            ex.rng_wait = ex.rng_done = None
         # heavy_wait (torch.cuda.Event): the last layer's sampler launch waits for it (ggms_sample_extra_t.heavy_wait)
         ex.heavy_wait = C.c_void_p(heavy_wait.cuda_event) if heavy_wait is not None else None
         ex.seeds_distinct = 1 if distinct else 0
