@@ -92,6 +92,10 @@ def parse():
                          "generator pool in order, so a second one in flight fills the first one's latency chains "
                          "(profiles/r03_ab_pipelines_products.txt); every other sampler: 1 or 2, whichever a 10-step trial "
                          "before the timed region finds faster (config.pipelines_trial)")
+    ap.add_argument("--extract-streams", type=int, default=None, choices=[1, 2],
+                    help="streams the feature gathers are issued on: with 2, consecutive batches' gathers alternate and may "
+                         "overlap (no wait packet between two gathers, one gather's head fills the other's tail).  Default: "
+                         "tried before the timed region like --pipelines (config.pipelines_trial)")
     ap.add_argument("--slots", type=int, default=0,
                     help="batch slots (a batch's outputs stay valid until its extract is done); default pipelines + 1")
     ap.add_argument("--heavy-after-gather", action="store_true",
@@ -655,11 +659,14 @@ def main():
     # timed region (10 steps each, outside it) and runs with two only where that is at least 5 % faster -- two chains
     # fill each other's latency gaps on small frontiers (papers100M [25,10]: 0.19 -> 0.165 ms/step) and only add
     # memory-side contention on large ones (default workload + 3 %, products + 7 %: profiles/r05_ab_pipelines.txt).
-    auto_pipes = args.pipelines is None and not args.slots and args.sample_type != "khop0" and not args.no_overlap
+    auto_pipes = (args.pipelines is None and args.extract_streams is None and not args.slots and not args.no_overlap)
+    khop0 = args.sample_type == "khop0"
     if args.pipelines is None:
-        args.pipelines = 2 if (args.sample_type == "khop0" or auto_pipes) else 1
+        args.pipelines = 2 if (khop0 or auto_pipes) else 1
     K = 1 if args.no_overlap else max(1, args.pipelines)
-    NSLOT = args.slots if args.slots else K + 1
+    # extract streams in use (allocated: two unless --no-overlap / --extract-streams 1)
+    n_xs = 1 if args.no_overlap else (args.extract_streams or (2 if auto_pipes else 1))
+    NSLOT = args.slots if args.slots else K + n_xs - (1 if auto_pipes and not khop0 else 0)  # (the trial never runs 2 x 2)
     sampler = ops.BatchSampler(g, fanouts, args.batch, sample_type=code, seed=0x5EED + rank, device=dev,
                                num_slots=NSLOT, num_pipelines=K, **extra_kw)
     out = [torch.empty((sampler.max_unique, dim), dtype=torch.float32, device=dev) for _ in range(NSLOT)]
@@ -669,6 +676,8 @@ def main():
     prio = os.environ.get("GGMS_BENCH_STREAM_PRIORITY", "")
     s_samples = [torch.cuda.Stream(device=dev, priority=-1 if prio == "sample" else 0) for _ in range(K)]
     s_extract = s_samples[0] if args.no_overlap else torch.cuda.Stream(device=dev, priority=-1 if prio == "extract" else 0)
+    # a second extract stream: consecutive batches' gathers alternate and may overlap (profiles/r05_ab_extract_streams.txt)
+    s_extracts = [s_extract] + [torch.cuda.Stream(device=dev) for _ in range(n_xs - 1)]
     slot_free = [None] * NSLOT  # event: the slot's previous extract has finished
 
     # DistAlignedShuffler semantics (dist_shuffler_aligned.cc:37-146): pad to a multiple of world,
@@ -731,6 +740,8 @@ def main():
                 labelled = torch.cuda.Event()
                 labelled.record(s_sample)
             h3 = time.perf_counter()
+            # (an extract with collectives inside -- the a2a store -- stays on ONE stream: every rank issues them in one order)
+            s_extract = s_extracts[step % n_xs] if getattr(extract_fn, "single_launch", True) else s_extracts[0]
             with torch.cuda.stream(s_extract):
                 s_extract.wait_event(sampled)
                 counts = sampler.counts_slots[slot]
@@ -812,18 +823,23 @@ def main():
             t_sample_ms = sum(e[0].elapsed_time(e[1]) for e in ev)   # on the sampling stream
             if timed and step_events:  # HIP events on the gather's own dispatch packet, on the stream it is launched on
                 t_extract_ms = sum(t.elapsed_us() for t in step_tm) / 1e3
+                span_ms = step_tm[0].span_us(step_tm[-1]) / 1e3  # first launch's start -> last launch's end
             else:                      # HIP event pair around the launch on that stream
                 t_extract_ms = sum(e[2].elapsed_time(e[3]) for e in ev)
+                span_ms = t_extract_ms
             if not step_events:
-                t_sample_ms = t_extract_ms = elapsed * 1e3
+                t_sample_ms = t_extract_ms = span_ms = elapsed * 1e3
+            # gathers on two streams overlap: a launch's own duration then counts time it shares with its neighbour;
+            # sum of durations / span = launches in flight on average (below 1 on one stream: the gaps between them)
+            in_flight = max(1.0, t_extract_ms / span_ms) if span_ms > 0 else 1.0
             stats = torch.tensor([elapsed, float(edges), float(rows), t_sample_ms, t_extract_ms,
-                                  rows * row_bytes / (t_extract_ms / 1e3) / 1e9]
+                                  rows * row_bytes / (t_extract_ms / in_flight / 1e3) / 1e9]
                                  + [float(x) for x in counters.cpu().tolist()], dtype=torch.float64, device=dev)
             if world > 1 and backend != "nccl":
                 stats = stats.cpu()
             mx, sm = parallel.reduce_stats(stats, dist if world > 1 else None)
             blocks.append(dict(elapsed=mx[0].item(), edges_all=sm[1].item(), rows_all=sm[2].item(), edges=edges,
-                               rows=rows, inputs=inputs, t_sample_ms=t_sample_ms, t_extract_ms=t_extract_ms,
+                               rows=rows, inputs=inputs, t_sample_ms=t_sample_ms, t_extract_ms=t_extract_ms, in_flight=in_flight,
                                feat_rate_all=sm[5].item(), tiers_all=[sm[6 + i].item() for i in range(4)]))
         return blocks, first_step + total
 
@@ -858,20 +874,26 @@ def main():
     pipes_trial, first_main = None, 0
     if auto_pipes:
         # every rank sees the same (max-over-ranks) times and takes the same turn
-        trial_steps, per_k = 10, {}
-        for k in (1, 2):
-            K, NSLOT = k, k + 1
+        trial_steps, per, base = 12, {}, None
+        cands = [(2, 1), (2, 2)] if khop0 else [(1, 1), (1, 2), (2, 1)]  # (sampling pipelines, extract streams); baseline first
+        if not getattr(extract_main, "single_launch", True):
+            cands = [c for c in cands if c[1] == 1]
+        for k, x in cands:
+            K, n_xs, NSLOT = k, x, k + x
             sampler.use_pipelines(k)
             slot_free[:] = [None] * len(slot_free)
             tb, first_main = measure(extract_main, trial_steps, 3, 1, first_step=first_main)
-            per_k[k] = tb[0]["elapsed"] / trial_steps * 1e3
-        K = 2 if per_k[2] < 0.95 * per_k[1] else 1
-        NSLOT = K + 1
+            per[(k, x)] = tb[0]["elapsed"] / trial_steps * 1e3
+        base = cands[0]
+        best = min(per, key=per.get)
+        K, n_xs = best if per[best] < 0.97 * per[base] else base
+        NSLOT = K + n_xs
         sampler.use_pipelines(K)
         slot_free[:] = [None] * len(slot_free)
-        pipes_trial = {"ms_per_step_with_1": per_k[1], "ms_per_step_with_2": per_k[2], "chosen": K,
-                       "rule": "10 steps each before the timed region; two pipelines only if at least 5 % faster"}
-        log(f"pipelines trial: {per_k} -> {K}")
+        pipes_trial = {"ms_per_step": {f"{k} pipeline(s), {x} extract stream(s)": v for (k, x), v in per.items()},
+                       "chosen": {"pipelines": K, "extract_streams": n_xs},
+                       "rule": f"{trial_steps} steps each before the timed region; the first entry unless another is at least 3 % faster"}
+        log(f"pipelines trial: {per} -> {K} x {n_xs}")
     blocks, next_step = measure(extract_main, args.steps, args.warmup, repeats, first_step=first_main)
     log("main region done")
     blk = median_block(blocks)
@@ -969,12 +991,15 @@ def main():
     if rank == 0:
         ext_s = blk["t_extract_ms"] / 1e3
         algo_bytes_per_launch = rows / args.steps * (4 + 2 * row_bytes)
-        avg_launch_s = ext_s / args.steps
-        achieved = algo_bytes_per_launch / avg_launch_s / 1e9
+        avg_launch_s = ext_s / args.steps  # a launch's own duration (what rocprof's kernel trace averages)
+        # launches in flight on average: 1 on one extract stream; with two, consecutive gathers overlap and every launch's own
+        # duration counts the time it shares with its neighbour -- the kernel moves in_flight launches' bytes in that time
+        in_flight = blk["in_flight"]
+        achieved = algo_bytes_per_launch * in_flight / avg_launch_s / 1e9
         tr = measured_traffic(args.preset)
         traffic = None
         if tr is not None and not tr["stale"] and world == 1 and full:  # (the profiled kernel: one GPU, every row in HBM) PMC bytes per row (profiled run of this command) x rows of this run / this run's launch time
-            traffic = tr["hbm_bytes_per_launch"] / tr["rows_per_launch"] * (rows / args.steps) / avg_launch_s / 1e9
+            traffic = tr["hbm_bytes_per_launch"] / tr["rows_per_launch"] * (rows / args.steps) * in_flight / avg_launch_s / 1e9
         elapsed_all = [b["elapsed"] for b in blocks]
         res = {
             "metric": "sampled edges/s + feature-extract GB/s per epoch-step",
@@ -1011,7 +1036,8 @@ def main():
                 "parallelism": f"dp{world}",
                 "streams": "1 (serial)" if args.no_overlap else
                            f"{K} sampling pipeline(s) (batches in flight, RNG pool consumed in batch order; label gather behind the "
-                           "batch) + 1 extract stream (the feature gather alone)",
+                           f"batch) + {n_xs} extract stream(s) (the feature gathers alone"
+                           + ("; consecutive batches' gathers alternate between them and may overlap)" if n_xs > 1 else ")"),
                 **({"pipelines_trial": pipes_trial} if pipes_trial else {}),
                 "neighbour_skew": args.neighbour_skew,
                 "seeds_distinct_promise": not args.no_distinct_seeds,
@@ -1036,7 +1062,7 @@ def main():
                 "frac": achieved / 8000.0, "traffic": traffic,
                 # the READ side alone, rows * (dim * 4 + 4) / t / 8e12 (a gather also writes every byte
                 # it reads, so this figure cannot exceed half of what the memory system sustains)
-                "hbm_read_frac": rows / args.steps * (row_bytes + 4) / avg_launch_s / 8e12,
+                "hbm_read_frac": rows / args.steps * (row_bytes + 4) * in_flight / avg_launch_s / 8e12,
                 # north_star's target is stated on this read-only figure; a gather writes every byte it reads, so the
                 # figure cannot pass HALF of what a device-to-device copy sustains on the box (guide: 6.29 of 8 TB/s)
                 "hbm_read_frac_target": 0.60,
@@ -1048,6 +1074,15 @@ def main():
                 serial_rows * (row_bytes + 4) / (serial_us * 1e-6) / 8e12,
                 "algorithmic_bytes_per_row": 4 + 2 * row_bytes,
                 "avg_launch_us": avg_launch_s * 1e6,
+                # achieved = algorithmic bytes per launch x launches_in_flight / avg_launch_us
+                "launches_in_flight": in_flight,
+                "extract_streams": n_xs,
+                "frac_of_one_launch": algo_bytes_per_launch / avg_launch_s / 1e9 / 8000.0,
+                **({"in_flight_note": "two extract streams: consecutive batches' gathers overlap (sum of the launches' own durations "
+                                      "/ time from the first launch's start to the last one's end = launches_in_flight); a launch's "
+                                      "own duration -- avg_launch_us, rocprof's average -- counts the time it shares with its "
+                                      "neighbour, so the kernel's rate is launches_in_flight launches' bytes per avg_launch_us; "
+                                      "frac_of_one_launch is what ONE of the overlapping launches gets"} if in_flight > 1.0 else {}),
                 "avg_launch_us_alone": serial_us,
                 "traffic_source": (tr["source"] + (" (stale: extract.hip changed since; traffic nulled)" if tr["stale"] else
                                                    f" @ extract.hip sha256 {tr['extract_hip_sha256'][:12]}")) if tr else None,

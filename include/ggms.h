@@ -498,6 +498,7 @@ int ggms_extract_tiered(void *out, const ggms_id_t *nodes, size_t num_nodes,
  *                zero rows -- leaves it armed)
  *   wait(t, s):  stream s waits for the timed launch (no-op if the timer never rode a launch)
  *   elapsed_us:  blocks until the launch has finished; GGMS_ERR_INVALID if the timer never rode a launch
+ *   span_us:     see below
  * ------------------------------------------------------------------------- */
 typedef struct ggms_launch_timer ggms_launch_timer_t;
 int ggms_launch_timer_create(ggms_launch_timer_t **timer);
@@ -505,6 +506,9 @@ int ggms_launch_timer_destroy(ggms_launch_timer_t *timer);
 int ggms_launch_timer_arm(ggms_launch_timer_t *timer);
 int ggms_launch_timer_wait(ggms_launch_timer_t *timer, ggms_stream_t stream);
 int ggms_launch_timer_elapsed_us(ggms_launch_timer_t *timer, double *us);
+/* from the start of `first`'s launch to the end of `last`'s (both finished: blocks for them): with launches that may
+ * overlap on two streams, sum of durations / span = how many are in flight on average */
+int ggms_launch_timer_span_us(ggms_launch_timer_t *first, ggms_launch_timer_t *last, double *us);
 
 /* ---------------------------------------------------------------------------
  * GGMS shards across processes (one process per GPU).

@@ -36,8 +36,14 @@ def test_single_gpu_line():
     assert d["rows_verified"] and d["repeats"]["blocks"] == 3 and 0 < d["roofline"]["hbm_read_frac"] < 0.5
     # one or two sampling pipelines: tried before the timed region, the line says what was chosen and why
     pt = d["config"]["pipelines_trial"]
-    assert pt["chosen"] in (1, 2) and pt["ms_per_step_with_1"] > 0 and pt["ms_per_step_with_2"] > 0
-    assert d["config"]["streams"].startswith(f"{pt['chosen']} sampling pipeline")
+    ch = pt["chosen"]
+    assert ch["pipelines"] in (1, 2) and ch["extract_streams"] in (1, 2) and len(pt["ms_per_step"]) == 3
+    assert all(v > 0 for v in pt["ms_per_step"].values())
+    assert d["config"]["streams"].startswith(f"{ch['pipelines']} sampling pipeline")
+    rf = d["roofline"]
+    assert rf["extract_streams"] == ch["extract_streams"] and 1.0 <= rf["launches_in_flight"] < 2.0
+    # achieved = algorithmic bytes per launch x launches in flight / a launch's own duration
+    assert abs(rf["frac"] - rf["frac_of_one_launch"] * rf["launches_in_flight"]) < 1e-9
     assert d["host_tier"]["feature_extract_GBps"] > 0 and d["host_tier"]["pinned_h2d_copy_GBps"] > 0
     cb = d["cpu_baseline"]
     assert cb["cores"] >= 1 and cb["value"] > 0 and set(cb["seconds"]) == {"sample", "remap", "extract", "total"}

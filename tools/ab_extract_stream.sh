@@ -5,7 +5,7 @@
 #   events  : GGMS_BENCH_GATHER_TIMING=events: wait(sampled), record, GATHER, record   (labels waited for on the sampling stream)
 #   timer   : the default: wait(sampled), GATHER -- timing and "rows are out" ride on the dispatch packet (ggms_launch_timer_t)
 #   lean    : GGMS_BENCH_STEP_EVENTS=0: no per-step timing on either stream (a bound: what is left is the wait packet)
-F="--no-engine --no-configs --no-staged-host --no-host-tier --no-cpu-baseline --no-sampler-roofline $*"
+F="--no-engine --no-configs --no-staged-host --no-host-tier --no-cpu-baseline --no-sampler-roofline --pipelines 1 --extract-streams 1 $*"
 pick='import sys,json; d=json.loads([l for l in sys.stdin if l.startswith("{")][-1]); print("%-7s" % sys.argv[1], "ms/step %.4f" % d["ms_per_step"], "edges/s %.4g" % d["value"], "gather us %.1f" % d["roofline"]["avg_launch_us"], "alone %.1f" % (d["roofline"]["avg_launch_us_alone"] or 0), "sample ms %.3f" % d["per_gpu"]["sample_ms_per_step"])'
 for rep in 1 2 3; do
   [ -f bench_prev.py ] && python bench_prev.py $F 2>/dev/null | python -c "$pick" prev

@@ -17,9 +17,12 @@ def main():
               f"value_over_box {d['value_over_box']:.4g}")
         pt = d.get("config", {}).get("pipelines_trial")
         if pt:
-            print(f"sampling pipelines: {pt['chosen']} (trial before the timed region: {pt['ms_per_step_with_1']:.4f} / "
-                  f"{pt['ms_per_step_with_2']:.4f} ms/step with one / two)")
+            print(f"streams: {pt['chosen']['pipelines']} sampling pipeline(s), {pt['chosen']['extract_streams']} extract stream(s) "
+                  "(trial before the timed region, ms/step: " + ", ".join(f"{k}: {v:.4f}" for k, v in pt["ms_per_step"].items()) + ")")
         r = d["roofline"]
+        if r.get("launches_in_flight", 1.0) > 1.0:
+            print(f"gather launches overlap on {r['extract_streams']} extract streams: {r['launches_in_flight']:.2f} in flight on average, a "
+                  f"launch's own duration {r['avg_launch_us']:.0f} us (one launch alone gets {r['frac_of_one_launch']:.3f} of 8 TB/s)")
         print(f"gather: {r['frac']:.3f} of 8 TB/s in the pipeline, {r['frac_alone']:.3f} alone; hbm_read_frac {r['hbm_read_frac']:.3f} "
               f"(target {r['hbm_read_frac_target']}, ceiling for a copy on this box {r['hbm_read_frac_ceiling_for_a_copy']:.3f})")
     if what in ("configs", "all") and d.get("configs"):
@@ -30,8 +33,10 @@ def main():
             print(f"configs.{k}: {c['ms_per_step']:.4f} ms/step, {c['edges_per_s']:.4g} edges/s, feature {c['feature_extract_GBps']:.0f} GB/s, "
                   f"gather {c['gather_frac']:.3f} in the pipeline / {c['gather_frac_alone']:.3f} alone, {c['edges_per_step']:.0f} edges and "
                   f"{c['rows_per_step']:.0f} rows per step"
-                  + (f"; sampling pipelines {c['pipelines_trial']['chosen']} (trial: {c['pipelines_trial']['ms_per_step_with_1']:.4f} / "
-                     f"{c['pipelines_trial']['ms_per_step_with_2']:.4f} ms with one / two)" if c.get("pipelines_trial") else ""))
+                  + (f"; {c['pipelines_trial']['chosen']['pipelines']} sampling pipeline(s), "
+                     f"{c['pipelines_trial']['chosen']['extract_streams']} extract stream(s) (trial: "
+                     + ", ".join(f"{v:.4f}" for v in c["pipelines_trial"]["ms_per_step"].values()) + " ms/step)"
+                     if c.get("pipelines_trial") else ""))
     st = (d.get("host_tier") or {}).get("staged") or d.get("host_tier_staged")
     if what in ("staged", "all") and st:
         h = d.get("host_tier") or {}

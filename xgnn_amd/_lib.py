@@ -122,6 +122,7 @@ SYMBOLS = {
     "ggms_launch_timer_arm": (_i, [_vp]),
     "ggms_launch_timer_wait": (_i, [_vp, _vp]),
     "ggms_launch_timer_elapsed_us": (_i, [_vp, C.POINTER(C.c_double)]),
+    "ggms_launch_timer_span_us": (_i, [_vp, _vp, C.POINTER(C.c_double)]),
 }
 
 ABI_VERSION = 3  # include/ggms.h as this binding declares it (struct layouts, host / device pointer conventions)

@@ -144,6 +144,8 @@ void Engine::Configure(const std::unordered_map<std::string, std::string> &kv_in
   if (kv.count("lookahead")) cfg.lookahead = std::stoull(kv["lookahead"]);
   if (kv.count("staged_serial_epochs")) cfg.staged_serial_epochs = std::stoull(kv["staged_serial_epochs"]);
   if (kv.count("staged_serial_steps")) cfg.staged_serial_steps = std::stoull(kv["staged_serial_steps"]);
+  if (kv.count("extract_streams")) cfg.extract_streams = std::max<size_t>(1, std::min<size_t>(2, std::stoull(kv["extract_streams"])));
+  if (const char *e = getenv("SAMGRAPH_EXTRACT_STREAMS")) cfg.extract_streams = (e[0] == '1') ? 1 : 2; // A/B hook
   if (kv.count("pipelines")) cfg.pipelines = std::max<size_t>(1, std::min<size_t>(4, std::stoull(kv["pipelines"])));
   if (cfg.lookahead + 1 < cfg.pipelines) cfg.pipelines = cfg.lookahead + 1; // nothing to overlap without batches ahead
   SAM_CHECK(cfg.sample_type >= GGMS_KHOP0 && cfg.sample_type <= GGMS_KHOP3, "unknown sample type");
@@ -651,6 +653,7 @@ void Engine::SampleInit(int worker_id, const std::string &ctx) {
   SAM_HIP(hipSetDevice(device_));
   SAM_HIP(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
   SAM_HIP(hipStreamCreateWithFlags(&stream_extract_, hipStreamNonBlocking));
+  if (cfg.extract_streams > 1) SAM_HIP(hipStreamCreateWithFlags(&stream_extract2_, hipStreamNonBlocking));
   UploadGraph();
   ShufflerInit();
   const uint32_t L = (uint32_t)cfg.fanout.size();
@@ -962,6 +965,7 @@ void Engine::Shutdown() {
     if (P.stream) (void)hipStreamSynchronize(P.stream);
   if (stream_) (void)hipStreamSynchronize(stream_);
   if (stream_extract_) (void)hipStreamSynchronize(stream_extract_);
+  if (stream_extract2_) (void)hipStreamSynchronize(stream_extract2_);
 }
 
 // ------------------------------------------------------------------ hot loop
@@ -1059,7 +1063,7 @@ bool Engine::EnqueueOne(bool background) {
   }
   // The gather is HBM-bound, the sampler latency-bound: they run on separate streams so that batch k's
   // extract overlaps batch k+1's sampling (the reference serialises them, dist_loops_arch6.cc:248-251)
-  hipStream_t xs = stream_extract_;
+  hipStream_t xs = (b->lean && stream_extract2_ && (enq_count_ & 1)) ? stream_extract2_ : stream_extract_;
   SAM_HIP(hipStreamWaitEvent(xs, b->ev_sampled, 0));
   if (b->lean) SAM_GGMS(ggms_launch_timer_arm(b->gather_timer));
   else SAM_HIP(hipEventRecord(b->ev_xstart, xs)); // the extract's own start: behind the previous batch's extract on xs
@@ -1299,11 +1303,25 @@ void Engine::StagedExtract(Batch *b, hipStream_t ss, hipStream_t xs) {
 }
 
 // block until the batch is complete, publish sizes, log the items the scripts read
-void Engine::Finish(Batch *b) {
+// prev: the batch handed out before this one (still owned by the caller: its timer has not been re-armed)
+void Engine::Finish(Batch *b, Batch *prev) {
   if (cfg.arch == kArch0) return; // complete (and logged) when it was enqueued
   SAM_HIP(hipEventSynchronize(b->ev_done));
   double us_gather = 0; // a lean batch's rows: complete when its gather is (the timer's end event)
-  if (b->lean) SAM_GGMS(ggms_launch_timer_elapsed_us(b->gather_timer, &us_gather));
+  double us_busy = 0;   // ... and what it added to the extract streams' busy time
+  if (b->lean) {
+    SAM_GGMS(ggms_launch_timer_elapsed_us(b->gather_timer, &us_gather));
+    us_busy = us_gather;
+    // Two extract streams: this gather may have started while the previous batch's was still running.  The epoch's
+    // copy time (kLogEpochCopyTime: bytes / time = the extract rate the scripts print) counts every moment once:
+    // this batch adds  min(own duration, its end - the previous gather's end).
+    if (stream_extract2_ && prev && prev->lean) {
+      double us_span = 0, us_prev = 0; // previous start -> this end; previous duration
+      if (ggms_launch_timer_span_us(prev->gather_timer, b->gather_timer, &us_span) == GGMS_OK &&
+          ggms_launch_timer_elapsed_us(prev->gather_timer, &us_prev) == GGMS_OK)
+        us_busy = std::min(us_gather, std::max(0.0, us_span - us_prev));
+    }
+  }
   const uint32_t L = (uint32_t)cfg.fanout.size();
   b->num_input = b->counts[3 * L];
   b->num_miss = b->counts[3 * L + 2];
@@ -1320,6 +1338,7 @@ void Engine::Finish(Batch *b) {
   (void)hipEventElapsedTime(&ms_sample, b->ev_start, b->ev_sampled);
   if (b->lean) ms_copy = (float)(us_gather * 1e-3); // the gather kernel's own time
   else (void)hipEventElapsedTime(&ms_copy, b->ev_xstart, b->ev_done); // not from ev_sampled: that would add the queueing behind the previous extract
+  const double s_copy_epoch = b->lean ? us_busy * 1e-6 : ms_copy * 1e-3;
   uint64_t edges = 0;
   for (uint32_t i = 0; i < L; ++i) edges += b->counts[3 * i];
   const double row_bytes = (double)ds.feat_dim * ggms_dtype_bytes(ds.feat_dtype);
@@ -1332,18 +1351,17 @@ void Engine::Finish(Batch *b) {
   prof.LogStep(b->key, 9, b->num_input * row_bytes);
   prof.LogStep(b->key, 13, b->num_miss * row_bytes);
   prof.LogEpochAdd(b->key, 0 /*kLogEpochSampleTime*/, ms_sample * 1e-3);
-  prof.LogEpochAdd(b->key, 8 /*kLogEpochCopyTime*/, ms_copy * 1e-3);
+  prof.LogEpochAdd(b->key, 8 /*kLogEpochCopyTime*/, s_copy_epoch);
   prof.LogEpochAdd(b->key, 12 /*kLogEpochFeatureBytes*/, b->num_input * row_bytes);
   prof.LogEpochAdd(b->key, 13 /*kLogEpochMissBytes*/, b->num_miss * row_bytes);
   prof.LogEpochAdd(b->key, 15 /*kLogEpochNumSample*/, (double)edges);
 }
 
 uint64_t Engine::GetNextBatch() { // operation.cc:366-378 + GraphPool::GetGraphBatch graph_pool.cc:31-49
-  if (current_) {
-    std::lock_guard<std::mutex> lk(pool_mu_);
-    current_->in_use = false; // the engine drops its own reference to the previous batch (:370)
-    current_ = nullptr;
-  }
+  // the engine drops its own reference to the previous batch (:370) -- once the next one's gather has been measured
+  // against it (Finish): until then its slot, and with it its launch timer, is not handed to the sampler again
+  Batch *prev = current_;
+  current_ = nullptr;
   Batch *b = nullptr;
   {
     std::unique_lock<std::mutex> lk(pool_mu_);
@@ -1354,7 +1372,11 @@ uint64_t Engine::GetNextBatch() { // operation.cc:366-378 + GraphPool::GetGraphB
     b = pool_.front();
     pool_.pop_front();
   }
-  Finish(b);
+  Finish(b, prev);
+  if (prev) {
+    std::lock_guard<std::mutex> lk(pool_mu_);
+    prev->in_use = false;
+  }
   current_ = b;
   return b->key;
 }

@@ -73,6 +73,7 @@ struct RunConfig {
   uint64_t seed = 0;
   bool direct_table = true;
   size_t lookahead = 2; // batches sample_once() keeps enqueued beyond the one it was asked for (config key `lookahead`)
+  size_t extract_streams = 2; // lean batches' gathers alternate between this many streams (1 or 2; config key `extract_streams`)
   size_t pipelines = 1; // batches the sampler itself has in flight: own stream + dedup table + workspace each (`pipelines`);
                         // measured on papers100M-shaped GCN: a second pipeline loses 2-3 % (the step is bound by the memory
                         // fabric, not by sampler latency) and costs a second 8 B x num_node table
@@ -227,12 +228,15 @@ class Engine {
   void CpuInit();
   bool CpuEnqueueOne(bool background);
   void CpuShutdown();
-  void Finish(Batch *b);
+  void Finish(Batch *b, Batch *prev);
 
   bool data_ready_ = false, sample_ready_ = false, train_ready_ = false, shutdown_ = false;
   int worker_id_ = 0, device_ = 0;
   hipStream_t stream_ = nullptr;         // shuffle + sampling (latency-bound)
   hipStream_t stream_extract_ = nullptr; // feature gather (HBM-bound): overlaps the next batch's sampling
+  // a second one: consecutive lean batches' gathers alternate and may overlap -- no wait packet between two gathers, and
+  // one gather's head fills the other's tail (default workload -5 %, profiles/r05_ab_extract_streams.txt)
+  hipStream_t stream_extract2_ = nullptr;
   // device graph
   uint32_t *d_indptr_ = nullptr, *d_indices_ = nullptr;
   std::vector<void *> part_indptr_, part_indices_; // P+1 entries (slot P = host CSR)

@@ -568,4 +568,18 @@ int ggms_launch_timer_elapsed_us(ggms_launch_timer_t *timer, double *us) {
   return GGMS_OK;
 }
 
+int ggms_launch_timer_span_us(ggms_launch_timer_t *first, ggms_launch_timer_t *last, double *us) {
+  GGMS_CHECK_ARG(first && last && us);
+  if (!first->launched || !last->launched) {
+    set_error("ggms_launch_timer_span_us: a timer that never rode a launch");
+    return GGMS_ERR_INVALID;
+  }
+  GGMS_HIP(hipEventSynchronize(first->stop));
+  GGMS_HIP(hipEventSynchronize(last->stop));
+  float ms = 0.f;
+  GGMS_HIP(hipEventElapsedTime(&ms, first->start, last->stop));
+  *us = (double)ms * 1e3;
+  return GGMS_OK;
+}
+
 } // extern "C"

@@ -404,6 +404,12 @@ class LaunchTimer:
         check(lib().ggms_launch_timer_elapsed_us(self._h, C.byref(us)), "ggms_launch_timer_elapsed_us")
         return us.value
 
+    def span_us(self, last):
+        """From the start of this timer's launch to the end of `last`'s (both waited for)."""
+        us = C.c_double(0)
+        check(lib().ggms_launch_timer_span_us(self._h, last._h, C.byref(us)), "ggms_launch_timer_span_us")
+        return us.value
+
     def close(self):
         if self._h:
             lib().ggms_launch_timer_destroy(self._h)
