@@ -826,7 +826,7 @@ def main():
                 span_ms = step_tm[0].span_us(step_tm[-1]) / 1e3  # first launch's start -> last launch's end
             else:                      # HIP event pair around the launch on that stream
                 t_extract_ms = sum(e[2].elapsed_time(e[3]) for e in ev)
-                span_ms = t_extract_ms
+                span_ms = ev[0][2].elapsed_time(ev[-1][3]) if step_events else t_extract_ms
             if not step_events:
                 t_sample_ms = t_extract_ms = span_ms = elapsed * 1e3
             # gathers on two streams overlap: a launch's own duration then counts time it shares with its neighbour;
@@ -891,7 +891,7 @@ def main():
         sampler.use_pipelines(K)
         slot_free[:] = [None] * len(slot_free)
         pipes_trial = {"ms_per_step": {f"{k} pipeline(s), {x} extract stream(s)": v for (k, x), v in per.items()},
-                       "chosen": {"pipelines": K, "extract_streams": n_xs},
+                       "chosen": {"pipelines": K, "extract_streams": n_xs}, "steps_each": trial_steps, "warmup_each": 3,
                        "rule": f"{trial_steps} steps each before the timed region; the first entry unless another is at least 3 % faster"}
         log(f"pipelines trial: {per} -> {K} x {n_xs}")
     blocks, next_step = measure(extract_main, args.steps, args.warmup, repeats, first_step=first_main)

@@ -119,11 +119,25 @@ def main():
          if is_main(r["Kernel_Name"])]
     g.sort()
     durs = [d for _, d in g]
+    # (before the main region: the trial of sampling pipelines x extract streams, config.pipelines_trial)
+    pt = bench["config"].get("pipelines_trial") or {}
+    skip = len(pt.get("ms_per_step", {})) * (pt.get("steps_each", 0) + pt.get("warmup_each", 0))
+    g, durs = g[skip:], durs[skip:]
     in_pipe = bench["warmup"] + bench["steps"] * bench["repeats"]["blocks"]
     if len(durs) >= in_pipe + 10:
         timed = durs[bench["warmup"]:in_pipe]
         out["rocprof_avg_us_timed_steps"] = sum(timed) / len(timed)
         out["rocprof_avg_us_alone"] = sum(durs[in_pipe:in_pipe + 10]) / 10
+        # launches in flight per timed block: sum of durations / (first start -> last end); two extract streams overlap them
+        fl = []
+        for blk in range(bench["repeats"]["blocks"]):
+            lo = bench["warmup"] + blk * bench["steps"]
+            seg = g[lo:lo + bench["steps"]]
+            span = (seg[-1][0] - seg[0][0]) / 1e3 + seg[-1][1]
+            fl.append(sum(d for _, d in seg) / span)
+        out["rocprof_launches_in_flight"] = sum(fl) / len(fl)
+        out["bench_launches_in_flight_same_run"] = bench["roofline"].get("launches_in_flight")
+        out["extract_streams"] = bench["roofline"].get("extract_streams")
         out["bench_avg_launch_us_same_run"] = bench["roofline"]["avg_launch_us"]
         out["bench_avg_launch_us_alone_same_run"] = bench["roofline"]["avg_launch_us_alone"]
     # what the counters describe: bench.py nulls roofline.traffic when the kernel source has changed since
