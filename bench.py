@@ -655,10 +655,12 @@ def main():
         extra_kw = dict(random_walk_length=3, random_walk_restart_prob=0.5, num_random_walk=4)
     # batches in flight: K sampling pipelines (own stream, dedup table, workspace; RNG pool consumed in batch
     # order) + the extract stream; outputs live in batch slots, as in the engine
-    # Default (no --pipelines / --slots): khop0 runs two; every other sampler is TRIED with one and with two before the
-    # timed region (10 steps each, outside it) and runs with two only where that is at least 5 % faster -- two chains
-    # fill each other's latency gaps on small frontiers (papers100M [25,10]: 0.19 -> 0.165 ms/step) and only add
-    # memory-side contention on large ones (default workload + 3 %, products + 7 %: profiles/r05_ab_pipelines.txt).
+    # Default (no --pipelines / --extract-streams / --slots): (sampling pipelines, extract streams) = (1, 1), (1, 2), (2, 1)
+    # -- khop0, whose batches need no shared generator pool: (2, 1), (2, 2) -- are TRIED before the timed region (two blocks
+    # of 12 steps each, outside it); the first one stays unless another is at least 2 % faster.  Two sampling chains fill
+    # each other's latency gaps on small frontiers (papers100M [25,10]: 0.19 -> 0.165 ms/step) and only add memory-side
+    # contention on large ones (profiles/r05_ab_pipelines.txt); two extract streams let consecutive batches' gathers
+    # overlap where the gather bounds the step (default workload - 3..5 %, profiles/r05_ab_extract_streams.txt).
     auto_pipes = (args.pipelines is None and args.extract_streams is None and not args.slots and not args.no_overlap)
     khop0 = args.sample_type == "khop0"
     if args.pipelines is None:
@@ -882,17 +884,18 @@ def main():
             K, n_xs, NSLOT = k, x, k + x
             sampler.use_pipelines(k)
             slot_free[:] = [None] * len(slot_free)
-            tb, first_main = measure(extract_main, trial_steps, 3, 1, first_step=first_main)
-            per[(k, x)] = tb[0]["elapsed"] / trial_steps * 1e3
+            tb, first_main = measure(extract_main, trial_steps, 3, 2, first_step=first_main)
+            per[(k, x)] = min(b["elapsed"] for b in tb) / trial_steps * 1e3  # the better of two blocks
         base = cands[0]
         best = min(per, key=per.get)
-        K, n_xs = best if per[best] < 0.97 * per[base] else base
+        K, n_xs = best if per[best] < 0.98 * per[base] else base
         NSLOT = K + n_xs
         sampler.use_pipelines(K)
         slot_free[:] = [None] * len(slot_free)
         pipes_trial = {"ms_per_step": {f"{k} pipeline(s), {x} extract stream(s)": v for (k, x), v in per.items()},
-                       "chosen": {"pipelines": K, "extract_streams": n_xs}, "steps_each": trial_steps, "warmup_each": 3,
-                       "rule": f"{trial_steps} steps each before the timed region; the first entry unless another is at least 3 % faster"}
+                       "chosen": {"pipelines": K, "extract_streams": n_xs}, "steps_each": trial_steps, "blocks_each": 2, "warmup_each": 3,
+                       "rule": f"two blocks of {trial_steps} steps each before the timed region, the better block counts; the first "
+                               "entry unless another is at least 2 % faster"}
         log(f"pipelines trial: {per} -> {K} x {n_xs}")
     blocks, next_step = measure(extract_main, args.steps, args.warmup, repeats, first_step=first_main)
     log("main region done")

@@ -499,6 +499,7 @@ int ggms_extract_tiered(void *out, const ggms_id_t *nodes, size_t num_nodes,
  *   wait(t, s):  stream s waits for the timed launch (no-op if the timer never rode a launch)
  *   elapsed_us:  blocks until the launch has finished; GGMS_ERR_INVALID if the timer never rode a launch
  *   span_us:     see below
+ * A timer belongs to the thread that arms it until its launch has been issued: destroy it from that thread, or after.
  * ------------------------------------------------------------------------- */
 typedef struct ggms_launch_timer ggms_launch_timer_t;
 int ggms_launch_timer_create(ggms_launch_timer_t **timer);

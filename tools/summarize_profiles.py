@@ -121,7 +121,7 @@ def main():
     durs = [d for _, d in g]
     # (before the main region: the trial of sampling pipelines x extract streams, config.pipelines_trial)
     pt = bench["config"].get("pipelines_trial") or {}
-    skip = len(pt.get("ms_per_step", {})) * (pt.get("steps_each", 0) + pt.get("warmup_each", 0))
+    skip = len(pt.get("ms_per_step", {})) * (pt.get("steps_each", 0) * pt.get("blocks_each", 1) + pt.get("warmup_each", 0))
     g, durs = g[skip:], durs[skip:]
     in_pipe = bench["warmup"] + bench["steps"] * bench["repeats"]["blocks"]
     if len(durs) >= in_pipe + 10:
