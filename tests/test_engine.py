@@ -315,6 +315,22 @@ def test_arch1_end_to_end(tmp_path, pipelined, sample_type, table):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("streams,pipelined", [(1, 0), (2, 0), (2, 1)])
+def test_arch1_one_and_two_extract_streams_give_the_oracles_batches(tmp_path, streams, pipelined):
+    """Config key `extract_streams` (an extension; default 2): consecutive lean batches' gathers alternate between two
+    extract streams and may overlap; with three batches enqueued ahead (lookahead 2) two gathers and a sampler are in
+    flight at once.  Every batch still equals the oracle's, whoever finishes first."""
+    d = make_dataset(tmp_path / "ds")
+    prefix = str(tmp_path / "out")
+    r = subprocess.run([sys.executable, DRIVER, d["path"], prefix, "arch1", "1", f"pipelined={pipelined}", "sample_type=khop3",
+                        "seed=7", "batch_size=64", "fanout=5 4", "lookahead=2", f"extract_streams={streams}", "num_epoch=3"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    want = _oracle_batches(d, 0, 1, 64, 3, [5, 4], 7, arch6=False)
+    _check(np.load(prefix + ".w0.npz"), want, 2)
+
+
+@pytest.mark.gpu
 def test_arch1_weighted_and_random_walk(tmp_path):
     """PinSAGE (random walk, train_pinsage.py defaults) and weighted sampling through the engine."""
     d = make_dataset(tmp_path / "ds")
