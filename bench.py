@@ -907,14 +907,20 @@ def main():
         n_all = args.warmup + args.steps * repeats
         print("host enqueue ms/step:", {n: round(1e3 * t / n_all, 4) for n, t in zip(names, host_t)}, file=sys.stderr)
 
-    # self-check outside the timed region: the last batch's rows against the generator's closed form
-    last_slot = (args.warmup + args.steps * repeats - 1) % NSLOT
+    # self-check outside the timed region: the rows of the last batch in EVERY slot (with two extract streams the last two
+    # gathers ran side by side) against the generator's closed form
+    total_steps = args.warmup + args.steps * repeats
+    last_slot = (total_steps - 1) % NSLOT
+    rows_ok = True
+    for back in range(min(NSLOT, total_steps)):
+        slot_c = (total_steps - 1 - back) % NSLOT
+        n_c = int(sampler.counts_slots[slot_c][3 * L].item())
+        ids = sampler.input_nodes[slot_c][:n_c].to(torch.int64)
+        stride = max(1, n_c // 4096)
+        want = torch.empty((ids[::stride].numel(), dim), dtype=torch.float32, device=dev)
+        feat_rows(ids[::stride], want)
+        rows_ok = rows_ok and n_c > 0 and bool(torch.equal(out[slot_c][:n_c][::stride], want))
     n_last = int(sampler.counts_slots[last_slot][3 * L].item())
-    ids = sampler.input_nodes[last_slot][:n_last].to(torch.int64)
-    stride = max(1, n_last // 4096)
-    want = torch.empty((ids[::stride].numel(), dim), dtype=torch.float32, device=dev)
-    feat_rows(ids[::stride], want)
-    rows_ok = bool(torch.equal(out[last_slot][:n_last][::stride], want))
     if not rows_ok:
         raise SystemExit("bench self-check failed: gathered rows differ from the feature generator")
 
