@@ -668,7 +668,9 @@ def main():
     K = 1 if args.no_overlap else max(1, args.pipelines)
     # extract streams in use (allocated: two unless --no-overlap / --extract-streams 1)
     n_xs = 1 if args.no_overlap else (args.extract_streams or (2 if auto_pipes else 1))
-    NSLOT = args.slots if args.slots else K + n_xs - (1 if auto_pipes and not khop0 else 0)  # (the trial never runs 2 x 2)
+    # batch slots: one per batch that can be in flight + one spare (the sampler may run one batch further ahead: - 1 % on the
+    # default workload, profiles/r05_ab_slots_two_streams.txt); allocated for the largest candidate of the trial
+    NSLOT = args.slots if args.slots else K + n_xs + 1 - (1 if auto_pipes and not khop0 else 0)  # (the trial never runs 2 x 2)
     sampler = ops.BatchSampler(g, fanouts, args.batch, sample_type=code, seed=0x5EED + rank, device=dev,
                                num_slots=NSLOT, num_pipelines=K, **extra_kw)
     out = [torch.empty((sampler.max_unique, dim), dtype=torch.float32, device=dev) for _ in range(NSLOT)]
@@ -881,7 +883,7 @@ def main():
         if not getattr(extract_main, "single_launch", True):
             cands = [c for c in cands if c[1] == 1]
         for k, x in cands:
-            K, n_xs, NSLOT = k, x, k + x
+            K, n_xs, NSLOT = k, x, k + x + 1
             sampler.use_pipelines(k)
             slot_free[:] = [None] * len(slot_free)
             tb, first_main = measure(extract_main, trial_steps, 3, 2, first_step=first_main)
@@ -889,7 +891,7 @@ def main():
         base = cands[0]
         best = min(per, key=per.get)
         K, n_xs = best if per[best] < 0.98 * per[base] else base
-        NSLOT = K + n_xs
+        NSLOT = K + n_xs + 1
         sampler.use_pipelines(K)
         slot_free[:] = [None] * len(slot_free)
         pipes_trial = {"ms_per_step": {f"{k} pipeline(s), {x} extract stream(s)": v for (k, x), v in per.items()},
