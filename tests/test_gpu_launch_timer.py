@@ -84,3 +84,33 @@ def test_a_timer_rides_one_launch_and_orders_another_stream_behind_it(ops):
     again = tm.elapsed_us()
     assert 0.0 < again < first
     tm.close()
+
+
+def test_span_of_two_timed_launches_on_two_streams(ops):
+    """ggms_launch_timer_span_us: first launch's start -> last launch's end.  Two gathers issued on two streams may
+    overlap: the span is of the order of one launch at least and never longer than the two back to back plus slack."""
+    dev = torch.device("cuda", 0)
+    n, dim, rows = 1 << 20, 128, 1 << 19
+    feat, t_feat = _table(n, dim, dev)
+    idx = np.random.RandomState(8).randint(0, n, rows).astype(np.uint32)
+    t_idx = torch.from_numpy(idx.view(np.int32)).to(dev)
+    outs = [torch.empty((rows, dim), dtype=torch.float32, device=dev) for _ in range(2)]
+    tms = [ops.LaunchTimer(), ops.LaunchTimer()]
+    streams = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
+    from xgnn_amd._lib import GgmsError
+    with pytest.raises(GgmsError):
+        tms[0].span_us(tms[1])  # neither rode a launch yet
+    for _ in range(2):  # second pass: warm
+        torch.cuda.synchronize()
+        for t, s, o in zip(tms, streams, outs):
+            with torch.cuda.stream(s):
+                t.arm()
+                ops.extract(t_feat, t_idx, out=o)
+        a, b = tms[0].elapsed_us(), tms[1].elapsed_us()
+        span = tms[0].span_us(tms[1])
+    torch.cuda.synchronize()
+    assert span >= 0.5 * min(a, b) and span <= a + b + 200.0, (a, b, span)
+    want = oracle.extract(feat, idx).tobytes()
+    assert outs[0].cpu().numpy().tobytes() == want and outs[1].cpu().numpy().tobytes() == want
+    for t in tms:
+        t.close()
