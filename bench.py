@@ -1346,21 +1346,22 @@ def main():
 
     # ---- N = 1: the other single-GPU configurations BASELINE.json names, one block of this script each (child process) ---
     if default_workload and not args.no_configs:
-        me = [sys.executable, os.path.abspath(__file__), "--no-engine", "--no-host-tier", "--no-cpu-baseline",
+        me = [sys.executable, os.path.abspath(__file__), "--no-host-tier", "--no-cpu-baseline",
               "--no-sampler-roofline", "--no-configs", "--steps", str(args.steps), "--warmup", str(args.warmup),
               "--repeats", str(repeats)]
         res["configs"] = {}
         for name, flags, need, what in (
-                ("products_graphsage_25_10", ["--preset", "products"], 12.0,
+                ("products_graphsage_25_10", ["--preset", "products"], 25.0,  # (with its `engine` record: seconds at this size)
                  "BASELINE configs[1]: ogbn-products-shaped CSR, GraphSAGE fanout [25,10], graph + features in HBM"),
-                ("friendster_pinsage_rw", ["--preset", "friendster", "--sample-type", "random_walk", "--fanout", "5,5,5"], 30.0,
+                ("friendster_pinsage_rw", ["--preset", "friendster", "--sample-type", "random_walk", "--fanout", "5,5,5", "--no-engine"], 30.0,
                  "BASELINE configs[4]'s workload on one GPU: Friendster-scale power-law CSR, 256-dim f32 rows, PinSAGE "
                  "random walk (length 3, restart 0.5, 4 walks, top-5, 3 layers)"),
-                ("papers100M_graphsage_25_10", ["--fanout", "25,10"], 30.0,
+                ("papers100M_graphsage_25_10", ["--fanout", "25,10", "--no-engine"], 30.0,
                  "BASELINE configs[3]'s workload on one GPU: papers100M-shaped CSR, GraphSAGE fanout [25,10]")):
             if test_configs:
                 flags = (["--preset", test_configs, "--batch", str(args.batch)]
-                         + (["--sample-type", "random_walk", "--fanout", "5,5,5"] if "pinsage" in name else []))
+                         + (["--sample-type", "random_walk", "--fanout", "5,5,5"] if "pinsage" in name else [])
+                         + ([] if name.startswith("products") else ["--no-engine"]))
             if not fits(f"configs.{name}", need):
                 res["configs"][name] = res.pop(f"configs.{name}")
                 continue
@@ -1372,7 +1373,9 @@ def main():
                      "gather_frac_alone": rf["frac_alone"], "rows_verified": r["rows_verified"],
                      "edges_per_step": r["per_gpu"]["edges_per_step"], "rows_per_step": r["per_gpu"]["rows_per_step"],
                      "spread": r["repeats"]["spread"], "streams": r["config"]["streams"],
-                     "pipelines_trial": r["config"].get("pipelines_trial")}
+                     "pipelines_trial": r["config"].get("pipelines_trial"),
+                     # the same workload through the samgraph.torch surface (the child's own `engine` record)
+                     **({"engine": {k: v for k, v in r["engine"].items() if k != "surface"}} if isinstance(r.get("engine"), dict) else {})}
             res["configs"][name] = r
         log("configs sub-record done")
 

@@ -82,6 +82,10 @@ def test_single_gpu_line_carries_its_box_the_other_configs_and_the_staged_host_t
         assert c["ms_per_step"] > 0 and c["edges_per_s"] > 0 and c["feature_extract_GBps"] > 0 and c["rows_verified"]
         assert 0 < c["gather_frac"] < 1
     assert "random_walk" in cf["friendster_pinsage_rw"]["workload"]
+    # configs[1] also through the samgraph.torch surface (the child's own engine record)
+    en = cf["products_graphsage_25_10"]["engine"]
+    assert "error" not in en, en
+    assert en["ms_per_step"] > 0 and en["edges_per_s"] > 0
     st = d["host_tier"]["staged"]
     assert st["reference_published"]["h2d_GBps"] == 23.33
     for name in ("cache_0", "cache_0.64"):

@@ -36,7 +36,9 @@ def main():
                   + (f"; {c['pipelines_trial']['chosen']['pipelines']} sampling pipeline(s), "
                      f"{c['pipelines_trial']['chosen']['extract_streams']} extract stream(s) (trial: "
                      + ", ".join(f"{v:.4f}" for v in c["pipelines_trial"]["ms_per_step"].values()) + " ms/step)"
-                     if c.get("pipelines_trial") else ""))
+                     if c.get("pipelines_trial") else "")
+                  + (f"; through samgraph.torch (engine): {c['engine']['ms_per_step']:.4f} ms/step, {c['engine']['edges_per_s']:.4g} edges/s"
+                     if isinstance(c.get("engine"), dict) and "ms_per_step" in c["engine"] else ""))
     st = (d.get("host_tier") or {}).get("staged") or d.get("host_tier_staged")
     if what in ("staged", "all") and st:
         h = d.get("host_tier") or {}
