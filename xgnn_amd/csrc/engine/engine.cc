@@ -255,7 +255,8 @@ void Engine::LoadDataset() {
     // An anonymous mapping nobody has written is ONE zero page behind every address: a host gather of such a table reads
     // 4 KB over and over and measures the cache.  SAMGRAPH_FILL_FAKE_FEAT=1 gives every page a frame of its own (and the
     // rows a checkable content: 32-bit word w of the table holds w), filled by omp_thread_num threads.
-    if (getenv("SAMGRAPH_FILL_FAKE_FEAT")) {
+    ds.feat_is_zero = !getenv("SAMGRAPH_FILL_FAKE_FEAT");
+    if (!ds.feat_is_zero) {
       Team team((int)cfg.omp_thread_num);
       uint32_t *words = (uint32_t *)ds.feat.ptr;
       team.ParallelFor(ds.feat.bytes / 4, [&](size_t lo, size_t hi, int) {
@@ -843,6 +844,13 @@ void Engine::BuildCache() {
     void *d = nullptr;
     // shards are published to the other workers with hipIpc: sized so that a peer can open them (include/ggms.h)
     SAM_HIP(hipMalloc(&d, ggms_ipc_safe_bytes(std::max<size_t>(count * row_bytes, 16))));
+    if (ds.feat_is_zero) {
+      // rows of a table that is known to be all zero need no gather: touching them in rank order would fault in every
+      // page of the untouched anonymous mapping once per worker (two minutes of page faults at papers100M size)
+      SAM_HIP(hipMemsetAsync(d, 0, count * row_bytes, stream_));
+      SAM_HIP(hipStreamSynchronize(stream_));
+      return d;
+    }
     size_t k = 0;
     for (size_t lo = 0; lo < count; lo += step, ++k) {
       const size_t m = std::min(step, count - lo);
@@ -1052,7 +1060,10 @@ bool Engine::EnqueueOne(bool background) {
   // counters, no visit counts), so the batch's counts go to the host behind the label gather on the SAMPLING stream,
   // which has the slack, and the extract stream carries one wait and the gather -- whose start / end timestamps and
   // "rows are out" event ride on its own dispatch packet (b->gather_timer).  Otherwise the sequence the counters need.
-  const bool gather_counts = cfg.UseGPUCache() && (mock || num_replica_ || cache_table_);
+  // (no row can miss when every node is cached: the miss count stays the zero the sampling stream wrote, and the
+  // per-tier row counts, which nothing on the host reads, are not taken)
+  const bool can_miss = num_cached_nodes_ < ds.num_node;
+  const bool gather_counts = cfg.UseGPUCache() && (mock || ((num_replica_ || cache_table_) && can_miss));
   static const bool lean_off = [] { const char *e = getenv("SAMGRAPH_LEAN_EXTRACT"); return e && e[0] == '0'; }(); // A/B hook
   b->lean = !lean_off && !StagedHostTier() && !gather_counts && !node_access_dev_;
   if (b->lean) {
@@ -1070,7 +1081,7 @@ bool Engine::EnqueueOne(bool background) {
   if (StagedHostTier()) {
     StagedExtract(b, ss, xs);
   } else if (cfg.UseGPUCache() && (mock || num_replica_)) { // every tier in one gather; rows per tier counted
-    SAM_HIP(hipMemsetAsync(n_miss, 0, 4 * 8, xs)); // {host, remote shard, local shard, replica} = counts[3L+2 .. 3L+5]
+    if (gather_counts) SAM_HIP(hipMemsetAsync(n_miss, 0, 4 * 8, xs)); // {host, remote shard, local shard, replica} = counts[3L+2 .. 3L+5]
     ggms_feature_tiers_t tiers{};
     tiers.table = cache_table_;
     tiers.replica = d_replica_;
@@ -1080,13 +1091,14 @@ bool Engine::EnqueueOne(bool background) {
     tiers.my_part = cfg.part_cache ? (uint32_t)worker_id_ : 0;
     tiers.host_feat = feat_src_;
     tiers.host_row_mask = mock ? ds.feat_mask : 0;
-    SAM_GGMS(ggms_extract_tiered(b->feat, b->input_nodes, max_unique_, n_in, &tiers, ds.feat_dim, ds.feat_dtype, n_miss, xs));
+    SAM_GGMS(ggms_extract_tiered(b->feat, b->input_nodes, max_unique_, n_in, &tiers, ds.feat_dim, ds.feat_dtype,
+                                 gather_counts ? n_miss : nullptr, xs));
   } else if (cfg.UseGPUCache()) {
     // DoArch6GetCacheMissIndex + DoArch6GPUCacheFeatureCopy (dist_loops.cc:1015-1285) in one pass; everything cached in
     // node order (no table): no row can miss, the count stays the zero the sampling stream wrote
     SAM_GGMS(ggms_extract_cached(b->feat, b->input_nodes, max_unique_, n_in, cache_table_,
                                  (const void *const *)cache_parts_.data(), num_cache_part_, feat_src_, ds.feat_dim,
-                                 ds.feat_dtype, cache_table_ ? n_miss : nullptr, xs));
+                                 ds.feat_dtype, (cache_table_ && can_miss) ? n_miss : nullptr, xs));
   } else if (mock) { // GPUMockExtract, cuda_loops.cc:692-700 / dist_loops.cc:608-616
     SAM_GGMS(ggms_gather_scatter_masked(b->feat, feat_src_, b->input_nodes, nullptr, max_unique_, n_in, ds.feat_dim,
                                         ds.feat_dtype, ds.feat_mask, xs));

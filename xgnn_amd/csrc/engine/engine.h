@@ -96,6 +96,7 @@ struct Dataset {
   size_t num_train = 0, num_valid = 0, num_test = 0;
   HostArray indptr, indices, feat, label, train_set, valid_set, test_set, ranking_nodes, prob_table, alias_table;
   bool feat_is_fake = false;
+  bool feat_is_zero = false; // the stand-in table of a dataset without feat.bin that nobody has written: every row is zero
   // SAMGRAPH_EMPTY_FEAT = k (engine.cc:198-235): the feature table is a 2^k-row stand-in, row of node v = v & mask
   uint32_t feat_mask = 0xffffffffu;
   size_t feat_rows = 0; // rows of ds.feat (num_node, or 2^k)
