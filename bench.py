@@ -545,7 +545,19 @@ def main():
     # slot or kEmptyKey, the rest comes from pinned host memory.
     full = args.cache_ratio >= 1.0
     num_cached = N if full else int(N * args.cache_ratio)
-    t_rank = None if full and world == 1 else to_dev(datagen.degree_rank(graph["indptr"]))
+    # cache rank list (cache_by_degree.bin: node ids by descending in-degree, ties by id) -- datagen.degree_rank's order,
+    # computed on the GPU: the host's stable argsort of 111 M degrees is 15-20 s per rank, the device's a fraction of one
+    t_rank = None
+    if not (full and world == 1):
+        try:
+            ip_src = indptr
+        except NameError:  # --dist-graph --host-indptr at N = 1 gave the device copy back
+            ip_src = to_dev(graph["indptr"])
+        ip64 = ip_src.to(torch.int64) & 0xFFFFFFFF
+        del ip_src
+        t_rank = torch.argsort(ip64[1:] - ip64[:-1], descending=True, stable=True).to(torch.int32)
+        del ip64
+        torch.cuda.empty_cache()  # the sort's scratch (several GB at this size) goes back to the device
     host_feat = None
     if not full:  # host tier: the full table in pinned host memory, read zero-copy by the gather kernel
         host_feat = torch.empty((N, dim), dtype=torch.float32, pin_memory=True)
@@ -1307,6 +1319,12 @@ def main():
                 engine = engine_record(ds_dir, fanouts, args, log, timeout=child_timeout)
             else:  # rank 0 runs the child (which forks one engine worker per GPU), the other ranks wait
                 extract_main = keep_main = None  # the engine's workers build their own shards on these GPUs
+                # nothing after this sub-record runs another batch at N > 1: the batch slots, the sampler's tables and the
+                # CSR go back to the device too (one GPU holds a rank AND an engine worker; a one-GPU rehearsal two of each)
+                out.clear()
+                out_label.clear()
+                slot_free[:] = []
+                sampler = g = indptr = indices = labels = t_rank = None
                 import gc
                 gc.collect()
                 torch.cuda.empty_cache()
