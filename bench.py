@@ -682,7 +682,9 @@ def main():
     n_xs = 1 if args.no_overlap else (args.extract_streams or (2 if auto_pipes else 1))
     # batch slots: one per batch that can be in flight + one spare (the sampler may run one batch further ahead: - 1 % on the
     # default workload, profiles/r05_ab_slots_two_streams.txt); allocated for the largest candidate of the trial
-    NSLOT = args.slots if args.slots else K + n_xs + 1 - (1 if auto_pipes and not khop0 else 0)  # (the trial never runs 2 x 2)
+    def slots_for(k, x):  # ... rounded up to a multiple of k: a slot's next user then runs on the same sampling stream
+        return (k + x + 1 + k - 1) // k * k
+    NSLOT = args.slots if args.slots else (max(slots_for(1, 2), slots_for(2, 1)) if auto_pipes and not khop0 else slots_for(K, n_xs))
     sampler = ops.BatchSampler(g, fanouts, args.batch, sample_type=code, seed=0x5EED + rank, device=dev,
                                num_slots=NSLOT, num_pipelines=K, **extra_kw)
     out = [torch.empty((sampler.max_unique, dim), dtype=torch.float32, device=dev) for _ in range(NSLOT)]
@@ -733,11 +735,17 @@ def main():
             s_sample = s_samples[step % K]
             h0 = time.perf_counter()
             with torch.cuda.stream(s_sample):
-                for e in slot_free[slot] or ():  # the slot's previous rows are out (extract stream) and its labels too
-                    if isinstance(e, ops.LaunchTimer):
-                        e.wait(s_sample)
+                # the slot's previous rows are out (extract stream) and its labels too (the sampling stream they were gathered
+                # on: the slot count is a multiple of K, so that is THIS stream again and needs no wait -- a cross-stream wait
+                # per step on a sampling stream is dead time where the sampling streams bound the step: khop0)
+                prev_done, prev_labelled, prev_pipe = slot_free[slot] or (None, None, None)
+                if prev_done is not None:
+                    if isinstance(prev_done, ops.LaunchTimer):
+                        prev_done.wait(s_sample)
                     else:
-                        s_sample.wait_event(e)
+                        s_sample.wait_event(prev_done)
+                    if prev_pipe != step % K:
+                        s_sample.wait_event(prev_labelled)
                 if ev4 is not None:
                     ev4[0].record(s_sample)
                 h1 = time.perf_counter()
@@ -781,7 +789,7 @@ def main():
                     last_gather[0] = torch.cuda.Event()
                     last_gather[0].record(s_extract)
                 h4 = h5 = time.perf_counter()
-                slot_free[slot] = (done, labelled)
+                slot_free[slot] = (done, labelled, step % K)
             h6 = time.perf_counter()
             for i, (a, b) in enumerate([(h0, h1), (h1, h2), (h2, h3), (h3, h4), (h4, h5), (h5, h6)]):
                 host_t[i] += b - a
@@ -895,7 +903,7 @@ def main():
         if not getattr(extract_main, "single_launch", True):
             cands = [c for c in cands if c[1] == 1]
         for k, x in cands:
-            K, n_xs, NSLOT = k, x, k + x + 1
+            K, n_xs, NSLOT = k, x, slots_for(k, x)
             sampler.use_pipelines(k)
             slot_free[:] = [None] * len(slot_free)
             tb, first_main = measure(extract_main, trial_steps, 3, 2, first_step=first_main)
@@ -903,7 +911,7 @@ def main():
         base = cands[0]
         best = min(per, key=per.get)
         K, n_xs = best if per[best] < 0.98 * per[base] else base
-        NSLOT = K + n_xs + 1
+        NSLOT = slots_for(K, n_xs)
         sampler.use_pipelines(K)
         slot_free[:] = [None] * len(slot_free)
         pipes_trial = {"ms_per_step": {f"{k} pipeline(s), {x} extract stream(s)": v for (k, x), v in per.items()},
