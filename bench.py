@@ -240,6 +240,22 @@ def cpu_baseline(graph, fanouts, batch, feat, seconds):
     }
 
 
+def slots_for(pipelines, extract_streams):
+    """Batch slots for `pipelines` sampling pipelines and `extract_streams` extract streams: one per batch that can be
+    in flight + one spare (the sampler may run one batch further ahead: - 1 % on the default workload,
+    profiles/r05_ab_slots_two_streams.txt), rounded up to a multiple of the pipelines -- a slot's next user then runs
+    on the sampling stream that gathered the slot's labels and needs no cross-stream wait for them."""
+    return (pipelines + extract_streams + 1 + pipelines - 1) // pipelines * pipelines
+
+
+def choose_streams(ms_per_step, margin=0.02):
+    """The streams trial's verdict.  ms_per_step: {(pipelines, extract streams): ms} in candidate order, baseline first.
+    The baseline stays unless the fastest candidate is at least `margin` faster."""
+    cands = list(ms_per_step)
+    best = min(cands, key=ms_per_step.get)
+    return best if ms_per_step[best] < (1.0 - margin) * ms_per_step[cands[0]] else cands[0]
+
+
 def launch_ranks(args):
     """`python bench.py --gpus N` (N > 1) started as a plain script: become the launcher of N ranks, one per GPU --
     `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 bench.py <same flags>` as a
@@ -682,8 +698,6 @@ def main():
     n_xs = 1 if args.no_overlap else (args.extract_streams or (2 if auto_pipes else 1))
     # batch slots: one per batch that can be in flight + one spare (the sampler may run one batch further ahead: - 1 % on the
     # default workload, profiles/r05_ab_slots_two_streams.txt); allocated for the largest candidate of the trial
-    def slots_for(k, x):  # ... rounded up to a multiple of k: a slot's next user then runs on the same sampling stream
-        return (k + x + 1 + k - 1) // k * k
     NSLOT = args.slots if args.slots else (max(slots_for(1, 2), slots_for(2, 1)) if auto_pipes and not khop0 else slots_for(K, n_xs))
     sampler = ops.BatchSampler(g, fanouts, args.batch, sample_type=code, seed=0x5EED + rank, device=dev,
                                num_slots=NSLOT, num_pipelines=K, **extra_kw)
@@ -898,7 +912,7 @@ def main():
     pipes_trial, first_main = None, 0
     if auto_pipes:
         # every rank sees the same (max-over-ranks) times and takes the same turn
-        trial_steps, per, base = 12, {}, None
+        trial_steps, per = 12, {}
         cands = [(2, 1), (2, 2)] if khop0 else [(1, 1), (1, 2), (2, 1)]  # (sampling pipelines, extract streams); baseline first
         if not getattr(extract_main, "single_launch", True):
             cands = [c for c in cands if c[1] == 1]
@@ -908,9 +922,7 @@ def main():
             slot_free[:] = [None] * len(slot_free)
             tb, first_main = measure(extract_main, trial_steps, 3, 2, first_step=first_main)
             per[(k, x)] = min(b["elapsed"] for b in tb) / trial_steps * 1e3  # the better of two blocks
-        base = cands[0]
-        best = min(per, key=per.get)
-        K, n_xs = best if per[best] < 0.98 * per[base] else base
+        K, n_xs = choose_streams(per)
         NSLOT = slots_for(K, n_xs)
         sampler.use_pipelines(K)
         slot_free[:] = [None] * len(slot_free)

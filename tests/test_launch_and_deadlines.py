@@ -365,3 +365,21 @@ def test_link_probe_plumbing_two_ranks(tmp_path, mode):
         else:
             # copy: 100 * reader + (owner + 1); gather: 10 * reader + (owner + 1); inbound: 10 * reader + (peer + 1)
             assert "REC [[1.0, 2.0], [101.0, 102.0]] [[1.0, 2.0], [11.0, 12.0]] [2.0, 11.0] 2.0 2.0" in out
+
+
+def test_streams_trial_verdict_and_slot_counts():
+    """bench.py's host logic around the streams trial (no GPU): the baseline stays unless another candidate is at least
+    2 % faster; batch slots = batches in flight + one spare, a multiple of the sampling pipelines."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)  # (imports numpy only: torch is imported inside main())
+    assert bench.choose_streams({(1, 1): 0.700, (1, 2): 0.690, (2, 1): 0.710}) == (1, 1)   # 1.4 %: not enough
+    assert bench.choose_streams({(1, 1): 0.700, (1, 2): 0.650, (2, 1): 0.640}) == (2, 1)
+    assert bench.choose_streams({(1, 1): 0.300, (1, 2): 0.301, (2, 1): 0.320}) == (1, 1)
+    assert bench.choose_streams({(2, 1): 0.380, (2, 2): 0.369}) == (2, 2)
+    assert [bench.slots_for(*kx) for kx in ((1, 1), (1, 2), (2, 1), (2, 2))] == [3, 4, 4, 6]
+    for k in (1, 2, 3):
+        for x in (1, 2):
+            n = bench.slots_for(k, x)
+            assert n >= k + x + 1 and n % k == 0
