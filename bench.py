@@ -684,7 +684,7 @@ def main():
     # batches in flight: K sampling pipelines (own stream, dedup table, workspace; RNG pool consumed in batch
     # order) + the extract stream; outputs live in batch slots, as in the engine
     # Default (no --pipelines / --extract-streams / --slots): (sampling pipelines, extract streams) = (1, 1), (1, 2), (2, 1)
-    # -- khop0, whose batches need no shared generator pool: (2, 1), (2, 2) -- are TRIED before the timed region (two blocks
+    # -- khop0, whose batches need no shared generator pool: (2, 2), (2, 1) -- are TRIED before the timed region (two blocks
     # of 12 steps each, outside it); the first one stays unless another is at least 2 % faster.  Two sampling chains fill
     # each other's latency gaps on small frontiers (papers100M [25,10]: 0.19 -> 0.165 ms/step) and only add memory-side
     # contention on large ones (profiles/r05_ab_pipelines.txt); two extract streams let consecutive batches' gathers
@@ -913,7 +913,9 @@ def main():
     if auto_pipes:
         # every rank sees the same (max-over-ranks) times and takes the same turn
         trial_steps, per = 12, {}
-        cands = [(2, 1), (2, 2)] if khop0 else [(1, 1), (1, 2), (2, 1)]  # (sampling pipelines, extract streams); baseline first
+        # (sampling pipelines, extract streams); baseline first -- khop0's is (2, 2): 2-3 % ahead of (2, 1) in every pairing
+        # of profiles/r05_ab_extract_streams.txt, which a 2 % margin would decide by the box's noise
+        cands = [(2, 2), (2, 1)] if khop0 else [(1, 1), (1, 2), (2, 1)]
         if not getattr(extract_main, "single_launch", True):
             cands = [c for c in cands if c[1] == 1]
         for k, x in cands:
