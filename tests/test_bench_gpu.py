@@ -56,6 +56,8 @@ def test_single_gpu_line():
     en = d["engine"]
     assert "error" not in en, en
     assert en["ms_per_step"] > 0 and en["edges_per_s"] > 0 and en["feature_GBps"] > 0 and en["steps"] == 8
+    # two extract streams: the epoch's copy time counts the streams' BUSY time once, not every gather's own duration
+    assert 0 < en["log_items"]["kLogEpochCopyTime"] <= 1.05 * en["wall_s"], en
 
 
 def test_single_gpu_line_carries_its_box_the_other_configs_and_the_staged_host_tier():
