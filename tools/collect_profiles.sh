@@ -4,6 +4,7 @@
 #        (then: python tools/summarize_profiles.py gpurun_out/profiles_<tag> profiles/<round>)
 TAG=${1:-r02}; shift
 OUT=$GRAFT_REPO_ROOT/gpurun_out/profiles_$TAG
+rm -rf $OUT  # (a directory of an earlier collection would leave its files beside the new ones)
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 BENCH=$GRAFT_REPO_ROOT/bench.py
