@@ -23,7 +23,8 @@ def one(pattern):
     """The file of the BENCH process: the default command also runs the `engine` sub-record in a child process, which
     rocprofv3 traces into files of its own (another pid).  Only the bench process launches k_fabric_probe
     (roofline_sampler) and the IdentRows gather; the child is recognised by their absence."""
-    f = sorted(glob.glob(pattern))
+    # newest first: gpurun MERGES a call's files into the local gpurun_out/, so an earlier collection's files may lie beside
+    f = sorted(glob.glob(pattern), key=os.path.getmtime, reverse=True)
     if not f:
         raise SystemExit(f"missing {pattern}")
     for cand in f:
